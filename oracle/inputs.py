@@ -1,0 +1,62 @@
+"""oracle/inputs.py -- TEST INFRASTRUCTURE: seeded synthetic spectra shared by the golden
+generator, the tests and bench.py (CPU generator => identical on every host with the same torch).
+Distributions follow SURVEY.md §8(d): uniform U[0,1), "peaky" U^8 (close to real harmonic
+spectra), dyadic k/32 (row sums exact in fp32 under ANY summation order), and edge rows."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+import torch
+
+
+def gen_inputs(kind, B, n, m, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, n, generator=g)
+    y = torch.rand(B, m, generator=g)
+    if kind == "uniform":
+        pass
+    elif kind == "peaky":
+        x, y = x ** 8, y ** 8
+    elif kind == "dyadic":
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randint(0, 32, (B, n), generator=g).float() / 32
+        y = torch.randint(0, 32, (B, m), generator=g).float() / 32
+    elif kind == "edge":  # zero rows, Diracs, zero-weight runs, identical rows, sub-eps mass
+        x, y = x ** 4, y ** 4
+        x[0] = 0.0                                 # all-zero x row
+        if B > 1:
+            y[1] = 0.0                             # all-zero y row
+        if B > 2:
+            x[2] = 0.0
+            x[2, n // 3] = 1.0                     # Dirac vs Dirac
+            y[2] = 0.0
+            y[2, (2 * m) // 3] = 2.5
+        if B > 3:
+            y[3, : m // 2] = 0.0                   # leading zero-weight run
+            x[3, n // 2:] = 0.0                    # trailing zero-weight run
+        if B > 4 and n == m:
+            y[4] = x[4]                            # identical distributions
+        if B > 5:
+            x[5] = x[5] * 1e-9                     # mass below the 1e-7 guard of safe_divide
+    else:
+        raise ValueError(kind)
+    return x.contiguous(), y.contiguous()
+
+
+def positions(spec, n):
+    """Position grids named in the manifest."""
+    if spec == "linspace":
+        return torch.linspace(0, 1, n)
+    if spec.startswith("rfftfreq"):
+        nfft = 2 * (n - 1)
+        pos = torch.fft.rfftfreq(nfft, 1 / 16000.0)
+        return (pos / pos.max()).float()
+    raise ValueError(spec)
+
+
+def sha256_of(*tensors) -> str:
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.numpy()).tobytes())
+    return h.hexdigest()
