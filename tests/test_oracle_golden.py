@@ -101,7 +101,7 @@ def test_oracle_backward_matches_reference_autograd(name, manifest):
     sx, sy = torch.autograd.grad(loss, [xt, yt])
     for got, stable, ref in ((gx, sx.numpy(), g["grad_x"].reshape(gx.shape)),
                              (gy, sy.numpy(), g["grad_y"].reshape(gy.shape))):
-        tol = 2e-6 * np.abs(stable).max(axis=1, keepdims=True) + 1e-12
+        tol = 2e-6 * np.abs(stable).max(axis=1, keepdims=True) + 3e-8  # 3e-8: fp32 cancellation noise of autograd on zero-gradient rows
         assert (np.abs(got - stable) <= tol).all(), name
         assert (np.abs(got - ref) <= tol)[rows_ok].all(), name
 
