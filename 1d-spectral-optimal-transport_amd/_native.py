@@ -1,0 +1,250 @@
+"""ctypes binding of libsot_hip.so (include/sot_hip.h).  PyTorch supplies device memory and
+streams only; every computation on the hot path happens inside the HIP library.
+
+There is deliberately NO fallback: if the library is missing or a tensor is not on a HIP device
+the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import build as _build
+
+FLAG_SQUARE = 1
+FLAG_DONT_NORMALIZE = 2
+FLAG_LIMIT_Q = 4
+FLAG_REQUIRE_SORT = 8
+
+SOT_OK = 0
+SOT_ERR_INVALID_P = -1
+
+_vp = ctypes.c_void_p
+
+
+class SotProblem(ctypes.Structure):
+    _fields_ = [("x", _vp), ("y", _vp), ("xpos", _vp), ("ypos", _vp),
+                ("B", ctypes.c_int64), ("n", ctypes.c_int32), ("m", ctypes.c_int32),
+                ("x_row_stride", ctypes.c_int64), ("y_row_stride", ctypes.c_int64),
+                ("xpos_row_stride", ctypes.c_int64), ("ypos_row_stride", ctypes.c_int64),
+                ("p", ctypes.c_float), ("flags", ctypes.c_uint32),
+                ("xperm", _vp), ("yperm", _vp), ("perm_is_identity", _vp)]
+
+
+EXPORTS = {
+    "sot_abi_version": (ctypes.c_int, []),
+    "sot_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "sot_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(SotProblem)]),
+    "sot_prepare_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sot_w1d_forward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, ctypes.c_size_t, _vp]),
+    "sot_w1d_reduce_mean": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_float,
+                                           _vp, _vp, _vp]),
+    "sot_w1d_backward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "sot_w1d_quantiles": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, _vp, _vp,
+                                         ctypes.c_size_t, _vp]),
+    "sot_segmented_sort": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load libsot_hip.so; raises if it cannot be found/built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            if not build_if_missing:
+                raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (build()) first")
+            _build.build()
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)  # AttributeError here = ABI mismatch, reported loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sot_abi_version() != 1:
+            raise RuntimeError("libsot_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+class SotError(RuntimeError):
+    pass
+
+
+def check(rc: int, p=None):
+    if rc == SOT_OK:
+        return
+    if rc == SOT_ERR_INVALID_P:  # same exception type and text as losses.py:271
+        raise AssertionError(f"The OT loss is only valid for p>=1, {p} was given")
+    raise SotError(f"libsot_hip: {load().sot_status_string(rc).decode()} (status {rc})")
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "sot_amd is the MI355X HIP implementation of the SOT loss and has no CPU path: got a "
+                f"{t.device} tensor. Move inputs to the GPU (torch device 'cuda' on ROCm).")
+        if t.dtype != torch.float32:
+            raise TypeError(f"sot_amd computes in float32; got {t.dtype} (convert with .float())")
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def rows_view(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 view with unit inner stride (copies only if the inner dim is strided)."""
+    if t.stride(-1) != 1 and t.shape[-1] > 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def make_problem(x, y, xpos, ypos, p, flags, plan=None) -> SotProblem:
+    B, n = x.shape
+    m = y.shape[1]
+    pr = SotProblem()
+    pr.x, pr.y = x.data_ptr(), y.data_ptr()
+    pr.B, pr.n, pr.m = B, n, m
+    pr.x_row_stride = x.stride(0) if B > 1 else n
+    pr.y_row_stride = y.stride(0) if B > 1 else m
+    pr.p, pr.flags = float(p), int(flags)
+    if plan is not None:
+        pr.xpos, pr.ypos = plan.xpos_sorted.data_ptr(), plan.ypos_sorted.data_ptr()
+        pr.xperm, pr.yperm = plan.xperm.data_ptr(), plan.yperm.data_ptr()
+        pr.perm_is_identity = plan.ident.data_ptr()
+        pr.xpos_row_stride = pr.ypos_row_stride = 0
+    else:
+        pr.xpos, pr.ypos = xpos.data_ptr(), ypos.data_ptr()
+        pr.xpos_row_stride = 0 if xpos.ndim == 1 else (xpos.stride(0) if B > 1 else n)
+        pr.ypos_row_stride = 0 if ypos.ndim == 1 else (ypos.stride(0) if B > 1 else m)
+        pr.xperm = pr.yperm = pr.perm_is_identity = None
+    return pr
+
+
+class PositionPlan:
+    """Sorted shared positions + permutation + identity flags (sot_prepare_positions)."""
+
+    def __init__(self, xpos: torch.Tensor, ypos: torch.Tensor):
+        require_hip(xpos, ypos)
+        lib = load()
+        n, m = xpos.numel(), ypos.numel()
+        dev = xpos.device
+        self.xpos_sorted = torch.empty(n, dtype=torch.float32, device=dev)
+        self.ypos_sorted = torch.empty(m, dtype=torch.float32, device=dev)
+        self.xperm = torch.empty(n, dtype=torch.int32, device=dev)
+        self.yperm = torch.empty(m, dtype=torch.int32, device=dev)
+        self.ident = torch.empty(2, dtype=torch.int32, device=dev)
+        xp, yp = xpos.contiguous(), ypos.contiguous()
+        with torch.cuda.device(dev):
+            check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
+                                            self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
+                                            self.yperm.data_ptr(), self.ident.data_ptr(), stream_ptr(dev)))
+
+
+def workspace(pr: SotProblem, device) -> torch.Tensor:
+    nbytes = load().sot_workspace_bytes(ctypes.byref(pr))
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+def forward_rows(x, y, xpos, ypos, p, flags, plan=None, out=None) -> torch.Tensor:
+    """row_loss[B] = W_p^p per row (sot_w1d_forward)."""
+    lib = load()
+    dev = x.device
+    B = x.shape[0]
+    row_loss = out if out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    ws = workspace(pr, dev) if need_ws else None
+    with torch.cuda.device(dev):
+        rc = lib.sot_w1d_forward(ctypes.byref(pr), row_loss.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0,
+                                 stream_ptr(dev))
+    check(rc, p)
+    return row_loss
+
+
+def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False):
+    lib = load()
+    dev = row_loss.device
+    B = row_loss.numel()
+    mean = torch.empty((), dtype=torch.float32, device=dev)
+    total = torch.empty((), dtype=torch.float64, device=dev) if want_sum else None
+    with torch.cuda.device(dev):
+        check(lib.sot_w1d_reduce_mean(row_loss.data_ptr(), B, float(B if denom is None else denom),
+                                      0 if hinge is None else 1, 0.0 if hinge is None else float(hinge),
+                                      mean.data_ptr(), _ptr(total), stream_ptr(dev)))
+    return (mean, total) if want_sum else mean
+
+
+def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=True, plan=None):
+    lib = load()
+    dev = x.device
+    B, n = x.shape
+    m = y.shape[1]
+    gx = torch.empty(B, n, dtype=torch.float32, device=dev) if need_gx else None
+    gy = torch.empty(B, m, dtype=torch.float32, device=dev) if need_gy else None
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    ws = workspace(pr, dev) if need_ws else None
+    g = grad_row.contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.sot_w1d_backward(ctypes.byref(pr), g.data_ptr(), _ptr(gx), _ptr(gy), _ptr(ws),
+                                  ws.numel() if ws is not None else 0, stream_ptr(dev))
+    check(rc, p)
+    return gx, gy
+
+
+def quantiles(x, y, xpos, ypos, p, flags, plan=None):
+    lib = load()
+    dev = x.device
+    B, n = x.shape
+    m = y.shape[1]
+    K = n + m
+    uq = torch.empty(B, K, dtype=torch.float32, device=dev)
+    vq = torch.empty(B, K, dtype=torch.float32, device=dev)
+    Q = torch.empty(B, K, dtype=torch.float32, device=dev)
+    U = torch.empty(B, n, dtype=torch.float32, device=dev)
+    V = torch.empty(B, m, dtype=torch.float32, device=dev)
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    ws = workspace(pr, dev) if need_ws else None
+    with torch.cuda.device(dev):
+        rc = lib.sot_w1d_quantiles(ctypes.byref(pr), uq.data_ptr(), vq.data_ptr(), Q.data_ptr(), U.data_ptr(),
+                                   V.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
+    check(rc, p)
+    return uq, vq, Q, U, V
+
+
+def segmented_sort(keys: torch.Tensor):
+    """(values, int64 indices) of a per-row ascending stable sort (sot_segmented_sort)."""
+    require_hip(keys)
+    lib = load()
+    keys = rows_view(keys)
+    B, n = keys.shape
+    vals = torch.empty(B, n, dtype=torch.float32, device=keys.device)
+    idx = torch.empty(B, n, dtype=torch.int64, device=keys.device)
+    with torch.cuda.device(keys.device):
+        check(lib.sot_segmented_sort(keys.data_ptr(), B, n, keys.stride(0) if B > 1 else n, vals.data_ptr(),
+                                     idx.data_ptr(), stream_ptr(keys.device)))
+    return vals, idx

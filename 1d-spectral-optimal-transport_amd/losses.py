@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference's loss interface for the SOT hot path.
+
+Same names, argument meaning and error behaviour as the reference's ``losses`` module
+(/root/reference/losses.py): ``Wasserstein1D`` (:89-211), ``quantile_function`` (:214-220),
+``wasserstein_1d`` (:223-313), ``MixOfLosses`` (:346-362) and ``utils.safe_divide``
+(utils.py:135-142), so ``trainer.py:220/228``, ``metrics.py:148`` and the YAML
+``class_path: losses.Wasserstein1D`` keep working unchanged.
+
+All arithmetic on the path runs in the hand-written HIP library (csrc/, C ABI in
+include/sot_hip.h); this file only reshapes, marshals pointers and wires autograd.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as nat
+
+__all__ = ["Wasserstein1D", "wasserstein_1d", "quantile_function", "MixOfLosses", "safe_divide"]
+
+FLAG_PRENORMALIZED = 16  # weights are used as given (the functional form wasserstein_1d)
+
+
+def safe_divide(numerator, denominator, eps=1e-7):
+    """utils.py:135-142 -- kept for API compatibility (the fused kernel applies the same guard)."""
+    safe_denominator = torch.where(denominator <= eps,
+                                   torch.tensor(eps, dtype=torch.float32, device=denominator.device), denominator)
+    return numerator / safe_denominator
+
+
+def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized=False):
+    return ((nat.FLAG_SQUARE if square_dist else 0) | (nat.FLAG_DONT_NORMALIZE if dont_normalize else 0)
+            | (nat.FLAG_LIMIT_Q if limit_quantile_range else 0) | (nat.FLAG_REQUIRE_SORT if require_sort else 0)
+            | (FLAG_PRENORMALIZED if prenormalized else 0))
+
+
+class _RowLoss(torch.autograd.Function):
+    """rows[B] = W_p^p per spectrum pair; backward = closed-form HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, y, xpos, ypos, p, flags, plan):
+        rows = nat.forward_rows(x, y, xpos, ypos, p, flags, plan)
+        ctx.save_for_backward(x, y, xpos, ypos)
+        ctx.p, ctx.flags, ctx.plan = p, flags, plan
+        return rows
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        x, y, xpos, ypos = ctx.saved_tensors
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise NotImplementedError("gradients w.r.t. support positions are not implemented "
+                                      "(no reference call site uses them)")
+        gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, grad_rows.float(),
+                                   need_gx=ctx.needs_input_grad[0], need_gy=ctx.needs_input_grad[1], plan=ctx.plan)
+        return gx, gy, None, None, None, None, None
+
+
+class _RowMean(torch.autograd.Function):
+    """losses.py:211 with dims=None: fixed-order fp64 accumulation on the GPU."""
+
+    @staticmethod
+    def forward(ctx, rows):
+        ctx.count = rows.numel()
+        return nat.reduce_mean(rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.count).expand(ctx.count)
+
+
+class _PlanCache:
+    """Position plans keyed by tensor identity+version, so a persistent grid is sorted once."""
+
+    def __init__(self, capacity=4):
+        self.capacity = capacity
+        self.entries = []  # (key, xpos_ref, ypos_ref, plan)
+
+    def get(self, xpos, ypos):
+        key = (xpos.data_ptr(), ypos.data_ptr(), xpos.numel(), ypos.numel(), xpos._version, ypos._version,
+               xpos.device)
+        for k, _, _, plan in self.entries:
+            if k == key:
+                return plan
+        plan = nat.PositionPlan(xpos.detach(), ypos.detach())
+        self.entries.append((key, xpos, ypos, plan))  # tensor refs pin the storage behind data_ptr
+        if len(self.entries) > self.capacity:
+            self.entries.pop(0)
+        return plan
+
+
+def _prepare(x, y, xpos, ypos):
+    """Common marshalling: 2-D fp32 HIP rows and matching positions."""
+    nat.require_hip(x, y, xpos, ypos)
+    if x.ndim != 2 or y.ndim != 2:
+        raise ValueError(f"expected 2-D [rows, features] weights, got {tuple(x.shape)} and {tuple(y.shape)}")
+    if x.shape[0] != y.shape[0]:
+        raise RuntimeError(f"row count mismatch: {x.shape[0]} vs {y.shape[0]}")
+    x, y = nat.rows_view(x), nat.rows_view(y)
+    if xpos.shape[-1] != x.shape[1] or ypos.shape[-1] != y.shape[1]:
+        raise RuntimeError("positions and weights must have the same number of features")
+    if (xpos.ndim == 1) != (ypos.ndim == 1):  # mixed: materialise the shared row for every batch row
+        if xpos.ndim == 1:
+            xpos = xpos.unsqueeze(0).expand_as(x)
+        else:
+            ypos = ypos.unsqueeze(0).expand_as(y)
+    if xpos.ndim == 2:
+        if xpos.shape[0] != x.shape[0] or ypos.shape[0] != y.shape[0]:
+            raise RuntimeError("per-row positions must have one row per weight row")
+        xpos, ypos = xpos.contiguous(), ypos.contiguous()
+    else:
+        xpos, ypos = xpos.contiguous(), ypos.contiguous()
+    return x, y, xpos, ypos
+
+
+_functional_plans = _PlanCache()
+
+
+def quantile_function(qs, cws, xs):
+    """losses.py:214-220.  Compatibility helper only: inside this package the inverse-CDF lookup is
+    fused into the merge kernel and this function is never called on the hot path."""
+    n = xs.shape[1]
+    idx = torch.searchsorted(cws, qs)
+    return torch.take_along_dim(xs, torch.clamp(idx, 0, n - 1), dim=1)
+
+
+def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, require_sort=True,
+                   return_quantiles=False, limit_quantile_range=False):
+    """losses.py:223-313: W_p^p per row of two discrete measures (weights used as given)."""
+    assert p >= 1, f"The OT loss is only valid for p>=1, {p} was given"
+    n, m = u_values.shape[1], v_values.shape[1]
+    if u_weights is None:
+        u_weights = torch.full(u_values.shape, 1.0 / n, device=u_values.device, dtype=u_values.dtype)
+    if v_weights is None:
+        v_weights = torch.full(v_values.shape, 1.0 / m, device=v_values.device, dtype=v_values.dtype)
+    # stride-0 expanded positions (losses.py:167-170) are passed down as one shared row
+    def shared_row(t):
+        return t[0] if (t.ndim == 2 and t.shape[0] > 1 and t.stride(0) == 0) else t
+    upos, vpos = shared_row(u_values), shared_row(v_values)
+    x, y, upos, vpos = _prepare(u_weights, v_weights, upos, vpos)
+    flags = _flags(False, False, limit_quantile_range, require_sort, prenormalized=True)
+    plan = _functional_plans.get(upos, vpos) if (require_sort and upos.ndim == 1) else None
+    if return_quantiles:
+        return nat.quantiles(x, y, upos, vpos, p, flags, plan)
+    return _RowLoss.apply(x, y, upos, vpos, float(p), flags, plan)
+
+
+class Wasserstein1D(torch.nn.Module):
+    """Drop-in for losses.Wasserstein1D (losses.py:89-211); see that docstring for the arguments."""
+
+    def __init__(self, p=1, fixed_x=None, require_sort=True, log_scaled_x=False, **kwargs):
+        super().__init__()
+        self.p = p
+        self.require_sort = require_sort
+        self.log_scaled_x = log_scaled_x  # flag only, like the reference (trainer.py:187 reads it)
+        self.dont_normalize = kwargs.get("dont_normalize", False)
+        self.limit_quantile_range = kwargs.get("limit_quantile_range", False)
+        self.hinge = kwargs.get("hinge", False)
+        self.square_dist = kwargs.get("square_dist", False)
+        # unknown kwargs (e.g. cumsum_only from the paper YAMLs) are accepted and ignored, losses.py:96
+        if fixed_x is not None:
+            self.register_buffer("fixed_x", torch.linspace(0, 1, fixed_x))
+        else:
+            self.register_buffer("fixed_x", None)
+        self._plans = _PlanCache()
+
+    def _marshal(self, x, y, x_pos, y_pos, kwargs):
+        if (x_pos is None or y_pos is None) and self.fixed_x is None:
+            raise ValueError("If fixed_x is not provided, x_pos and y_pos must be provided")
+        assert self.p >= 1, f"The OT loss is only valid for p>=1, {self.p} was given"  # losses.py:271
+
+        x_pos_ = self.fixed_x if x_pos is None else x_pos
+        y_pos_ = self.fixed_x if y_pos is None else y_pos
+
+        original_shape = x.shape[:-1]
+        if x.ndim == 3:
+            x = x.reshape(-1, x.shape[-1])
+        if y.ndim == 3:
+            y = y.reshape(-1, y.shape[-1])
+        if x_pos_.ndim == 3:
+            x_pos_ = x_pos_.reshape(-1, x_pos_.shape[-1])
+        if y_pos_.ndim == 3:
+            y_pos_ = y_pos_.reshape(-1, y_pos_.shape[-1])
+
+        dont_normalize = bool(kwargs.get("dont_normalize", False) or self.dont_normalize)
+        limit_q = bool(kwargs.get("limit_quantile_range", False) or self.limit_quantile_range)
+        flags = _flags(self.square_dist, dont_normalize, limit_q, self.require_sort)
+
+        x, y, x_pos_, y_pos_ = _prepare(x, y, x_pos_, y_pos_)
+        plan = self._plans.get(x_pos_, y_pos_) if (self.require_sort and x_pos_.ndim == 1) else None
+        return x, y, x_pos_, y_pos_, flags, plan, original_shape
+
+    def row_losses(self, x, y, x_pos=None, y_pos=None, **kwargs):
+        """Flat [rows] tensor of W_p^p per spectrum pair (after the optional hinge, before the mean):
+        what losses.py:186-205 holds before its reshape/mean.  Used by the row-sharded multi-GPU path."""
+        x, y, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
+        loss = _RowLoss.apply(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
+        if self.hinge:
+            loss = torch.nn.functional.relu(loss - kwargs.get("hinge", 0.0))
+        return loss
+
+    def forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
+        if kwargs.get("return_quantiles", False):
+            x2, y2, x_pos_, y_pos_, flags, plan, original_shape = self._marshal(x, y, x_pos, y_pos, kwargs)
+            out = nat.quantiles(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
+            return [t.reshape(original_shape + (-1,)) for t in out]
+
+        original_shape = x.shape[:-1]
+        loss = self.row_losses(x, y, x_pos, y_pos, **kwargs)
+        dims = kwargs.get("dims", None)
+        if dims is None:
+            return _RowMean.apply(loss)  # torch.mean over every row -> 0-d tensor (losses.py:211)
+        loss = loss.reshape(original_shape)
+        return torch.mean(loss, dim=dims)
+
+
+class MixOfLosses(torch.nn.Module):
+    """losses.py:346-362: weighted dict of losses keyed by class name."""
+
+    def __init__(self, losses, weights=None):
+        super().__init__()
+        self.losses = losses
+        self.weights = weights
+
+    def forward(self, x, y, **kwargs):
+        loss = {}
+        for loss_fn, weight in zip(self.losses, self.weights):
+            loss_ = loss_fn(x, y, **kwargs) * weight
+            loss[loss_fn.__class__.__name__] = loss_
+        return loss

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- SOT-loss evaluations/s on [B, N_fft] spectrum pairs (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic spectrum pairs already resident in
+HBM: Wasserstein1D forward (fused HIP kernel + fixed-order mean).  With N>1 every rank owns its own
+B rows (weak scaling, no data-path collective) and the step ends with ONE RCCL all-reduce of the
+scalar partial sum.  Inputs rotate over several distinct sets so that the 256 MiB Infinity Cache
+cannot serve them.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- dominant kernel (sot_forward_kernel): algorithmic bytes per launch / average launch
+                  duration measured with HIP events on the launch stream inside the timed region;
+  cpu_baseline -- the op-for-op torch restatement of the reference (oracle/torch_restatement.py,
+                  kind "port") timed on this host's cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MODES = {
+    "p1": dict(p=1),  # north_star: L1-normalised Wasserstein-1
+    "cutoff": dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True),  # paper SOT-2048
+    "nocut": dict(p=2, square_dist=True),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md "Chip-level parameters": HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=8192, help="rows (spectrum pairs) per GPU")
+    ap.add_argument("--nfft", type=int, default=2048, help="row length N")
+    ap.add_argument("--mode", choices=list(MODES), default="p1")
+    ap.add_argument("--sets", type=int, default=6, help="distinct rotating input sets (>= 4 defeats the 256 MiB L3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=2048)
+    return ap.parse_args()
+
+
+def cpu_baseline(mode, n, rows, seed):
+    """The reference's CPU PyTorch path (op-for-op restatement), all host cores, bounded sample."""
+    from oracle import torch_restatement as tr
+    from oracle.inputs import gen_inputs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, y = gen_inputs("uniform", rows, n, n, seed)
+    pos = torch.linspace(0, 1, n)
+    c = MODES[mode]
+    kw = dict(p=c.get("p", 1), square_dist=c.get("square_dist", False), dont_normalize=c.get("dont_normalize", False),
+              limit_quantile_range=c.get("limit_quantile_range", False))
+    with torch.no_grad():
+        tr.sot_loss(x, y, pos, pos.clone(), **kw)  # warm-up
+        best = float("inf")
+        t_end = time.perf_counter() + 20.0
+        reps = 0
+        while reps < 5 and time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            val = tr.sot_loss(x, y, pos, pos.clone(), **kw)
+            best = min(best, time.perf_counter() - t0)
+            reps += 1
+    return {"value": rows / best, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} rows x N={n}, mode {mode}, best of {reps} calls of oracle/torch_restatement.sot_loss "
+                      f"(torch {torch.__version__} CPU, {cores} threads)", "scalar": float(val)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from sot_amd import _native as nat
+    from sot_amd.distributed import global_mean_from_local_sum
+    from sot_amd.losses import Wasserstein1D
+    from oracle.inputs import gen_inputs
+
+    nat.load(build_if_missing=False)  # must be the prebuilt in-tree library
+    B, N = args.rows, args.nfft
+    mod = Wasserstein1D(**MODES[args.mode]).to(dev)
+    pos_x = torch.linspace(0, 1, N, device=dev)
+    pos_y = pos_x.clone()
+
+    # set 0: the BASELINE recipe (CPU generator, seed 1234 + rank, x drawn before y); others: device RNG
+    x0, y0 = gen_inputs("uniform", B, N, N, 1234 + rank)
+    sets = [(x0.to(dev), y0.to(dev))]
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    for _ in range(args.sets - 1):
+        sets.append((torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)))
+
+    def step(i, profile=None):
+        x, y = sets[i % len(sets)]
+        with torch.no_grad():
+            if world == 1:
+                if profile is not None:
+                    a, b = profile
+                    a.record()
+                rows = mod.row_losses(x, y, x_pos=pos_x, y_pos=pos_y)
+                if profile is not None:
+                    b.record()
+                return nat.reduce_mean(rows)
+            if profile is not None:
+                a, b = profile
+                a.record()
+            rows = mod.row_losses(x, y, x_pos=pos_x, y_pos=pos_y)
+            if profile is not None:
+                b.record()
+            _, local_sum = nat.reduce_mean(rows, want_sum=True)
+            return global_mean_from_local_sum(local_sum, B)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        out = step(i)
+    first = float(step(0))  # parity value on set 0
+    torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i, events[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    del out
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    bytes_per_row = 4 * (N + N) + 4  # fwd, shared positions
+    achieved = bytes_per_row * B / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        parity = None
+        try:
+            man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+            if (B, N) == (8192, 2048):
+                want = man["_config2_b8192n2048_seed1234"][f"uniform_{args.mode}"]
+                parity = abs(first - want) / abs(want)
+        except Exception:
+            parity = None
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
+            if pj.get("workload") == f"B={B},N={N},{args.mode}":
+                traffic = pj["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        rec = {
+            "metric": "sot_loss_evals_per_sec", "value": world * B * args.steps / elapsed, "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SOT-2048 config: B={B} rows/GPU x N_fft={N} fp32 spectrum pairs, forward, mode {args.mode} "
+                                   f"({json.dumps(MODES[args.mode])}), shared linspace positions, {len(sets)} rotating input sets "
+                                   f"({len(sets) * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",
+                       "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "global_rows": world * B,
+                       "collective": "none" if world == 1 else "one RCCL all-reduce of a 2-element fp64 tensor (sum, rows) per step",
+                       "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "sot_forward_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args.mode, N, min(args.cpu_rows, B), 1234)
+        print(json.dumps(rec), flush=True)
+    barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * sot_hip.h -- C ABI of libsot_hip.so, the MI355X (gfx950) implementation of the
+ * 1-D spectral optimal-transport loss.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference is pure
+ * Python on PyTorch (no FFI of its own), so each entry point replaces a *composition of
+ * ATen ops* in the reference; the Python binding a maintainer adds is shown in
+ * INTEGRATION.md (ctypes; the shipped host-side mirror is
+ * 1d-spectral-optimal-transport_amd/losses.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated;
+ *   - the caller owns and allocates everything (outputs and workspace); functions only
+ *     enqueue work on `stream` (a hipStream_t passed as void*; NULL = default stream):
+ *     no allocation, no host synchronisation, graph-capturable;
+ *   - return value: SOT_OK (0) or a negative sot_status; nothing aborts, nothing is
+ *     enqueued when an error is returned;
+ *   - rows are independent: a caller shards a batch by passing a sub-range of rows.
+ */
+#ifndef SOT_HIP_H
+#define SOT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOT_ABI_VERSION 1
+
+typedef enum sot_status {
+    SOT_OK = 0,
+    SOT_ERR_INVALID_P = -1,        /* p < 1          -> AssertionError in the reference (losses.py:271) */
+    SOT_ERR_BAD_SHAPE = -2,        /* B < 0, n < 1, m < 1, bad strides                                 */
+    SOT_ERR_UNSUPPORTED_SIZE = -3, /* a row's working set exceeds one CU's 160 KiB LDS (n + m > ~19000) */
+    SOT_ERR_NULL_POINTER = -4,
+    SOT_ERR_WORKSPACE = -5,        /* workspace smaller than sot_workspace_bytes()                     */
+    SOT_ERR_LAUNCH = -6            /* hipGetLastError() != hipSuccess after the launch                 */
+} sot_status;
+
+/* flag bits: the keyword arguments of Wasserstein1D (losses.py:90-121, 129-196) */
+#define SOT_FLAG_SQUARE 1u         /* square_dist: weights are squared first       (losses.py:172-174) */
+#define SOT_FLAG_DONT_NORMALIZE 2u /* y is divided by the mass of x, not its own   (losses.py:180-184) */
+#define SOT_FLAG_LIMIT_Q 4u        /* levels Q_k > 1 contribute nothing            (losses.py:306-307) */
+#define SOT_FLAG_REQUIRE_SORT 8u   /* sort supports, permute weights               (losses.py:286-290) */
+#define SOT_FLAG_PRENORMALIZED 16u /* weights are used as given: the functional wasserstein_1d(u_values,
+                                      v_values, u_weights, v_weights) of losses.py:223, which does not
+                                      normalise (flags SQUARE / DONT_NORMALIZE are then ignored)       */
+
+/* One batch of spectrum pairs.  Mirrors the arguments of Wasserstein1D.forward
+ * (losses.py:129) after its [batch,time,N] -> [B,N] reshape (losses.py:157-170). */
+typedef struct sot_problem {
+    const float *x;           /* [B, n] weights of the first measure (magnitude spectrum)             */
+    const float *y;           /* [B, m] weights of the second measure                                 */
+    const float *xpos;        /* support positions of x: [n] (row stride 0) or [B, n]                 */
+    const float *ypos;        /* support positions of y: [m] (row stride 0) or [B, m]                 */
+    int64_t B;                /* rows (spectrum pairs) in this call                                   */
+    int32_t n, m;             /* support sizes (row lengths)                                          */
+    int64_t x_row_stride;     /* elements between consecutive rows of x (>= n)                        */
+    int64_t y_row_stride;     /* elements between consecutive rows of y (>= m)                        */
+    int64_t xpos_row_stride;  /* 0 = one position row shared by all rows (the stride-0 expand of      */
+    int64_t ypos_row_stride;  /*     losses.py:167-170), otherwise >= n / >= m                        */
+    float p;                  /* order of the distance, p >= 1; result is W_p^p (no root)             */
+    uint32_t flags;           /* SOT_FLAG_*                                                           */
+    /* Optional position plan from sot_prepare_positions() (shared positions only).  When
+     * perm_is_identity != NULL, xpos/ypos must be the SORTED positions that call produced and
+     * SOT_FLAG_REQUIRE_SORT costs nothing extra (no internal sort, no workspace). NULL otherwise. */
+    const int32_t *xperm;            /* [n] sort permutation of the original xpos             */
+    const int32_t *yperm;            /* [m]                                                    */
+    const int32_t *perm_is_identity; /* [2] device flags: 1 = positions were already sorted    */
+} sot_problem;
+
+int sot_abi_version(void);
+const char *sot_status_string(int status);
+
+/* Bytes of device workspace the calls below need for this problem (host-side arithmetic only). */
+size_t sot_workspace_bytes(const sot_problem *prob);
+
+/*
+ * Position plan for row-invariant supports (the 1-D x_pos/y_pos of trainer.py:192-197 and the
+ * fixed_x buffer of losses.py:124-127): checks sortedness and, if needed, sorts (position, index)
+ * pairs once (torch.sort of losses.py:287-288 on a row that is the same for every batch row).
+ * Outputs: sorted positions, int32 permutations, and two device flags.  A training loop that keeps
+ * its position grid calls this once and passes the plan in sot_problem.
+ */
+int sot_prepare_positions(const float *xpos, const float *ypos, int32_t n, int32_t m,
+                          float *xpos_sorted /* [n] */, float *ypos_sorted /* [m] */,
+                          int32_t *xperm /* [n] */, int32_t *yperm /* [m] */,
+                          int32_t *perm_is_identity /* [2] */, void *stream);
+
+/*
+ * Forward: row_loss[r] = W_p^p(x_r, y_r) for r in [0, B).
+ * Replaces Wasserstein1D.forward steps 3-5 + wasserstein_1d + quantile_function
+ * (losses.py:172-196, 214-220, 271-313): square, row mass (ATen summation order),
+ * safe_divide (utils.py:135-142), position sort + weight gather, fp64-accumulated CDFs,
+ * merge of the two CDFs (= sort(cat(U,V)) + 2x searchsorted + 2x take_along_dim), level
+ * widths, cutoff mask, |q_x - q_y|^p, weighted row sum.
+ */
+int sot_w1d_forward(const sot_problem *prob, float *row_loss /* [B] */,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Batch reduction of losses.py:211 (`torch.mean(loss)`, dims=None) with a fixed-order fp64
+ * accumulation: *mean_out = (float)(sum_r row_loss[r] / denom) and, if sum_out != NULL,
+ * *sum_out = sum_r row_loss[r] (the per-shard partial that is all-reduced across GPUs).
+ * hinge_threshold: rows are replaced by relu(row - threshold) first when apply_hinge != 0
+ * (losses.py:203-205).
+ */
+int sot_w1d_reduce_mean(const float *row_loss, int64_t B, double denom, int apply_hinge, float hinge_threshold,
+                        float *mean_out, double *sum_out, void *stream);
+
+/*
+ * Backward of the forward above w.r.t. the weights (closed form of the autograd graph of
+ * losses.py:172-313; positions receive no gradient, as in every reference call site).
+ * grad_row[r] = dL/d(row_loss[r]).  grad_x and/or grad_y may be NULL (trainer.py only needs
+ * grad_y: x is the target spectrum).  Row strides of the gradients equal n and m.
+ * Tie convention: gradients of a run of equal quantile levels go to the run's last member in
+ * stable-sort order (U before V, lower index first).
+ */
+int sot_w1d_backward(const sot_problem *prob, const float *grad_row /* [B] */,
+                     float *grad_x /* [B,n] or NULL */, float *grad_y /* [B,m] or NULL */,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * return_quantiles=True (losses.py:198-201, 299-300): the five tensors the reference returns,
+ * uq/vq/Q: [B, n+m], U: [B, n], V: [B, m]; any output pointer may be NULL.
+ */
+int sot_w1d_quantiles(const sot_problem *prob, float *uq, float *vq, float *Q, float *U, float *V,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Segmented (per-row) stable ascending sort with index payload: what torch.sort(keys, 1)
+ * returns at losses.py:287-288 (indices are int64 like torch's; bit-identical to torch on
+ * distinct keys; ties keep the lower index first).  row_stride in elements; outputs are
+ * dense [B, n].  Either output may be NULL.
+ */
+int sot_segmented_sort(const float *keys, int64_t B, int32_t n, int64_t row_stride,
+                       float *sorted_keys, int64_t *indices, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOT_HIP_H */

@@ -1,0 +1,283 @@
+"""-m gpu: the HIP path (through the C ABI) against the golden vectors captured from the reference
+and against the CPU oracle on identical inputs.
+
+Tolerances (BASELINE north_star: 1e-5 relative fp32, sort indices bit-exact):
+  * per-row loss and batch mean: rel <= 1e-5 -- in practice the row mass S and the CDFs are
+    bit-identical to the reference's and rows differ by a few ulp of summation order;
+  * CDFs U, V / levels Q / quantiles: bit-exact except for fp64-association double roundings
+    (allowed: <= 1 ulp on <= 1e-4 of the elements);
+  * gradients: <= 1e-5 of the row's max |grad| against the closed-form oracle (stable tie order).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, case_names, ctor_to_flags, load_case
+from gpu_util import device, module_for, native, to_dev, ulp_diff
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def pos_kwargs(meta, g):
+    if meta["pos"] == "fixed_x":
+        return {}
+    return dict(x_pos=to_dev(g["x_pos"]), y_pos=to_dev(g["y_pos"]))
+
+
+def run_rows(mod, x, y, pk):
+    """per-row losses via the module (dims keeps every row)"""
+    x2 = x.reshape(-1, 1, x.shape[-1])
+    y2 = y.reshape(-1, 1, y.shape[-1])
+    pk2 = {k: (v.reshape(-1, 1, v.shape[-1]) if v.ndim >= 2 else v) for k, v in pk.items()}
+    return mod(x2, y2, dims=[1], **pk2)
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_forward_matches_reference_fixture(name, manifest):
+    meta, g = load_case(name, manifest)
+    mod = module_for(meta["ctor"])
+    x, y = to_dev(g["x"]), to_dev(g["y"])
+    pk = pos_kwargs(meta, g)
+    scalar = mod(x, y, **pk)
+    assert scalar.ndim == 0 and scalar.dtype == torch.float32
+    rows = run_rows(mod, x, y, pk).cpu().numpy()
+    want_rows = g["row_loss"].reshape(-1)
+    np.testing.assert_allclose(rows, want_rows, rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(float(scalar), float(g["scalar"]), rtol=RTOL, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if n.startswith(("b4n512", "nm_", "unsorted", "edge", "fixedx"))])
+def test_quantile_tensors_match_reference(name, manifest):
+    meta, g = load_case(name, manifest)
+    mod = module_for(meta["ctor"])
+    x, y = to_dev(g["x"]), to_dev(g["y"])
+    out = mod(x, y, return_quantiles=True, **pos_kwargs(meta, g))
+    lead = tuple(g["x"].shape[:-1])
+    for got, key in zip(out, ("uq", "vq", "Q", "U", "V")):
+        assert tuple(got.shape[:-1]) == lead
+        got = got.cpu().numpy().reshape(g[key].shape)
+        d = ulp_diff(got, g[key])
+        if key in ("U", "V", "Q"):
+            assert d.max() <= 1 and (d > 0).mean() <= 1e-4, (key, d.max(), (d > 0).mean())
+        else:  # quantile values: a 1-ulp CDF flip can move a rank by one position
+            assert (got != g[key]).mean() <= 1e-3, key
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if not n.startswith("seeded_b256")])
+def test_backward_matches_oracle(name, manifest):
+    from oracle import sot_oracle as so
+    meta, g = load_case(name, manifest)
+    p, flags = ctor_to_flags(meta["ctor"])
+    mod = module_for(meta["ctor"])
+    x = to_dev(g["x"]).requires_grad_(True)
+    y = to_dev(g["y"]).requires_grad_(True)
+    loss = mod(x, y, **pos_kwargs(meta, g))
+    loss.backward()
+    x2 = g["x"].reshape(-1, g["x"].shape[-1])
+    y2 = g["y"].reshape(-1, g["y"].shape[-1])
+    xp = g["x_pos"].reshape(-1, g["x_pos"].shape[-1]) if g["x_pos"].ndim == 3 else g["x_pos"]
+    yp = g["y_pos"].reshape(-1, g["y_pos"].shape[-1]) if g["y_pos"].ndim == 3 else g["y_pos"]
+    B = x2.shape[0]
+    gx, gy = so.backward(x2, y2, xp, yp, np.full(B, 1.0 / B, np.float32), p=p, flags=flags)
+    for got, want in ((x.grad, gx), (y.grad, gy)):
+        got = got.cpu().numpy().reshape(want.shape)
+        tol = 1e-5 * np.abs(want).max(axis=1, keepdims=True) + 3e-8
+        assert (np.abs(got - want) <= tol).all(), (name, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("kind", ["uniform", "peaky", "dyadic"])
+@pytest.mark.parametrize("mode", ["p1", "cutoff", "nocut"])
+def test_config2_full_size_scalars(kind, mode, manifest):
+    """BASELINE config 2: B=8192, N=2048, inputs regenerated from the seed; scalar from the reference."""
+    from oracle.inputs import gen_inputs, sha256_of
+    from oracle.make_golden import MODES
+    big = manifest["_config2_b8192n2048_seed1234"]
+    x, y = gen_inputs(kind, 8192, 2048, 2048, 1234)
+    assert sha256_of(x, y) == big[f"{kind}_sha256"]
+    pos = torch.linspace(0, 1, 2048).to(device())
+    mod = module_for(MODES[mode])
+    got = float(mod(x.to(device()), y.to(device()), x_pos=pos, y_pos=pos.clone()))
+    want = big[f"{kind}_{mode}"]
+    assert abs(got - want) <= RTOL * abs(want), (got, want)
+
+
+def test_full_size_properties():
+    """Size-independent properties at B=8192, N=2048 (no oracle needed)."""
+    from oracle.inputs import gen_inputs
+    x, y = gen_inputs("peaky", 8192, 2048, 2048, 77)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.linspace(0, 1, 2048).to(device())
+    w1 = module_for(dict(p=1))
+    rows_xy = run_rows(w1, x, y, dict(x_pos=pos, y_pos=pos))
+    rows_yx = run_rows(w1, y, x, dict(x_pos=pos, y_pos=pos))
+    torch.testing.assert_close(rows_xy, rows_yx, rtol=2e-6, atol=0)          # symmetry
+    rows_sc = run_rows(w1, 3.0 * x, 0.25 * y, dict(x_pos=pos, y_pos=pos))
+    torch.testing.assert_close(rows_xy, rows_sc, rtol=2e-5, atol=0)          # scale invariance
+    assert float(run_rows(w1, x, x, dict(x_pos=pos, y_pos=pos)).abs().max()) == 0.0   # identity
+    k = 5                                                                    # shift by k bins -> k/(N-1)
+    xs = torch.zeros(4, 2048, device=device())
+    xs[:, 100:600] = x[:4, 100:600]
+    ys = torch.roll(xs, k, dims=1)
+    got = run_rows(w1, xs, ys, dict(x_pos=pos, y_pos=pos))
+    torch.testing.assert_close(got, torch.full_like(got, k / 2047.0), rtol=1e-5, atol=0)
+
+
+def test_known_answers_and_errors():
+    from sot_amd.losses import Wasserstein1D, wasserstein_1d
+    native()
+    dev = device()
+    n = 64
+    pos = torch.linspace(0, 1, n, device=dev)
+    a = torch.zeros(1, n, device=dev)
+    b = torch.zeros(1, n, device=dev)
+    a[0, 10] = 3.0
+    b[0, 37] = 0.5
+    d = (pos[10] - pos[37]).abs()
+    assert float(Wasserstein1D(p=1)(a, b, x_pos=pos, y_pos=pos)) == float(d)
+    assert float(Wasserstein1D(p=2)(a, b, x_pos=pos, y_pos=pos)) == float(d * d)
+    with pytest.raises(ValueError):
+        Wasserstein1D(p=1)(a, b)
+    with pytest.raises(AssertionError):
+        Wasserstein1D(p=0.5)(a, b, x_pos=pos, y_pos=pos)
+    with pytest.raises(AssertionError):
+        wasserstein_1d(pos[None], pos[None], a, b, p=0.5)
+    with pytest.raises(RuntimeError):
+        Wasserstein1D(p=1)(a.cpu(), b.cpu(), x_pos=pos.cpu(), y_pos=pos.cpu())
+    # fixed_x buffer form (metrics.py:148) under inference_mode
+    with torch.inference_mode():
+        m = Wasserstein1D(p=2, fixed_x=n).to(dev)
+        assert float(m(a, b)) == float(d * d)
+    # functional form: weights used as given, default uniform weights
+    w = wasserstein_1d(pos[None].expand(2, n), pos[None].expand(2, n) * 0.5)
+    exp = (pos - 0.5 * pos).abs().mean()
+    torch.testing.assert_close(w, exp.expand(2), rtol=1e-5, atol=0)
+
+
+def test_host_semantics_dims_hinge_strides():
+    from oracle import torch_restatement as tr
+    from oracle.inputs import gen_inputs
+    from sot_amd.losses import MixOfLosses, Wasserstein1D
+    native()
+    dev = device()
+    x, y = gen_inputs("peaky", 12, 40, 40, 21)
+    pos = torch.linspace(0, 1, 40)
+    x3, y3 = x.reshape(3, 4, 40), y.reshape(3, 4, 40)
+    mod = Wasserstein1D(p=2, square_dist=True, hinge=True).to(dev)
+    for dims in (None, [1], [0], [0, 1]):
+        got = mod(x3.to(dev), y3.to(dev), x_pos=pos.to(dev), y_pos=pos.to(dev), dims=dims, hinge=0.003)
+        want = tr.sot_loss(x3, y3, pos, pos, p=2, square_dist=True, hinge=True, hinge_value=0.003, dims=dims)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-9)
+    # call-time kwargs are OR-ed with ctor flags (losses.py:180,194-195)
+    m2 = Wasserstein1D(p=2, square_dist=True).to(dev)
+    got = m2(x.to(dev), y.to(dev), x_pos=pos.to(dev), y_pos=pos.to(dev), dont_normalize=True, limit_quantile_range=True)
+    want = tr.sot_loss(x, y, pos, pos, p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=0)
+    # non-contiguous inputs (a strided view) are accepted
+    wide = torch.zeros(12, 80)
+    wide[:, ::2] = x
+    got = m2(wide.to(dev)[:, ::2], y.to(dev), x_pos=pos.to(dev), y_pos=pos.to(dev))
+    want = tr.sot_loss(x, y, pos, pos, p=2, square_dist=True)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=0)
+    # row-strided view (rows of a wider matrix)
+    wide2 = torch.rand(12, 100)
+    wide2[:, :40] = x
+    got = m2(wide2.to(dev)[:, :40], y.to(dev), x_pos=pos.to(dev), y_pos=pos.to(dev))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=0)
+    # MixOfLosses passthrough (losses.py:346-362; trainer.py:220)
+    mix = MixOfLosses([m2], [0.5])
+    out = mix(x.to(dev), y.to(dev), x_pos=pos.to(dev), y_pos=pos.to(dev))
+    assert list(out) == ["Wasserstein1D"]
+    torch.testing.assert_close(out["Wasserstein1D"].cpu(), 0.5 * want, rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 100, 257, 1000, 1025, 2048, 3000, 5000])
+def test_segmented_sort_bit_exact_indices(n):
+    nat = native()
+    g = torch.Generator().manual_seed(n)
+    keys = torch.rand(7, n, generator=g)  # distinct keys: the permutation is unique
+    want_v, want_i = torch.sort(keys, 1)
+    got_v, got_i = nat.segmented_sort(keys.to(device()))
+    assert torch.equal(got_v.cpu(), want_v)
+    assert torch.equal(got_i.cpu(), want_i)
+    # ties: stable (lowest index first)
+    tied = torch.randint(0, 4, (3, n), generator=g).float()
+    want_v, want_i = torch.sort(tied, dim=1, stable=True)
+    got_v, got_i = nat.segmented_sort(tied.to(device()))
+    assert torch.equal(got_v.cpu(), want_v) and torch.equal(got_i.cpu(), want_i)
+
+
+@pytest.mark.parametrize("shape", [(5, 50, 70), (3, 300, 300), (9, 1025, 1025), (2, 2048, 2048)])
+@pytest.mark.parametrize("mode", ["p1", "cutoff"])
+def test_unsorted_positions_shared_and_per_row(shape, mode):
+    """require_sort does real work: shared unsorted grid (plan path) and per-row grids (in-LDS sort)."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import gen_inputs
+    from oracle.make_golden import MODES
+    B, n, m = shape
+    x, y = gen_inputs("uniform", B, n, m, 5 + n)
+    g = torch.Generator().manual_seed(n)
+    p, flags = ctor_to_flags(MODES[mode])
+    mod = module_for(MODES[mode])
+    for per_row in (False, True):
+        xp = torch.rand((B, n) if per_row else (n,), generator=g)
+        yp = torch.rand((B, m) if per_row else (m,), generator=g)
+        want = so.forward(x.numpy(), y.numpy(), xp.numpy(), yp.numpy(), p=p, flags=flags)
+        xd = x.to(device()).requires_grad_(True)
+        yd = y.to(device()).requires_grad_(True)
+        rows = run_rows(mod, xd, yd, dict(x_pos=xp.to(device()), y_pos=yp.to(device())))
+        np.testing.assert_allclose(rows.detach().cpu().numpy(), want, rtol=RTOL)
+        rows.sum().backward()
+        gx, gy = so.backward(x.numpy(), y.numpy(), xp.numpy(), yp.numpy(), np.ones(B, np.float32), p=p, flags=flags)
+        for got, ref in ((xd.grad, gx), (yd.grad, gy)):
+            tol = 1e-5 * np.abs(ref).max(axis=1, keepdims=True) + 3e-8
+            assert (np.abs(got.cpu().numpy() - ref) <= tol).all()
+
+
+@pytest.mark.parametrize("shape", [(3, 4000, 4000), (2, 8192, 8192), (2, 9000, 700), (300, 33, 2049)])
+def test_large_and_ragged_sizes_against_oracle(shape):
+    from oracle import sot_oracle as so
+    from oracle.inputs import gen_inputs
+    B, n, m = shape
+    x, y = gen_inputs("peaky", B, n, m, 1000 + n)
+    xp, yp = torch.linspace(0, 1, n), torch.linspace(0, 1, m)
+    for ctor in (dict(p=1), dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)):
+        p, flags = ctor_to_flags(ctor)
+        want = so.forward(x.numpy(), y.numpy(), xp.numpy(), yp.numpy(), p=p, flags=flags)
+        rows = run_rows(module_for(ctor), x.to(device()), y.to(device()), dict(x_pos=xp.to(device()), y_pos=yp.to(device())))
+        np.testing.assert_allclose(rows.cpu().numpy(), want, rtol=RTOL, atol=1e-12)
+
+
+def test_size_limit_is_an_error_not_a_crash():
+    from sot_amd import _native as nat
+    native()
+    dev = device()
+    x = torch.rand(2, 30000, device=dev)
+    pos = torch.linspace(0, 1, 30000, device=dev)
+    from sot_amd.losses import Wasserstein1D
+    with pytest.raises(nat.SotError):
+        Wasserstein1D(p=1)(x, x, x_pos=pos, y_pos=pos)
+
+
+def test_masked_dense_equals_ragged_removal():
+    """BASELINE config 4 semantics: zero-weight points are inert, i.e. masking == removing support points."""
+    from oracle.inputs import gen_inputs
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    B, N = 64, 512
+    x, y = gen_inputs("peaky", B, N, N, 1234)
+    g = torch.Generator().manual_seed(1234)
+    tau = 10 ** (-3 + 2.7 * torch.rand(B, 1, generator=g))
+    xm = torch.where(x < tau * x.amax(1, keepdim=True), torch.zeros_like(x), x)
+    ym = torch.where(y < tau * y.amax(1, keepdim=True), torch.zeros_like(y), y)
+    pos = torch.linspace(0, 1, N)
+    mod = Wasserstein1D(p=1).to(dev)
+    dense = run_rows(mod, xm.to(dev), ym.to(dev), dict(x_pos=pos.to(dev), y_pos=pos.to(dev))).cpu()
+    for r in range(0, B, 7):  # truly ragged evaluation of a few rows: only the kept support points
+        kx, ky = xm[r] > 0, ym[r] > 0
+        one = mod(xm[r][kx][None].to(dev), ym[r][ky][None].to(dev), x_pos=pos[kx].to(dev), y_pos=pos[ky].to(dev)).cpu()
+        torch.testing.assert_close(one, dense[r], rtol=5e-6, atol=0)

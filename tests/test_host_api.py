@@ -1,0 +1,105 @@
+"""CPU tests: host-side mirror of the reference interface, the C-ABI library's exports, and error
+behaviour that does not need a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import sot_amd
+    lib_path = sot_amd.build.build()
+    assert os.path.exists(lib_path)
+    handle = ctypes.CDLL(lib_path)
+    header = open(os.path.join(ROOT, "include", "sot_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?\s*(sot_\w+)\s*\(", header, flags=re.M))
+    assert {"sot_w1d_forward", "sot_w1d_backward", "sot_w1d_reduce_mean", "sot_w1d_quantiles", "sot_segmented_sort",
+            "sot_prepare_positions", "sot_workspace_bytes", "sot_abi_version", "sot_status_string"} <= declared
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert set(sot_amd._native.EXPORTS) == declared
+    handle.sot_abi_version.restype = ctypes.c_int
+    assert handle.sot_abi_version() == 1
+    handle.sot_status_string.restype = ctypes.c_char_p
+    assert b"p>=1" in handle.sot_status_string(-1)
+
+
+def test_host_side_validation_without_gpu():
+    """C-ABI argument validation runs on the host before anything is enqueued."""
+    from sot_amd import _native as nat
+    lib = nat.load()
+    pr = nat.SotProblem()
+    pr.B, pr.n, pr.m = 4, 16, 16
+    pr.x_row_stride = pr.y_row_stride = 16
+    pr.p, pr.flags = 0.5, 0
+    assert lib.sot_w1d_forward(ctypes.byref(pr), None, None, 0, None) == -4  # row_loss NULL
+    buf = (ctypes.c_float * 64)()
+    addr = ctypes.addressof(buf)
+    assert lib.sot_w1d_forward(ctypes.byref(pr), addr, None, 0, None) == nat.SOT_ERR_INVALID_P
+    pr.p = 1.0
+    assert lib.sot_w1d_forward(ctypes.byref(pr), addr, None, 0, None) == -4  # x/y NULL
+    pr.n = 0
+    assert lib.sot_w1d_forward(ctypes.byref(pr), addr, None, 0, None) == -2
+    pr.n = 16
+    assert lib.sot_workspace_bytes(ctypes.byref(pr)) >= 2 * 16 * 8 + 8
+    with pytest.raises(AssertionError, match="only valid for p>=1"):
+        nat.check(nat.SOT_ERR_INVALID_P, 0.5)
+    with pytest.raises(nat.SotError):
+        nat.check(-3)
+
+
+def test_module_surface_matches_reference():
+    from sot_amd.losses import MixOfLosses, Wasserstein1D
+    # paper YAML init_args (SOT-2048/c6m8cytv-42/train_config.yaml:89-99), incl. the ignored cumsum_only
+    m = Wasserstein1D(p=2, fixed_x=None, require_sort=True, log_scaled_x=False, cumsum_only=False, hinge=False,
+                      square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    assert m.__class__.__name__ == "Wasserstein1D"           # trainer.py:216, losses.py:361
+    assert (m.p, m.require_sort, m.log_scaled_x) == (2, True, False)
+    assert (m.dont_normalize, m.limit_quantile_range, m.hinge, m.square_dist) == (True, True, False, True)
+    assert m.fixed_x is None and list(m.state_dict()) == []
+    m2 = Wasserstein1D(p=1, fixed_x=257)
+    assert torch.equal(m2.fixed_x, torch.linspace(0, 1, 257)) and list(m2.state_dict()) == ["fixed_x"]
+    assert hasattr(m2, "log_scaled_x")                       # trainer.py:187
+    with pytest.raises(ValueError, match="x_pos and y_pos must be provided"):
+        m(torch.rand(2, 8), torch.rand(2, 8))
+    with pytest.raises(AssertionError, match="only valid for p>=1"):
+        Wasserstein1D(p=0.5, fixed_x=8)(torch.rand(2, 8), torch.rand(2, 8))
+    # no CPU path: a CPU tensor is a loud error, not a fallback
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m2(torch.rand(2, 257), torch.rand(2, 257))
+    with pytest.raises(TypeError):
+        from sot_amd import _native as nat
+        nat.require_hip(torch.rand(2, 2, dtype=torch.float64, device="meta") if False else _FakeCuda())
+    mix = MixOfLosses([m2], [1.0])
+    assert mix.losses[0] is m2 and mix.weights == [1.0]
+
+
+class _FakeCuda:
+    """minimal stand-in to exercise the dtype check without a GPU"""
+    is_cuda = True
+    dtype = torch.float64
+    device = "cuda:0"
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "1d-spectral-optimal-transport_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the C oracle", "").replace("CPU oracle", "") or f == "never", (f,)
+
+
+def test_shard_rows_partition():
+    from sot_amd.distributed import shard_rows
+    for total in (0, 1, 7, 8192, 65536, 65539):
+        for ws in (1, 2, 3, 8):
+            blocks = [shard_rows(total, r, ws) for r in range(ws)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
