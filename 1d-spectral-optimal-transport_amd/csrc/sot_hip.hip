@@ -88,9 +88,9 @@ __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     const int npad = next_pow2(len);
     float* key = smem;
     int* idx = reinterpret_cast<int*>(smem + npad);
-    __shared__ int unsorted;
+    int* const unsorted_flag = reinterpret_cast<int*>(smem + 2 * npad);  // all LDS is dynamic (16-B aligned carve)
     const int t = threadIdx.x, T = blockDim.x;
-    if (t == 0) unsorted = 0;
+    if (t == 0) *unsorted_flag = 0;
     for (int i = t; i < npad; i += T) {
         key[i] = (i < len) ? pos[i] : INFINITY;
         idx[i] = (i < len) ? i : INT_MAX;
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     __syncthreads();
     int bad = 0;
     for (int i = t; i + 1 < len; i += T) bad |= (key[i] > key[i + 1]);
-    if (bad) unsorted = 1;
+    if (bad) *unsorted_flag = 1;
     __syncthreads();
-    const bool need_sort = unsorted != 0;
+    const bool need_sort = *unsorted_flag != 0;
     if (need_sort) bitonic_sort_kv(key, idx, npad, t, T, [] { __syncthreads(); });
     for (int i = t; i < len; i += T) { spos[i] = key[i]; perm[i] = idx[i]; }
     if (t == 0) ident[which] = need_sort ? 0 : 1;
@@ -611,6 +611,13 @@ __global__ __launch_bounds__(256) void sot_segmented_sort_kernel(const float* __
 // ---------------------------------------------------------------------------------------------
 constexpr size_t kLdsLimit = 160 * 1024;
 
+// Allow a kernel to use up to the CU's full 160 KiB of dynamic LDS; leaves no sticky error behind.
+static void allow_full_lds(const void* kernel)
+{
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
+        (void)hipGetLastError();
+}
+
 static int device_cu_count()
 {
     static int cus = 0;
@@ -653,9 +660,10 @@ static hipError_t launch_forward(const FwdArgs& a, size_t lds, int grid, int blo
     auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+        allow_full_lds(reinterpret_cast<const void*>(kern));
         attr_set = true;
     }
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
     return hipGetLastError();
 }
@@ -708,14 +716,14 @@ static int launch_prepare(const float* xpos, const float* ypos, int n, int m, fl
                           hipStream_t s)
 {
     const int npad = next_pow2(n > m ? n : m);
-    const size_t prep_lds = (size_t)npad * 8;
+    const size_t prep_lds = (size_t)npad * 8 + 16;
     if (prep_lds > kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sot_prepare_positions_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+        allow_full_lds(reinterpret_cast<const void*>(sot_prepare_positions_kernel));
         attr_set = true;
     }
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(sot_prepare_positions_kernel, dim3(2), dim3(1024), prep_lds, s, xpos, ypos, n, m, sx, sy, px, py, ident);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
@@ -800,9 +808,10 @@ static hipError_t launch_backward(const BwdArgs& b, size_t lds, int grid, int bl
     auto kern = sot_backward_kernel<G, CPT, ROWPOS>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+        allow_full_lds(reinterpret_cast<const void*>(kern));
         attr_set = true;
     }
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
     return hipGetLastError();
 }
@@ -893,6 +902,7 @@ int sot_w1d_reduce_mean(const float* row_loss, int64_t B, double denom, int appl
     if (B < 0) return SOT_ERR_BAD_SHAPE;
     if (B > 0 && row_loss == nullptr) return SOT_ERR_NULL_POINTER;
     if (mean_out == nullptr && sum_out == nullptr) return SOT_ERR_NULL_POINTER;
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(sot::sot_reduce_mean_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), row_loss, B,
                        denom, apply_hinge, hinge_threshold, mean_out, sum_out);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
@@ -914,14 +924,14 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
     if (lds > sot::kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sot::sot_segmented_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sot::kLdsLimit);
+        sot::allow_full_lds(reinterpret_cast<const void*>(sot::sot_segmented_sort_kernel));
         attr_set = true;
     }
     int per_cu = (int)(sot::kLdsLimit / lds);
     if (per_cu > 8) per_cu = 8;
     int64_t cap = (int64_t)sot::device_cu_count() * per_cu;
     const int grid = (int)(B < cap ? B : cap);
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(sot::sot_segmented_sort_kernel, dim3(grid), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), keys, B,
                        (int)n, row_stride, sorted_keys, indices);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;

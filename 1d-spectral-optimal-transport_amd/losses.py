@@ -67,6 +67,13 @@ class _RowMean(torch.autograd.Function):
         return (g / ctx.count).expand(ctx.count)
 
 
+def _version_of(t):
+    try:
+        return t._version
+    except RuntimeError:  # inference tensors (metrics.py:144 runs under inference_mode) are immutable
+        return -1
+
+
 class _PlanCache:
     """Position plans keyed by tensor identity+version, so a persistent grid is sorted once."""
 
@@ -75,7 +82,7 @@ class _PlanCache:
         self.entries = []  # (key, xpos_ref, ypos_ref, plan)
 
     def get(self, xpos, ypos):
-        key = (xpos.data_ptr(), ypos.data_ptr(), xpos.numel(), ypos.numel(), xpos._version, ypos._version,
+        key = (xpos.data_ptr(), ypos.data_ptr(), xpos.numel(), ypos.numel(), _version_of(xpos), _version_of(ypos),
                xpos.device)
         for k, _, _, plan in self.entries:
             if k == key:

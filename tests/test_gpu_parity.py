@@ -123,7 +123,10 @@ def test_full_size_properties():
     xs[:, 100:600] = x[:4, 100:600]
     ys = torch.roll(xs, k, dims=1)
     got = run_rows(w1, xs, ys, dict(x_pos=pos, y_pos=pos))
-    torch.testing.assert_close(got, torch.full_like(got, k / 2047.0), rtol=1e-5, atol=0)
+    torch.testing.assert_close(got, torch.full_like(got, k / 2047.0), rtol=3e-4, atol=0)  # analytic value, fp32 conditioning
+    from oracle import sot_oracle as so
+    want = so.forward(xs.cpu().numpy(), ys.cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=1.0, flags=so.make_flags())
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL)
 
 
 def test_known_answers_and_errors():
@@ -198,7 +201,8 @@ def test_host_semantics_dims_hinge_strides():
 def test_segmented_sort_bit_exact_indices(n):
     nat = native()
     g = torch.Generator().manual_seed(n)
-    keys = torch.rand(7, n, generator=g)  # distinct keys: the permutation is unique
+    # distinct keys (a shuffled grid plus a tiny jitter): the permutation is unique, so torch's unstable sort agrees
+    keys = torch.stack([(torch.randperm(n, generator=g).float() + 0.25 * torch.rand(n, generator=g)) / n for _ in range(7)])
     want_v, want_i = torch.sort(keys, 1)
     got_v, got_i = nat.segmented_sort(keys.to(device()))
     assert torch.equal(got_v.cpu(), want_v)

@@ -1,0 +1,35 @@
+"""Summarise a tools/profile_round.sh output directory: per-kernel stats + per-kernel mean PMC values."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("stats/**/*kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        name = row.get("Name", "")[:90]
+        print(f"{name:90s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} total_ns={row.get('TotalDurationNs')} pct={row.get('Percentage')}")
+
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row.get("Kernel_Name", "")[:60]
+            acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
+    print(f"== {os.path.basename(d)} (mean per dispatch) ==")
+    for k, cs in acc.items():
+        if "sot_" not in k:
+            continue
+        print("  " + k)
+        for c, v in sorted(cs.items()):
+            print(f"     {c:28s} {sum(v) / len(v):16.1f}  (n={len(v)})")
