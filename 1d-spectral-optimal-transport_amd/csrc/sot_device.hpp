@@ -58,15 +58,24 @@ __device__ __forceinline__ void mass_chunk_sums(const float* raw, float* part, c
         const int s0 = h << 4;
         const int s1 = min(s0 + 16, mp.steps);
         float acc = 0.0f;
-        for (int s = s0; s < s1; ++s) acc += ldw<SQ>(raw, (s << 5) + c);
+        if (s1 - s0 == 16) {  // full chunk: issue the 16 LDS reads back to back, then the ordered adds
+            float v[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) v[s] = ldw<SQ>(raw, ((s0 + s) << 5) + c);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc += v[s];
+        } else {
+            for (int s = s0; s < s1; ++s) acc += ldw<SQ>(raw, (s << 5) + c);
+        }
         part[task] = acc;
     }
 }
 
-// Phase B: executed by 32 consecutive lanes (c = 0..31) of one wave; `half_base` is the lane id of
-// column 0 (0 or 32).  Returns S in every participating lane.
+// Phase B: executed by 32 consecutive lanes (c = 0..31), one per column: cascade of the chunk sums
+// plus the left-over 8-lane vectors (which ATen adds to ILP group 0).  Returns the column total.
+// For n < 8 (ATen's scalar_inner_sum path) lane c == 0 returns the complete row sum instead.
 template <bool SQ>
-__device__ __forceinline__ float mass_fold(const float* raw, const float* part, const MassPlan& mp, int c, int half_base)
+__device__ __forceinline__ float mass_column(const float* raw, const float* part, const MassPlan& mp, int c)
 {
     const int n = mp.n;
     if (n < 8) {  // scalar_inner_sum: 4 columns, then the tail into column 0
@@ -90,51 +99,110 @@ __device__ __forceinline__ float mass_fold(const float* raw, const float* part, 
     }
     if (mp.steps & 15) a0 = part[(nfull << 5) + c];
     float col = ((a0 + a1) + a2) + a3;
-    // left-over 8-lane vectors go to ILP group 0 (columns 0..7)
     const int vec_size = n >> 3;
     if (c < 8)
         for (int v = (mp.steps << 2); v < vec_size; ++v) col += ldw<SQ>(raw, (v << 3) + c);
-    // fold the 4 ILP groups: p0[l] = ((col[l] + col[8+l]) + col[16+l]) + col[24+l]
-    const int l = c & 7;
-    float p0 = __shfl(col, half_base + l);
-    p0 += __shfl(col, half_base + 8 + l);
-    p0 += __shfl(col, half_base + 16 + l);
-    p0 += __shfl(col, half_base + 24 + l);
-    // scalar tail first, then the 8 lanes, sequentially
+    return col;
+}
+
+// Phase C: every thread folds the 32 column totals itself (reads are LDS broadcasts), which removes
+// a serial single-wave step and a barrier from the row pipeline:
+//   p0[l] = ((col[l] + col[8+l]) + col[16+l]) + col[24+l];  S = (0 + tail...) + p0[0] + ... + p0[7].
+template <bool SQ>
+__device__ __forceinline__ float mass_fold(const float* raw, const float* colbuf, int n)
+{
+    if (n < 8) return colbuf[0];
+    const float4* c4 = reinterpret_cast<const float4*>(colbuf);
+    const float4 a0 = c4[0], a1 = c4[1], b0 = c4[2], b1 = c4[3], c0 = c4[4], c1 = c4[5], d0 = c4[6], d1 = c4[7];
+    const float p0 = ((a0.x + b0.x) + c0.x) + d0.x, p1 = ((a0.y + b0.y) + c0.y) + d0.y;
+    const float p2 = ((a0.z + b0.z) + c0.z) + d0.z, p3 = ((a0.w + b0.w) + c0.w) + d0.w;
+    const float p4 = ((a1.x + b1.x) + c1.x) + d1.x, p5 = ((a1.y + b1.y) + c1.y) + d1.y;
+    const float p6 = ((a1.z + b1.z) + c1.z) + d1.z, p7 = ((a1.w + b1.w) + c1.w) + d1.w;
     float fin = 0.0f;
-    for (int k = vec_size << 3; k < n; ++k) fin += ldw<SQ>(raw, k);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fin += __shfl(p0, half_base + k);
+    for (int k = (n >> 3) << 3; k < n; ++k) fin += ldw<SQ>(raw, k);
+    fin += p0; fin += p1; fin += p2; fin += p3; fin += p4; fin += p5; fin += p6; fin += p7;
     return fin;
 }
 
 __device__ __forceinline__ float guard_mass(float s) { return (s <= kMassEps) ? kMassEps : s; }
 
 // ---------------------------------------------------------------------------------------------
-// Wave / group scans and reductions
+// Correctly rounded x / S for a per-row constant S (utils.py:141 `numerator / safe_denominator`).
+// q0 = x*r with r = RN(1/S), e = x - q0*S (exact, one FMA), q1 = RN(q0 + e*r) is the IEEE quotient
+// (Markstein's reciprocal-refinement theorem) as long as the residual cannot underflow and the
+// quotient is normal; both hold when x >= 2^-78 and 2^-24 < S <= 2^40.  `risk` tracks the smallest
+// non-zero operand seen; the caller redoes the chunk with the IEEE sequence when it is below the bound.
+// 5 VALU per element instead of ~12 (v_div_scale x2, v_rcp, 4 FMA, v_div_fmas, v_div_fixup).
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kFastDivMinBits = 0x18800000u;  // 2^-78
+__device__ __forceinline__ float div_by_row_constant(float x, float S, float r, uint32_t& risk)
+{
+    const float q0 = x * r;
+    const float e = fmaf(-q0, S, x);
+    const float q1 = fmaf(e, r, q0);
+    risk = min(risk, __float_as_uint(x) - 1u);  // x == 0 (exact either way) wraps to UINT_MAX
+    return q1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level scans / reductions.  Forward scans use DPP (row_shr 1/2/4/8, row_bcast 15/31,
+// wave_shr 1): a handful of VALU ops instead of 6 dependent LDS-crossbar shuffles (12 for fp64).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v)  // value of the DPP source lane; +0.0 where there is none
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143, kWaveShr1 = 0x138;
+
 __device__ __forceinline__ double wave_incl_scan(double v)
+{
+    v += dpp_f64<kRowShr1>(v);
+    v += dpp_f64<kRowShr2>(v);
+    v += dpp_f64<kRowShr4>(v);
+    v += dpp_f64<kRowShr8>(v);
+    v += dpp_f64<kRowBcast15, 0xA>(v);
+    v += dpp_f64<kRowBcast31, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_shift_right1(double v) { return dpp_f64<kWaveShr1>(v); }  // lane 0 gets 0
+__device__ __forceinline__ double wave_last(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ float wave_sum(float v)  // total in every lane
+{
+    v += dpp_f32<kRowShr1>(v);
+    v += dpp_f32<kRowShr2>(v);
+    v += dpp_f32<kRowShr4>(v);
+    v += dpp_f32<kRowShr8>(v);
+    v += dpp_f32<kRowBcast15, 0xA>(v);
+    v += dpp_f32<kRowBcast31, 0xC>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ double wave_sum(double v) { return wave_last(wave_incl_scan(v)); }
+
+// suffix (right-to-left) inclusive scan, used by the backward's reverse cumsum
+__device__ __forceinline__ double wave_suffix_incl_scan(double v)
 {
     const int lane = lane_id();
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
-        const double o = __shfl_up(v, off);
-        if (lane >= off) v += o;
+        const double o = __shfl_down(v, off);
+        if (lane + off < kWave) v += o;
     }
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;  // lane 0 holds the total
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
 }
 
@@ -152,11 +220,13 @@ __device__ __forceinline__ int merge_path(const float* U, const float* V, int n,
     return lo;
 }
 
+// PM: 1 -> p == 1 (losses.py:311-312: no pow), 2 -> p == 2 (torch.pow(., 2) is an exact square), 0 -> powf
+template <int PM>
 __device__ __forceinline__ float transport_cost(float xa, float yb, float p)
 {
     const float d = fabsf(xa - yb);
-    if (p == 1.0f) return d;          // losses.py:311-312: no pow for p == 1
-    if (p == 2.0f) return d * d;      // torch.pow(., 2) is an exact square
+    if (PM == 1) return d;
+    if (PM == 2) return d * d;
     return powf(d, p);
 }
 

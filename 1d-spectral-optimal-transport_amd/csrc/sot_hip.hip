@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/sot_hip.h"
 #include "sot_device.hpp"
@@ -23,25 +24,34 @@ namespace sot {
 // LDS layout of one row group (identical arithmetic on host and device)
 // ---------------------------------------------------------------------------------------------
 struct RowLayout {
-    int nU, nV;      // floats reserved for U (n+1 incl. sentinel) and V (m+1), multiples of 4
-    int poff;        // PX = U + poff, PY = V + poff
+    int padcap;          // spare floats in front of U and of PX (front padding of the merge walk)
+    int nU, nV;          // floats reserved for U (padcap + n+1 incl. sentinel) and V (m+1), multiples of 4
+    int poff;            // PX = U + poff, PY = V + poff
     int part_x, part_y;  // chunk-sum scratch of the two row masses
-    int wtot;        // 2 * NW doubles (as float offset, even)
-    int red;         // 2*NW floats (reduction scratch) + 2 floats (S_x, S_y)
-    int grad;        // backward only: GU (nU floats) | GV (nV floats)
-    int row_floats;  // total, multiple of 4
+    int colbuf;          // 2 x 32 column totals of the row masses (16-B aligned)
+    int wtot;            // 2 * NW doubles (float offset, 8-B aligned)
+    int red;             // NW floats + 2 floats (S_x, S_y)
+    int grad;            // backward only: GU (nU floats) | GV (nV floats)
+    int row_floats;      // total, multiple of 4
 };
 
 __host__ __device__ inline int align4(int v) { return (v + 3) & ~3; }
 __host__ __device__ inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// merged elements handled by one thread: ceil(K / G) forced odd, so that the per-lane LDS address stride of
+// the merge walk (~E/2 floats) is not a multiple of the 32-bank period on regular data
+__host__ __device__ inline int merge_steps(int K, int G) { return ((K + G - 1) / G) | 1; }
+
 __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpos, bool with_grad = false)
 {
     RowLayout L;
-    L.nU = align4(n + 1);
+    // The U and PX regions start with `padcap` spare floats: the forward walk prepends pad < E zero-valued
+    // levels to U (zero width => zero contribution) so that every thread walks exactly E merged elements.
+    L.padcap = align4(merge_steps(n + m, G));
+    L.nU = L.padcap + align4(n + 1);
     L.nV = align4(m + 1);
     if (rowpos) {  // per-row position sort needs power-of-two scratch for the bitonic network
-        L.nU = max(L.nU, next_pow2(n));
+        L.nU = max(L.nU, L.padcap + next_pow2(n));
         L.nV = max(L.nV, next_pow2(m));
     }
     L.poff = L.nU + L.nV;
@@ -49,13 +59,23 @@ __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpo
     const int nchy = (((m >= 8) ? (m >> 5) : 0) + 15) >> 4;
     L.part_x = 2 * L.poff;
     L.part_y = L.part_x + 32 * nchx;
-    L.wtot = align4(L.part_y + 32 * nchy);
+    L.colbuf = align4(L.part_y + 32 * nchy);
+    L.wtot = L.colbuf + 64;
     const int NW = G / kWave;
     L.red = L.wtot + 4 * NW;  // 2 arrays * NW doubles = 4*NW floats
-    L.grad = align4(L.red + 2 * NW + 2);
+    L.grad = align4(L.red + NW + 2);
     L.row_floats = with_grad ? L.grad + L.nU + L.nV : L.grad;
     return L;
 }
+
+// Diagnostic build only (-DSOT_STAMPS -> libsot_hip_stamps.so): workgroup 0 stamps the shader clock at the
+// phase boundaries of its second row into a buffer of its own; no output value depends on a stamp.
+#ifdef SOT_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define SOT_STAMP(i) do { if (stamp_on) { __builtin_amdgcn_sched_barrier(0); g_stamps[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SOT_STAMP(i) do { } while (0)
+#endif
 
 struct FwdArgs {
     const float* x; const float* y;
@@ -113,11 +133,11 @@ template <int G>
 struct RowCtx {
     static constexpr int NW = G / kWave;
     float* base; float* U; float* V; float* PX; float* PY;
-    float* partx; float* party; double* wtot; float* red; float* Sv;
+    float* partx; float* party; float* colbuf; double* wtot; float* red;
     float* GU; float* GV;  // backward only
     RowLayout L;
     MassPlan mpx, mpy;
-    int n, m, K, E, cptn, cptm;
+    int n, m, K, E, Ga, pad;
     int t, lane, wv;
     bool sq, dn, lim, do_sort, prenorm, x_ident, y_ident;
     float p;
@@ -135,11 +155,11 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     c.n = a.n; c.m = a.m;
     c.L = make_layout(a.n, a.m, G, ROWPOS, with_grad_arrays);
     c.base = smem + rg * c.L.row_floats;
-    c.U = c.base; c.V = c.base + c.L.nU; c.PX = c.U + c.L.poff; c.PY = c.V + c.L.poff;
+    c.U = c.base + c.L.padcap; c.V = c.base + c.L.nU; c.PX = c.U + c.L.poff; c.PY = c.V + c.L.poff;
     c.partx = c.base + c.L.part_x; c.party = c.base + c.L.part_y;
+    c.colbuf = c.base + c.L.colbuf;
     c.wtot = reinterpret_cast<double*>(c.base + c.L.wtot);
     c.red = c.base + c.L.red;
-    c.Sv = c.red + 2 * RowCtx<G>::NW;
     c.GU = c.base + c.L.grad; c.GV = c.GU + c.L.nU;
     c.prenorm = a.flags & SOT_FLAG_PRENORMALIZED;
     c.sq = !c.prenorm && (a.flags & SOT_FLAG_SQUARE);
@@ -148,14 +168,17 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     c.do_sort = a.flags & SOT_FLAG_REQUIRE_SORT;
     c.p = a.p;
     c.mpx = make_mass_plan(a.n); c.mpy = make_mass_plan(a.m);
-    c.cptn = (a.n + G - 1) / G; c.cptm = (a.m + G - 1) / G;
     c.K = a.n + a.m;
-    c.E = (c.K + G - 1) / G;
+    c.E = merge_steps(c.K, G);
+    c.Ga = (c.K + c.E - 1) / c.E;       // threads that take part in the walk
+    c.pad = c.Ga * c.E - c.K;           // zero-valued levels prepended to U: 0 <= pad < E <= padcap
+    for (int e = c.t; e < c.pad; e += G) c.U[e - c.pad] = 0.0f;
     c.x_ident = true; c.y_ident = true;
     if (!ROWPOS) {
         if (a.ident != nullptr) { c.x_ident = a.ident[0] != 0; c.y_ident = a.ident[1] != 0; }
         for (int e = c.t; e < c.n; e += G) c.PX[e] = a.xpos[e];
         for (int e = c.t; e < c.m; e += G) c.PY[e] = a.ypos[e];
+        for (int e = c.t; e < c.pad; e += G) c.PX[e - c.pad] = a.xpos[0];  // any finite value: the width is 0
         if (c.t == 0) {
             c.PX[c.n] = a.xpos[c.n - 1];  // clamp of losses.py:220: ranks beyond the last index reuse it
             c.PY[c.m] = a.ypos[c.m - 1];
@@ -166,68 +189,103 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     return c;
 }
 
-// Phases P0-P3 for one row: positions (ROWPOS), staging, row masses, safe_divide, weight gather,
-// fp64-accumulated CDFs.  On return (after its final barrier) U/V hold the CDFs, PX/PY the sorted
-// positions incl. clamp slots, c.Sv the two masses.  wx/wy receive the ORIGINAL (unsquared) weights of
-// the elements this thread owns in sorted order; sidx/sidy their original column (for the backward
-// scatter); both are dead code in the forward kernel.
-template <int G, int CPT, bool ROWPOS>
-__device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c, const float* xr, const float* yr, int64_t rowc,
-                                           float (&wx)[CPT], float (&wy)[CPT], int (&sidx)[CPT], int (&sidy)[CPT])
+// ---- global -> register -> LDS staging of one row (VEC: 16 B per lane, rows 16-B aligned) ------------
+template <int G, int CPT, bool VEC>
+__device__ __forceinline__ void load_row(const float* __restrict__ src, int len, int t, float (&r)[CPT])
 {
-    constexpr int NW = G / kWave;
-    const int n = c.n, m = c.m, t = c.t;
-    float* const U = c.U; float* const V = c.V; float* const PX = c.PX; float* const PY = c.PY;
-    const bool sq = c.sq;
-    const int ex0 = t * c.cptn, ey0 = t * c.cptm;
-
-    // ---- P0 (ROWPOS only): this row's positions, sorted in LDS with an index payload --------------
-    int ix[ROWPOS ? CPT : 1], iy[ROWPOS ? CPT : 1];
-    if (ROWPOS) {
-        const float* xp = a.xpos + rowc * a.xps;
-        const float* yp = a.ypos + rowc * a.yps;
-        if (c.do_sort) {
-            int* const IX = reinterpret_cast<int*>(U);  // index payloads alias U/V until the weights arrive
-            int* const IY = reinterpret_cast<int*>(V);
-            const int npx = next_pow2(n), npy = next_pow2(m);
-            for (int e = t; e < npx; e += G) { PX[e] = (e < n) ? xp[e] : INFINITY; IX[e] = (e < n) ? e : INT_MAX; }
-            for (int e = t; e < npy; e += G) { PY[e] = (e < m) ? yp[e] : INFINITY; IY[e] = (e < m) ? e : INT_MAX; }
-            __syncthreads();
-            bitonic_sort_kv(PX, IX, npx, t, G, [] { __syncthreads(); });
-            bitonic_sort_kv(PY, IY, npy, t, G, [] { __syncthreads(); });
+    if (VEC) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const int ex = ex0 + k, ey = ey0 + k;
-                ix[k] = ((k < c.cptn) && (ex < n)) ? IX[ex] : 0;
-                iy[k] = ((k < c.cptm) && (ey < m)) ? IY[ey] : 0;
+        for (int k = 0; k < CPT / 4; ++k) {
+            const int q = t + k * G;
+            if (4 * q < len) {
+                const float4 v = s4[q];
+                r[4 * k] = v.x; r[4 * k + 1] = v.y; r[4 * k + 2] = v.z; r[4 * k + 3] = v.w;
             }
-            __syncthreads();
-        } else {
-            for (int e = t; e < n; e += G) PX[e] = xp[e];
-            for (int e = t; e < m; e += G) PY[e] = yp[e];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t + k * G;
+            if (e < len) r[k] = src[e];
         }
     }
-    // ---- P1: stage the raw weights in ORIGINAL order, 16 B per lane when the row is aligned --------
-    //      (squaring happens on the way out of LDS so that the backward keeps the unsquared value)
-    if (((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(xr) & 15) == 0)) {
-        const float4* src = reinterpret_cast<const float4*>(xr);
-        float4* dst = reinterpret_cast<float4*>(U);
-        for (int e = t; e < (n >> 2); e += G) dst[e] = src[e];
+}
+
+template <int G, int CPT, bool VEC>
+__device__ __forceinline__ void store_row(float* dst, int len, int t, const float (&r)[CPT])
+{
+    if (VEC) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int k = 0; k < CPT / 4; ++k) {
+            const int q = t + k * G;
+            if (4 * q < len) d4[q] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+        }
     } else {
-        for (int e = t; e < n; e += G) U[e] = xr[e];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t + k * G;
+            if (e < len) dst[e] = r[k];
+        }
     }
-    if (((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(yr) & 15) == 0)) {
-        const float4* src = reinterpret_cast<const float4*>(yr);
-        float4* dst = reinterpret_cast<float4*>(V);
-        for (int e = t; e < (m >> 2); e += G) dst[e] = src[e];
+}
+
+// ---- P0 (ROWPOS): this row's positions -> LDS, sorted with an index payload when REQUIRE_SORT ---------
+// On return ix/iy hold, for the CPT contiguous elements this thread owns in SORTED order, their
+// original column.  Ends with a barrier (U/V may be overwritten by the weights afterwards).
+template <int G, int CPT>
+__device__ __forceinline__ void rowpos_prepare(const FwdArgs& a, const RowCtx<G>& c, int64_t rowc, int (&ix)[CPT], int (&iy)[CPT])
+{
+    const int n = c.n, m = c.m, t = c.t;
+    const float* xp = a.xpos + rowc * a.xps;
+    const float* yp = a.ypos + rowc * a.yps;
+    if (c.do_sort) {
+        int* const IX = reinterpret_cast<int*>(c.U);  // index payloads alias U/V until the weights arrive
+        int* const IY = reinterpret_cast<int*>(c.V);
+        const int npx = next_pow2(n), npy = next_pow2(m);
+        for (int e = t; e < npx; e += G) { c.PX[e] = (e < n) ? xp[e] : INFINITY; IX[e] = (e < n) ? e : INT_MAX; }
+        for (int e = t; e < npy; e += G) { c.PY[e] = (e < m) ? yp[e] : INFINITY; IY[e] = (e < m) ? e : INT_MAX; }
+        __syncthreads();
+        bitonic_sort_kv(c.PX, IX, npx, t, G, [] { __syncthreads(); });
+        bitonic_sort_kv(c.PY, IY, npy, t, G, [] { __syncthreads(); });
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t * CPT + k;
+            ix[k] = (e < n) ? IX[e] : 0;
+            iy[k] = (e < m) ? IY[e] : 0;
+        }
     } else {
-        for (int e = t; e < m; e += G) V[e] = yr[e];
+        for (int e = t; e < n; e += G) c.PX[e] = xp[e];
+        for (int e = t; e < m; e += G) c.PY[e] = yp[e];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { ix[k] = t * CPT + k; iy[k] = t * CPT + k; }
     }
-    if (ROWPOS && t == 0) { PX[n] = PX[n - 1]; PY[m] = PY[m - 1]; }
     __syncthreads();
+    if (t == 0) { c.PX[n] = c.PX[n - 1]; c.PY[m] = c.PY[m - 1]; }
+    for (int e = t; e < c.pad; e += G) { c.PX[e - c.pad] = 0.0f; c.U[e - c.pad] = 0.0f; }  // the sort scratch overwrote them
+}
+
+// ---- P2-P3: row masses, safe_divide, weight gather, fp64-accumulated CDFs -----------------------------
+// Entry: U/V hold the raw weights in ORIGINAL column order (a barrier has been passed since they were
+// written).  Exit (after its final barrier): U/V hold the CDFs.  Each thread owns the CPT contiguous
+// elements [t*CPT, t*CPT + CPT) of each array in sorted order; wx/wy receive their ORIGINAL (unsquared)
+// weights and sidx/sidy their original column (both only consumed by the backward kernel).
+template <int G, int CPT, bool ROWPOS>
+__device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c, const int (&ix)[CPT], const int (&iy)[CPT],
+                                           float (&wx)[CPT], float (&wy)[CPT], int (&sidx)[CPT], int (&sidy)[CPT],
+                                           float& Sx_out, float& Sy_out, const bool stamp_on = false)
+{
+    (void)stamp_on;
+    constexpr int NW = G / kWave;
+    const int n = c.n, m = c.m, t = c.t;
+    float* const U = c.U; float* const V = c.V;
+    const bool sq = c.sq;
+    const int e0 = t * CPT;
 
     // ---- P2: row masses in ATen order (losses.py:177,184; the reference sums BEFORE it sorts, so the
-    //      staged row is still in its original element order here) ----------------------------------
+    //      staged row is still in its original column order here) -----------------------------------
+    float Sx = 1.0f, Sy = 1.0f;  // prenormalised: w / 1.0f == w exactly, weights enter the CDF unchanged
     if (!c.prenorm) {
         if (sq) {
             mass_chunk_sums<G, true>(U, c.partx, c.mpx, t);
@@ -237,48 +295,119 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             if (!c.dn) mass_chunk_sums<G, false>(V, c.party, c.mpy, (t + G / 2) & (G - 1));
         }
         __syncthreads();
-        if (c.wv == 0) {
+        SOT_STAMP(2);
+        // columns + fold by ONE wave per array (wave 0: x, wave 1: y; a single-wave row group does both
+        // in its two half-waves): the 32 column totals are exchanged through this wave's own LDS slots
+        float* const Sv = c.red + NW;
+        if (NW >= 2) {
+            if (c.wv < 2 && !(c.wv == 1 && c.dn)) {
+                const float* raw = c.wv ? V : U;
+                const float* part = c.wv ? c.party : c.partx;
+                const MassPlan& mp = c.wv ? c.mpy : c.mpx;
+                float* cb = c.colbuf + 32 * c.wv;
+                if (c.lane < 32) cb[c.lane] = sq ? mass_column<true>(raw, part, mp, c.lane) : mass_column<false>(raw, part, mp, c.lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float S = sq ? mass_fold<true>(raw, cb, mp.n) : mass_fold<false>(raw, cb, mp.n);
+                if (c.lane == 0) Sv[c.wv] = S;
+            }
+        } else {
             const int half = c.lane >> 5, col = c.lane & 31;
-            const bool use_y = half && !c.dn;  // in dont_normalize mode both halves sum x: S_y := S_x
-            const float S = sq ? mass_fold<true>(use_y ? V : U, use_y ? c.party : c.partx, use_y ? c.mpy : c.mpx, col, half << 5)
-                               : mass_fold<false>(use_y ? V : U, use_y ? c.party : c.partx, use_y ? c.mpy : c.mpx, col, half << 5);
-            if (col == 0) c.Sv[half] = S;
+            const bool use_y = half && !c.dn;
+            const float* raw = use_y ? V : U;
+            const float* part = use_y ? c.party : c.partx;
+            const MassPlan& mp = use_y ? c.mpy : c.mpx;
+            float* cb = c.colbuf + 32 * half;
+            cb[col] = sq ? mass_column<true>(raw, part, mp, col) : mass_column<false>(raw, part, mp, col);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float S = sq ? mass_fold<true>(raw, cb, mp.n) : mass_fold<false>(raw, cb, mp.n);
+            if (col == 0) Sv[half] = S;
         }
-    } else if (t == 0) {
-        c.Sv[0] = 1.0f;  // w / 1.0f == w exactly: weights enter the CDF unchanged
-        c.Sv[1] = 1.0f;
+        __syncthreads();
+        SOT_STAMP(3);
+        Sx = Sv[0];
+        Sy = c.dn ? Sx : Sv[1];
     }
-    __syncthreads();
+    Sx_out = Sx; Sy_out = Sy;
 
     // ---- P3: safe_divide (utils.py:135-142), weight gather by the position sort (losses.py:289-290)
     //      and fp64-accumulated CDFs (losses.py:292-293) --------------------------------------------
-    const float Sxh = guard_mass(c.Sv[0]);
-    const float Syh = guard_mass(c.Sv[1]);
+    const float Sxh = guard_mass(Sx);
+    const float Syh = guard_mass(Sy);
     const bool x_perm = ROWPOS ? c.do_sort : !c.x_ident;
     const bool y_perm = ROWPOS ? c.do_sort : !c.y_ident;
+    const bool fullx = (e0 + CPT <= n), fully = (e0 + CPT <= m);
+    // identity order + full chunk: two 16-B LDS reads per array; otherwise element-wise (also the gather)
+    if (!x_perm && fullx) {
+#pragma unroll
+        for (int k = 0; k < CPT; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(U + e0 + k);
+            wx[k] = v.x; wx[k + 1] = v.y; wx[k + 2] = v.z; wx[k + 3] = v.w;
+            sidx[k] = e0 + k; sidx[k + 1] = e0 + k + 1; sidx[k + 2] = e0 + k + 2; sidx[k + 3] = e0 + k + 3;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = e0 + k;
+            int sx = e;
+            if (ROWPOS) sx = ix[k]; else if (x_perm && e < n) sx = a.xperm[e];
+            wx[k] = (e < n) ? U[sx] : 0.0f;
+            sidx[k] = sx;
+        }
+    }
+    if (!y_perm && fully) {
+#pragma unroll
+        for (int k = 0; k < CPT; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(V + e0 + k);
+            wy[k] = v.x; wy[k + 1] = v.y; wy[k + 2] = v.z; wy[k + 3] = v.w;
+            sidy[k] = e0 + k; sidy[k + 1] = e0 + k + 1; sidy[k + 2] = e0 + k + 2; sidy[k + 3] = e0 + k + 3;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = e0 + k;
+            int sy = e;
+            if (ROWPOS) sy = iy[k]; else if (y_perm && e < m) sy = a.yperm[e];
+            wy[k] = (e < m) ? V[sy] : 0.0f;
+            sidy[k] = sy;
+        }
+    }
     double px[CPT], py[CPT];
     double runx = 0.0, runy = 0.0;
+    {
+        // quotients: reciprocal + FMA residual correction (exact, see div_by_row_constant); the chunk is
+        // redone with the IEEE sequence if an operand was small enough for the residual to underflow
+        const float rx = 1.0f / Sxh, ry = 1.0f / Syh;
+        float qx[CPT], qy[CPT];
+        uint32_t risk = 0xFFFFFFFFu;
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int ex = ex0 + k, ey = ey0 + k;
-        const bool okx = (k < c.cptn) && (ex < n), oky = (k < c.cptm) && (ey < m);
-        int sx = ex, sy = ey;
-        if (ROWPOS) { if (c.do_sort) { sx = ix[k]; sy = iy[k]; } }
-        else { if (x_perm && okx) sx = a.xperm[ex]; if (y_perm && oky) sy = a.yperm[ey]; }
-        const float ox = okx ? U[sx] : 0.0f;
-        const float oy = oky ? V[sy] : 0.0f;
-        wx[k] = ox; wy[k] = oy; sidx[k] = sx; sidy[k] = sy;
-        const float qx = (sq ? ox * ox : ox) / Sxh;  // IEEE division (built without fast-math / contraction)
-        const float qy = (sq ? oy * oy : oy) / Syh;
-        runx += okx ? (double)qx : 0.0;
-        runy += oky ? (double)qy : 0.0;
-        px[k] = runx;
-        py[k] = runy;
+        for (int k = 0; k < CPT; ++k) {
+            qx[k] = div_by_row_constant(sq ? wx[k] * wx[k] : wx[k], Sxh, rx, risk);
+            qy[k] = div_by_row_constant(sq ? wy[k] * wy[k] : wy[k], Syh, ry, risk);
+        }
+        if (risk < kFastDivMinBits || !(Sxh <= 0x1p40f) || !(Syh <= 0x1p40f)) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                qx[k] = (sq ? wx[k] * wx[k] : wx[k]) / Sxh;  // IEEE division (built without fast-math)
+                qy[k] = (sq ? wy[k] * wy[k] : wy[k]) / Syh;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const bool okx = (e0 + k < n), oky = (e0 + k < m);
+            runx += okx ? (double)qx[k] : 0.0;
+            runy += oky ? (double)qy[k] : 0.0;
+            px[k] = runx;
+            py[k] = runy;
+        }
     }
     const double inx = wave_incl_scan(runx), iny = wave_incl_scan(runy);
-    double exx = __shfl_up(inx, 1), exy = __shfl_up(iny, 1);
-    if (c.lane == 0) { exx = 0.0; exy = 0.0; }
+    double exx = wave_shift_right1(inx), exy = wave_shift_right1(iny);
     if (NW > 1 && c.lane == kWave - 1) { c.wtot[c.wv] = inx; c.wtot[NW + c.wv] = iny; }
+    SOT_STAMP(4);
     __syncthreads();  // every raw weight has been read (also through permutations) before U/V are rewritten
     if (NW > 1) {
         double ox = 0.0, oy = 0.0;
@@ -286,11 +415,23 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         exx += ox;
         exy += oy;
     }
+    if (fullx) {
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int ex = ex0 + k, ey = ey0 + k;
-        if ((k < c.cptn) && (ex < n)) U[ex] = (float)(exx + px[k]);
-        if ((k < c.cptm) && (ey < m)) V[ey] = (float)(exy + py[k]);
+        for (int k = 0; k < CPT; k += 4)
+            *reinterpret_cast<float4*>(U + e0 + k) = make_float4((float)(exx + px[k]), (float)(exx + px[k + 1]),
+                                                                 (float)(exx + px[k + 2]), (float)(exx + px[k + 3]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) if (e0 + k < n) U[e0 + k] = (float)(exx + px[k]);
+    }
+    if (fully) {
+#pragma unroll
+        for (int k = 0; k < CPT; k += 4)
+            *reinterpret_cast<float4*>(V + e0 + k) = make_float4((float)(exy + py[k]), (float)(exy + py[k + 1]),
+                                                                 (float)(exy + py[k + 2]), (float)(exy + py[k + 3]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) if (e0 + k < m) V[e0 + k] = (float)(exy + py[k]);
     }
     if (ROWPOS && t == 0) { U[n] = INFINITY; V[m] = INFINITY; }
     __syncthreads();
@@ -305,11 +446,18 @@ __device__ __forceinline__ int lower_rank(const float* A, int len, float q)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward kernel.  G threads per row, CPT = max elements of one array owned by a thread during
-// the scan, ROWPOS = positions differ per row (sorted in LDS when REQUIRE_SORT), QUANT = also
-// emit the return_quantiles tensors.
+// Forward kernel.
+//   G      threads per row (a whole number of wavefronts); 256-thread workgroups hold 256/G rows
+//   CPT    contiguous elements of each array owned by a thread during the scan (G*CPT >= max(n,m))
+//   ROWPOS positions differ per row (sorted in LDS when REQUIRE_SORT)
+//   QUANT  also emit the return_quantiles tensors
+//   PM     cost specialisation: 1 -> p == 1, 2 -> p == 2, 0 -> powf
+//   LIM    limit_quantile_range: levels Q_k > 1 contribute nothing
+//   VEC    rows are 16-B aligned and n, m multiples of 4: 16-B-per-lane global loads
+// Row pipeline: the NEXT row's weights are fetched into registers while the current row is being
+// processed in LDS, so HBM latency overlaps the scan/merge work of the same workgroup.
 // ---------------------------------------------------------------------------------------------
-template <int G, int CPT, bool ROWPOS, bool QUANT>
+template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
 __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const FwdArgs a)
 {
     constexpr int BLOCK = (G < 256 ? 256 : G);
@@ -322,33 +470,73 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
     float* const U = c.U; float* const V = c.V; float* const PX = c.PX; float* const PY = c.PY;
 
     const int64_t row_step = (int64_t)gridDim.x * RPW;
-    for (int64_t row0 = (int64_t)blockIdx.x * RPW; row0 < a.B; row0 += row_step) {
+    int64_t row0 = (int64_t)blockIdx.x * RPW;
+    float rx[CPT], ry[CPT];
+    if (row0 < a.B) {
+        const int64_t r = min(row0 + rg, a.B - 1);
+        load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
+        load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
+    }
+    for (; row0 < a.B; row0 += row_step) {
         const int64_t row = row0 + rg;
         const bool valid = row < a.B;
         const int64_t rowc = valid ? row : a.B - 1;
+#ifdef SOT_STAMPS
+        const bool stamp_on = (blockIdx.x == 0) && (threadIdx.x == 0) && (row0 == row_step);
+#endif
+        SOT_STAMP(0);
+        int ix[CPT], iy[CPT];
+        if (ROWPOS) rowpos_prepare<G, CPT>(a, c, rowc, ix, iy);
+        // ---- P1: registers -> LDS (original column order), then fetch the next row into the registers --
+        store_row<G, CPT, VEC>(U, n, t, rx);
+        store_row<G, CPT, VEC>(V, m, t, ry);
+        if (row0 + row_step < a.B) {
+            const int64_t r = min(row0 + row_step + rg, a.B - 1);
+            load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
+            load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
+        }
+        __syncthreads();
+        SOT_STAMP(1);
         float wx[CPT], wy[CPT]; int sidx[CPT], sidy[CPT];
-        build_cdfs<G, CPT, ROWPOS>(a, c, a.x + rowc * a.xs, a.y + rowc * a.ys, rowc, wx, wy, sidx, sidy);
+        float Sx, Sy;
+#ifdef SOT_STAMPS
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, sidx, sidy, Sx, Sy, stamp_on);
+#else
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, sidx, sidy, Sx, Sy);
+#endif
+        SOT_STAMP(5);
 
         // ---- P4: merge of the two CDFs = sort(cat(U,V)) + searchsorted + take_along_dim -----------
         //      (losses.py:295-298), level widths, cutoff mask, |.|^p, weighted sum (:301-313)
         float acc = 0.0f;
-        {
-            const int D0 = min(t * c.E, K), D1 = min(D0 + c.E, K);
-            if (D0 < D1) {
-                int i = merge_path(U, V, n, m, D0);
-                int j = D0 - i;
-                float qprev = 0.0f;  // Q_0 := 0 (the pad of losses.py:301)
-                if (i > 0) qprev = U[i - 1];
-                if (j > 0) qprev = fmaxf(qprev, V[j - 1]);
-                float ua = U[i], vb = V[j], xa = PX[i], yb = PY[j];
-                for (int k = D0; k < D1; ++k) {
-                    const bool tu = ua <= vb;
-                    const float q = tu ? ua : vb;
-                    const float cost = transport_cost(xa, yb, c.p);
-                    float delta = q - qprev;
-                    if (c.lim && q > 1.0f) delta = 0.0f;
-                    acc += delta * cost;
-                    if (QUANT && valid) {
+        if (t < c.Ga) {
+            // Walk over (Uw, V) where Uw = pad zero levels ++ U: exactly E steps for every thread.
+            const float* const Uw = U - c.pad;
+            const float* const PXw = PX - c.pad;
+            const int nw = n + c.pad;
+            const int D0 = t * c.E;
+            const int i0 = merge_path(Uw, V, nw, m, D0);
+            SOT_STAMP(6);
+            const int j0 = D0 - i0;
+            float qprev = 0.0f;  // Q_0 := 0 (the pad of losses.py:301)
+            if (i0 > 0) qprev = Uw[i0 - 1];
+            if (j0 > 0) qprev = fmaxf(qprev, V[j0 - 1]);
+            float ua = Uw[i0], vb = V[j0], xa = PXw[i0], yb = PY[j0];
+            // Byte offsets from Uw: Uw[i] at 4i; V[j] at 4(voff + j) with i + j = k => 4(voff + k) - 4i.
+            const char* const lb = reinterpret_cast<const char*>(Uw);
+            const uint32_t poff4 = 4u * (uint32_t)c.L.poff;
+            const int voff = (int)(V - Uw);
+            uint32_t iu = (uint32_t)i0;
+            for (int s = 0; s < c.E; ++s) {
+                const bool tu = ua <= vb;
+                const float q = tu ? ua : vb;
+                const float cost = transport_cost<PM>(xa, yb, c.p);
+                float delta = q - qprev;
+                if (LIM && q > 1.0f) delta = 0.0f;
+                acc = fmaf(delta, cost, acc);  // fused: no worse than the reference's separate rounding
+                if (QUANT && valid) {
+                    const int k = D0 + s - c.pad;  // index among the real merged levels
+                    if (k >= 0) {
                         const int64_t o = row * (int64_t)K + k;
                         if (a.oQ) a.oQ[o] = q;
                         if (a.oUq || a.oVq) {
@@ -361,30 +549,38 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
                             if (a.oVq) a.oVq[o] = vqv;
                         }
                     }
-                    qprev = q;
-                    const int idx = tu ? ++i : (c.L.nU + ++j);
-                    const float nv = c.base[idx];
-                    const float np = c.base[idx + c.L.poff];
-                    ua = tu ? nv : ua;
-                    xa = tu ? np : xa;
-                    vb = tu ? vb : nv;
-                    yb = tu ? yb : np;
                 }
+                qprev = q;
+                iu += tu ? 1u : 0u;
+                const uint32_t vk = (uint32_t)(voff + D0 + s + 1);  // uniform across the wave up to D0
+                const uint32_t off = 4u * (tu ? iu : (vk - iu));
+                const float nv = *reinterpret_cast<const float*>(lb + off);
+                const float np = *reinterpret_cast<const float*>(lb + off + poff4);
+                ua = tu ? nv : ua;
+                xa = tu ? np : xa;
+                vb = tu ? vb : nv;
+                yb = tu ? yb : np;
             }
         }
         if (QUANT && valid) {
             if (a.oU) for (int e = t; e < n; e += G) a.oU[row * (int64_t)n + e] = U[e];
             if (a.oV) for (int e = t; e < m; e += G) a.oV[row * (int64_t)m + e] = V[e];
         }
+        SOT_STAMP(7);
         acc = wave_sum(acc);
-        if (c.lane == 0) c.red[c.wv] = acc;
-        __syncthreads();
-        if (t == 0 && valid && a.row_loss) {
-            float tot = c.red[0];
-            for (int w = 1; w < NW; ++w) tot += c.red[w];
-            a.row_loss[row] = tot;
+        if (NW == 1) {
+            if (t == 0 && valid && a.row_loss) a.row_loss[row] = acc;
+            __syncthreads();  // this row's LDS reads are done before the next row's staging
+        } else {
+            if (c.lane == 0) c.red[c.wv] = acc;
+            __syncthreads();
+            if (t == 0 && valid && a.row_loss) {
+                float tot = c.red[0];
+                for (int w = 1; w < NW; ++w) tot += c.red[w];
+                a.row_loss[row] = tot;
+            }
         }
-        // the barrier above also orders this row's last LDS reads before the next row's staging
+        SOT_STAMP(8);
     }
 }
 
@@ -403,18 +599,7 @@ struct BwdArgs {
     float* gx; float* gy;
 };
 
-__device__ __forceinline__ double wave_suffix_incl_scan(double v)
-{
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const double o = __shfl_down(v, off);
-        if (lane + off < kWave) v += o;
-    }
-    return v;
-}
-
-template <int G, int CPT, bool ROWPOS>
+template <int G, int CPT, bool ROWPOS, int PM>
 __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const BwdArgs b)
 {
     constexpr int BLOCK = (G < 256 ? 256 : G);
@@ -432,8 +617,19 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         const int64_t row = row0 + rg;
         const bool valid = row < a.B;
         const int64_t rowc = valid ? row : a.B - 1;
+        int ix[CPT], iy[CPT];
+        if (ROWPOS) rowpos_prepare<G, CPT>(a, c, rowc, ix, iy);
+        {
+            float rx[CPT], ry[CPT];
+            load_row<G, CPT, false>(a.x + rowc * a.xs, n, t, rx);
+            load_row<G, CPT, false>(a.y + rowc * a.ys, m, t, ry);
+            store_row<G, CPT, false>(U, n, t, rx);
+            store_row<G, CPT, false>(V, m, t, ry);
+        }
+        __syncthreads();
         float wx[CPT], wy[CPT]; int sidx[CPT], sidy[CPT];
-        build_cdfs<G, CPT, ROWPOS>(a, c, a.x + rowc * a.xs, a.y + rowc * a.ys, rowc, wx, wy, sidx, sidy);
+        float Sx, Sy;
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, sidx, sidy, Sx, Sy);
 
         // ---- merge walk: route each run's gradient to its last member --------------------------------
         {
@@ -449,7 +645,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
                 {   // cost of the run the first element belongs to
                     const float q0 = fminf(ua, vb);
                     if (D0 > 0 && q0 == qprev) {  // we start inside a run: use the run's first member's ranks
-                        const float cst = transport_cost(PX[lower_rank(U, n, q0)], PY[lower_rank(V, m, q0)], c.p);
+                        const float cst = transport_cost<PM>(PX[lower_rank(U, n, q0)], PY[lower_rank(V, m, q0)], c.p);
                         dcur = (c.lim && q0 > 1.0f) ? 0.0f : cst;
                     }
                 }
@@ -457,14 +653,15 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
                     const bool tu = ua <= vb;
                     const float q = tu ? ua : vb;
                     if (k == 0 || q != qprev) {  // a new run starts here: its cost uses the running counts
-                        const float cst = transport_cost(xa, yb, c.p);
+                        const float cst = transport_cost<PM>(xa, yb, c.p);
                         dcur = (c.lim && q > 1.0f) ? 0.0f : cst;
                     }
                     qprev = q;
+                    const int voff = (int)(V - U);           // V[j] == U[voff + j], PX/PY sit c.L.poff further
                     const int slot = tu ? i : (c.L.nU + j);  // GU[i] or GV[j]  (GV = GU + nU)
-                    const int idx = tu ? ++i : (c.L.nU + ++j);
-                    const float nv = c.base[idx];
-                    const float np = c.base[idx + c.L.poff];
+                    const int idx = tu ? ++i : (voff + ++j);
+                    const float nv = U[idx];
+                    const float np = U[idx + c.L.poff];
                     ua = tu ? nv : ua;
                     xa = tu ? np : xa;
                     vb = tu ? vb : nv;
@@ -475,7 +672,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
                     } else {
                         const float qn = fminf(ua, vb);
                         if (qn != q) {
-                            const float cn = transport_cost(xa, yb, c.p);
+                            const float cn = transport_cost<PM>(xa, yb, c.p);
                             g = dcur - ((c.lim && qn > 1.0f) ? 0.0f : cn);
                         }
                     }
@@ -486,15 +683,14 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         __syncthreads();
 
         // ---- reverse cumsums (fp64), normalisation terms, scatter to the original columns -------------
-        const int ex0 = t * c.cptn, ey0 = t * c.cptm;
+        const int e0 = t * CPT;
         double ga[CPT], gb[CPT];
         double runx = 0.0, runy = 0.0;
 #pragma unroll
         for (int k = CPT - 1; k >= 0; --k) {
-            const int ex = ex0 + k, ey = ey0 + k;
-            const bool okx = (k < c.cptn) && (ex < n), oky = (k < c.cptm) && (ey < m);
-            runx += okx ? (double)c.GU[ex] : 0.0;
-            runy += oky ? (double)c.GV[ey] : 0.0;
+            const bool okx = (e0 + k < n), oky = (e0 + k < m);
+            runx += okx ? (double)c.GU[e0 + k] : 0.0;
+            runy += oky ? (double)c.GV[e0 + k] : 0.0;
             ga[k] = runx;
             gb[k] = runy;
         }
@@ -515,8 +711,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         for (int k = 0; k < CPT; ++k) {
             ga[k] += exx;
             gb[k] += exy;
-            const int ex = ex0 + k, ey = ey0 + k;
-            const bool okx = (k < c.cptn) && (ex < n), oky = (k < c.cptm) && (ey < m);
+            const bool okx = (e0 + k < n), oky = (e0 + k < m);
             const float sx = c.sq ? wx[k] * wx[k] : wx[k];
             const float sy = c.sq ? wy[k] * wy[k] : wy[k];
             dotx += okx ? ga[k] * (double)sx : 0.0;
@@ -529,7 +724,6 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         __syncthreads();
         double totx = 0.0, toty = 0.0;
         for (int w = 0; w < NW; ++w) { totx += c.wtot[w]; toty += c.wtot[NW + w]; }
-        const float Sx = c.Sv[0], Sy = c.Sv[1];
         const double dx = (double)guard_mass(Sx), dy = (double)guard_mass(Sy);
         double gSx = -totx, gSy = -toty;
         if (c.dn) { gSx += gSy; gSy = 0.0; }
@@ -539,13 +733,12 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         if (valid) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
-                const int ex = ex0 + k, ey = ey0 + k;
-                if (b.gx && (k < c.cptn) && (ex < n)) {
+                if (b.gx && (e0 + k < n)) {
                     double g = ga[k] / dx + gSx;
                     if (c.sq) g *= 2.0 * (double)wx[k];
                     b.gx[row * (int64_t)n + sidx[k]] = (float)(g * gr);
                 }
-                if (b.gy && (k < c.cptm) && (ey < m)) {
+                if (b.gy && (e0 + k < m)) {
                     double g = gb[k] / dy + gSy;
                     if (c.sq) g *= 2.0 * (double)wy[k];
                     b.gy[row * (int64_t)m + sidy[k]] = (float)(g * gr);
@@ -632,55 +825,102 @@ static int device_cu_count()
     return cus;
 }
 
+// Experiment knob (never set in production): SOT_DEBUG_EXTRA_LDS=<bytes> pads the dynamic LDS request of the
+// forward kernel to throttle its occupancy, which separates latency-bound from issue-bound behaviour.
+static size_t debug_extra_lds()
+{
+    const char* e = getenv("SOT_DEBUG_EXTRA_LDS");
+    return e ? (size_t)atol(e) : 0;
+}
+
 struct LaunchCfg { int G, CPT; };
 
+// Row-group geometries: (threads per row, contiguous elements per thread).  G*CPT >= max(n, m).
 static bool pick_cfg(int n, int m, bool rowpos, bool with_grad, LaunchCfg* cfg, size_t* lds_bytes, int* block, int* rpw)
 {
     const int N = n > m ? n : m;
-    static const int Gs[] = {64, 128, 256, 512, 1024};
-    for (int cpt = 8; cpt <= 16; cpt <<= 1) {
-        for (int gi = 0; gi < 5; ++gi) {
-            const int G = Gs[gi];
-            if ((int64_t)G * cpt < N) continue;
-            const int blk = G < 256 ? 256 : G;
-            const int r = blk / G;
-            const RowLayout L = make_layout(n, m, G, rowpos, with_grad);
-            const size_t bytes = (size_t)r * L.row_floats * sizeof(float);
-            if (bytes > kLdsLimit) continue;
-            cfg->G = G; cfg->CPT = cpt; *lds_bytes = bytes; *block = blk; *rpw = r;
-            return true;
-        }
+    static const LaunchCfg table[] = {{64, 8}, {256, 8}, {1024, 8}, {1024, 16}};
+    for (int ci = 0; ci < 4; ++ci) {
+        const LaunchCfg& c = table[ci];
+        if ((int64_t)c.G * c.CPT < N) continue;
+        const int blk = c.G < 256 ? 256 : c.G;
+        const int r = blk / c.G;
+        const RowLayout L = make_layout(n, m, c.G, rowpos, with_grad);
+        const size_t bytes = (size_t)r * L.row_floats * sizeof(float);
+        if (bytes > kLdsLimit) continue;
+        *cfg = c; *lds_bytes = bytes; *block = blk; *rpw = r;
+        return true;
     }
     return false;
 }
 
-template <int G, int CPT, bool ROWPOS, bool QUANT>
-static hipError_t launch_forward(const FwdArgs& a, size_t lds, int grid, int block, hipStream_t s)
+// Persistent grid: exactly as many workgroups as are co-resident (registers, LDS and wave slots all
+// taken into account by the occupancy query), never more than there are row groups.
+template <typename Kernel>
+static int resident_grid(Kernel kern, int block, size_t lds, int64_t want)
 {
-    auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        allow_full_lds(reinterpret_cast<const void*>(kern));
-        attr_set = true;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
     }
+    const int64_t cap = (int64_t)device_cu_count() * per_cu;
+    return (int)(want < cap ? want : cap);
+}
+
+template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
+static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT, PM, LIM, VEC>;
+    static const size_t extra_lds = debug_extra_lds();
+    lds += extra_lds;
+    static int grid_cap = 0;  // per instantiation; LDS size per (n, m) may differ, so cache per lds value
+    static size_t grid_lds = 0;
+    if (grid_cap == 0 || grid_lds != lds) {
+        allow_full_lds(reinterpret_cast<const void*>(kern));
+        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
+        grid_lds = lds;
+    }
+    const int grid = (int)(want < grid_cap ? want : grid_cap);
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
     return hipGetLastError();
 }
 
-template <bool ROWPOS, bool QUANT>
-static hipError_t dispatch_forward(const LaunchCfg& c, const FwdArgs& a, size_t lds, int grid, int block, hipStream_t s)
+template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
+static hipError_t dispatch_forward_pm(int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
 {
-    if (c.CPT == 8) {
-        switch (c.G) {
-            case 64: return launch_forward<64, 8, ROWPOS, QUANT>(a, lds, grid, block, s);
-            case 128: return launch_forward<128, 8, ROWPOS, QUANT>(a, lds, grid, block, s);
-            case 256: return launch_forward<256, 8, ROWPOS, QUANT>(a, lds, grid, block, s);
-            case 512: return launch_forward<512, 8, ROWPOS, QUANT>(a, lds, grid, block, s);
-            default: return launch_forward<1024, 8, ROWPOS, QUANT>(a, lds, grid, block, s);
-        }
+    switch (pm) {
+        case 1: return launch_forward<G, CPT, ROWPOS, false, 1, LIM, VEC>(a, lds, want, block, s);
+        case 2: return launch_forward<G, CPT, ROWPOS, false, 2, LIM, VEC>(a, lds, want, block, s);
+        default: return launch_forward<G, CPT, ROWPOS, false, 0, LIM, VEC>(a, lds, want, block, s);
     }
-    return launch_forward<1024, 16, ROWPOS, QUANT>(a, lds, grid, block, s);
+}
+
+template <int G, int CPT, bool ROWPOS>
+static hipError_t dispatch_forward_g(bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    const bool lim = a.flags & SOT_FLAG_LIMIT_Q;
+    if (quant)  // rare path: one generic build per cutoff flavour
+        return lim ? launch_forward<G, CPT, ROWPOS, true, 0, true, false>(a, lds, want, block, s)
+                   : launch_forward<G, CPT, ROWPOS, true, 0, false, false>(a, lds, want, block, s);
+    if (ROWPOS || !vec)
+        return lim ? dispatch_forward_pm<G, CPT, ROWPOS, true, false>(pm, a, lds, want, block, s)
+                   : dispatch_forward_pm<G, CPT, ROWPOS, false, false>(pm, a, lds, want, block, s);
+    return lim ? dispatch_forward_pm<G, CPT, false, true, true>(pm, a, lds, want, block, s)
+               : dispatch_forward_pm<G, CPT, false, false, true>(pm, a, lds, want, block, s);
+}
+
+template <bool ROWPOS>
+static hipError_t dispatch_forward(const LaunchCfg& c, bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want,
+                                   int block, hipStream_t s)
+{
+    if (c.CPT == 16) return dispatch_forward_g<1024, 16, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+    switch (c.G) {
+        case 64: return dispatch_forward_g<64, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+        case 256: return dispatch_forward_g<256, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+        default: return dispatch_forward_g<1024, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+    }
 }
 
 static int validate(const sot_problem* pr)
@@ -732,8 +972,10 @@ struct Launch {
     FwdArgs a;
     LaunchCfg cfg;
     size_t lds;
-    int block, grid;
-    bool rowpos;
+    int block;
+    int64_t want;  // row groups' worth of workgroups
+    bool rowpos, vec;
+    int pm;        // cost specialisation: 1 -> p == 1, 2 -> p == 2, 0 -> general
     hipStream_t s;
 };
 
@@ -774,14 +1016,11 @@ static int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, 
     }
     l.a = a;
 
-    // persistent grid: as many workgroups as the chip holds at this LDS footprint
-    int per_cu = (int)(kLdsLimit / l.lds);
-    const int wave_cap = 2048 / l.block;
-    if (per_cu > wave_cap) per_cu = wave_cap;
-    if (per_cu < 1) per_cu = 1;
-    const int64_t want = (pr->B + rpw - 1) / rpw;
-    const int64_t cap = (int64_t)device_cu_count() * per_cu;
-    l.grid = (int)(want < cap ? want : cap);
+    l.want = (pr->B + rpw - 1) / rpw;
+    l.pm = (pr->p == 1.0f) ? 1 : ((pr->p == 2.0f) ? 2 : 0);
+    // 16-B-per-lane loads need 16-B aligned rows of whole float4s
+    l.vec = ((n & 3) == 0) && ((m & 3) == 0) && ((pr->x_row_stride & 3) == 0) && ((pr->y_row_stride & 3) == 0) &&
+            ((reinterpret_cast<uintptr_t>(pr->x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(pr->y) & 15) == 0);
     return SOT_OK;
 }
 
@@ -794,41 +1033,47 @@ static int run_forward(const sot_problem* pr, float* row_loss, float* uq, float*
     if (pr->B == 0) return SOT_OK;
     l.a.row_loss = row_loss;
     l.a.oUq = uq; l.a.oVq = vq; l.a.oQ = Q; l.a.oU = U; l.a.oV = V;
-    hipError_t e;
-    if (l.rowpos) e = quant ? dispatch_forward<true, true>(l.cfg, l.a, l.lds, l.grid, l.block, l.s)
-                            : dispatch_forward<true, false>(l.cfg, l.a, l.lds, l.grid, l.block, l.s);
-    else e = quant ? dispatch_forward<false, true>(l.cfg, l.a, l.lds, l.grid, l.block, l.s)
-                   : dispatch_forward<false, false>(l.cfg, l.a, l.lds, l.grid, l.block, l.s);
+    const hipError_t e = l.rowpos ? dispatch_forward<true>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s)
+                                  : dispatch_forward<false>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
-template <int G, int CPT, bool ROWPOS>
-static hipError_t launch_backward(const BwdArgs& b, size_t lds, int grid, int block, hipStream_t s)
+template <int G, int CPT, bool ROWPOS, int PM>
+static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
 {
-    auto kern = sot_backward_kernel<G, CPT, ROWPOS>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM>;
+    static int grid_cap = 0;
+    static size_t grid_lds = 0;
+    if (grid_cap == 0 || grid_lds != lds) {
         allow_full_lds(reinterpret_cast<const void*>(kern));
-        attr_set = true;
+        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
+        grid_lds = lds;
     }
-    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
+    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
     return hipGetLastError();
 }
 
-template <bool ROWPOS>
-static hipError_t dispatch_backward(const LaunchCfg& c, const BwdArgs& b, size_t lds, int grid, int block, hipStream_t s)
+template <int G, int CPT, bool ROWPOS>
+static hipError_t dispatch_backward_g(int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
 {
-    if (c.CPT == 8) {
-        switch (c.G) {
-            case 64: return launch_backward<64, 8, ROWPOS>(b, lds, grid, block, s);
-            case 128: return launch_backward<128, 8, ROWPOS>(b, lds, grid, block, s);
-            case 256: return launch_backward<256, 8, ROWPOS>(b, lds, grid, block, s);
-            case 512: return launch_backward<512, 8, ROWPOS>(b, lds, grid, block, s);
-            default: return launch_backward<1024, 8, ROWPOS>(b, lds, grid, block, s);
-        }
+    switch (pm) {
+        case 1: return launch_backward<G, CPT, ROWPOS, 1>(b, lds, want, block, s);
+        case 2: return launch_backward<G, CPT, ROWPOS, 2>(b, lds, want, block, s);
+        default: return launch_backward<G, CPT, ROWPOS, 0>(b, lds, want, block, s);
     }
-    return launch_backward<1024, 16, ROWPOS>(b, lds, grid, block, s);
+}
+
+template <bool ROWPOS>
+static hipError_t dispatch_backward(const LaunchCfg& c, int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    if (c.CPT == 16) return dispatch_backward_g<1024, 16, ROWPOS>(pm, b, lds, want, block, s);
+    switch (c.G) {
+        case 64: return dispatch_backward_g<64, 8, ROWPOS>(pm, b, lds, want, block, s);
+        case 256: return dispatch_backward_g<256, 8, ROWPOS>(pm, b, lds, want, block, s);
+        default: return dispatch_backward_g<1024, 8, ROWPOS>(pm, b, lds, want, block, s);
+    }
 }
 
 static int run_backward(const sot_problem* pr, const float* grad_row, float* gx, float* gy, void* workspace,
@@ -841,8 +1086,8 @@ static int run_backward(const sot_problem* pr, const float* grad_row, float* gx,
     if (grad_row == nullptr) return SOT_ERR_NULL_POINTER;
     BwdArgs b{};
     b.f = l.a; b.grad_row = grad_row; b.gx = gx; b.gy = gy;
-    const hipError_t e = l.rowpos ? dispatch_backward<true>(l.cfg, b, l.lds, l.grid, l.block, l.s)
-                                  : dispatch_backward<false>(l.cfg, b, l.lds, l.grid, l.block, l.s);
+    const hipError_t e = l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, b, l.lds, l.want, l.block, l.s)
+                                  : dispatch_backward<false>(l.cfg, l.pm, b, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -854,6 +1099,15 @@ static int run_backward(const sot_problem* pr, const float* grad_row, float* gx,
 extern "C" {
 
 int sot_abi_version(void) { return SOT_ABI_VERSION; }
+
+#ifdef SOT_STAMPS
+// diagnostic build only: copies the phase stamps of workgroup 0's second row to the host (synchronises)
+int sot_debug_read_stamps(unsigned long long* host_out, int count)
+{
+    if (count > 32) count = 32;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sot::g_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#endif
 
 const char* sot_status_string(int status)
 {

@@ -285,3 +285,35 @@ def test_masked_dense_equals_ragged_removal():
         kx, ky = xm[r] > 0, ym[r] > 0
         one = mod(xm[r][kx][None].to(dev), ym[r][ky][None].to(dev), x_pos=pos[kx].to(dev), y_pos=pos[ky].to(dev)).cpu()
         torch.testing.assert_close(one, dense[r], rtol=5e-6, atol=0)
+
+
+@pytest.mark.parametrize("m", [1, 8])
+def test_row_constant_division_is_ieee_exact(m):
+    """The kernel divides by the row mass with a reciprocal + FMA-residual correction (IEEE fallback for tiny
+    operands).  Pin it against IEEE fp32 division on ~2M quotients: x row = [S] (n = 1, so the ATen-order
+    mass is S itself), dont_normalize => b_0 = y_0 / S and V_0 = fl32((double) b_0) = b_0."""
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    rng = np.random.default_rng(m)
+    B = 1 << 20
+    # divisors: random mantissas over many exponents + adversarial patterns (all-ones / one-bit mantissas)
+    mant = rng.integers(0, 1 << 23, B, dtype=np.uint32)
+    mant[: B // 8] = (1 << 23) - 1 - rng.integers(0, 4, B // 8, dtype=np.uint32)
+    mant[B // 8: B // 4] = rng.integers(0, 4, B // 8, dtype=np.uint32)
+    expo = rng.integers(127 - 20, 127 + 30, B, dtype=np.uint32)
+    S = ((expo << 23) | mant).view(np.float32)
+    # numerators: random mantissas, exponents from deep subnormal quotients up to > S (dont_normalize allows b > 1)
+    ymant = rng.integers(0, 1 << 23, (B, m), dtype=np.uint32)
+    yexp = rng.integers(1, 127 + 35, (B, m), dtype=np.uint32)
+    y = ((yexp << 23) | ymant).view(np.float32)
+    y[rng.random((B, m)) < 0.05] = 0.0
+    y[rng.random((B, m)) < 0.02] *= np.float32(1e-30)  # subnormal numerators / quotients
+    want = (y[:, 0] / S).astype(np.float32)            # numpy: IEEE fp32 division
+    mod = Wasserstein1D(p=1, dont_normalize=True, require_sort=False).to(dev)
+    px = torch.zeros(1, device=dev)
+    py = torch.linspace(0, 1, m, device=dev)
+    out = mod(to_dev(S[:, None]), to_dev(y), x_pos=px, y_pos=py, return_quantiles=True)
+    V0 = out[4][:, 0].cpu().numpy()
+    bad = V0.view(np.uint32) != want.view(np.uint32)
+    assert not bad.any(), (int(bad.sum()), S[bad][:4], y[bad, 0][:4], V0[bad][:4], want[bad][:4])

@@ -1,0 +1,42 @@
+"""Diagnostic: builds libsot_hip_stamps.so (-DSOT_STAMPS) and prints where one row of workgroup 0 spends
+its cycles (shares, not absolute speed: the stamp fences forbid overlaps the real kernel has)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import sot_amd  # noqa: E402
+from sot_amd import _native as nat  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "p1"
+B, N = 8192, int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+lib = os.path.join(ROOT, "gpurun_out", "libsot_hip_stamps.so")
+os.makedirs(os.path.dirname(lib), exist_ok=True)
+subprocess.run([sot_amd.build.hipcc_path(), *sot_amd.build.HIPCC_FLAGS, "-DSOT_STAMPS", "-o", lib, sot_amd.build.SRC], check=True)
+sot_amd.build.LIB = lib
+nat._lib = None
+h = nat.load(build_if_missing=False)
+from sot_amd.losses import Wasserstein1D  # noqa: E402
+
+dev = torch.device("cuda:0")
+MODES = {"p1": dict(p=1), "cutoff": dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)}
+mod = Wasserstein1D(**MODES[mode]).to(dev)
+x, y = torch.rand(B, N, device=dev), torch.rand(B, N, device=dev)
+pos = torch.linspace(0, 1, N, device=dev)
+for _ in range(5):
+    mod(x, y, x_pos=pos, y_pos=pos)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+raw = ctypes.CDLL(lib)
+raw.sot_debug_read_stamps(out, 16)
+names = ["store+prefetch+B1", "chunk sums+B2", "columns+B3", "fold+div+local scan+wave scan", "B4+offsets+write CDF+B5",
+         "merge_path", "merge walk", "reduce+B6+store"]
+tot = out[8] - out[0]
+print(f"mode={mode} N={N}: one row of WG0 = {tot} cycles")
+for i, nm in enumerate(names):
+    d = out[i + 1] - out[i]
+    print(f"  {nm:34s} {d:8d}  {100.0 * d / tot:5.1f}%")
