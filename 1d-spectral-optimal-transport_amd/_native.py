@@ -42,7 +42,10 @@ EXPORTS = {
     "sot_w1d_forward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_reduce_mean": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_float,
                                            _vp, _vp, _vp]),
-    "sot_w1d_backward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "sot_w1d_backward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, _vp,
+                                        ctypes.c_size_t, _vp]),
+    "sot_w1d_loss": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp, _vp,
+                                    _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_quantiles": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, _vp, _vp,
                                          ctypes.c_size_t, _vp]),
     "sot_segmented_sort": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
@@ -105,7 +108,26 @@ def require_hip(*tensors):
 
 
 def stream_ptr(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw hipStream_t of torch's current stream on `device` (cheap: no Stream object is built)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the common case costs nothing)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 def _ptr(t):
@@ -157,7 +179,7 @@ class PositionPlan:
         self.yperm = torch.empty(m, dtype=torch.int32, device=dev)
         self.ident = torch.empty(2, dtype=torch.int32, device=dev)
         xp, yp = xpos.contiguous(), ypos.contiguous()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
                                             self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
                                             self.yperm.data_ptr(), self.ident.data_ptr(), stream_ptr(dev)))
@@ -177,11 +199,30 @@ def forward_rows(x, y, xpos, ypos, p, flags, plan=None, out=None) -> torch.Tenso
     pr = make_problem(x, y, xpos, ypos, p, flags, plan)
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.sot_w1d_forward(ctypes.byref(pr), row_loss.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0,
                                  stream_ptr(dev))
     check(rc, p)
     return row_loss
+
+
+def loss_fused(x, y, xpos, ypos, p, flags, plan=None, denom=None, hinge=None, want_sum=False):
+    """Forward + batch mean behind one FFI call (sot_w1d_loss: two back-to-back kernels).  Returns (mean 0-d fp32, row_loss [B], sum fp64 or None)."""
+    lib = load()
+    dev = x.device
+    B = x.shape[0]
+    row_loss = torch.empty(B, dtype=torch.float32, device=dev)
+    mean = torch.empty((), dtype=torch.float32, device=dev)
+    total = torch.empty((), dtype=torch.float64, device=dev) if want_sum else None
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    ws = workspace(pr, dev) if need_ws else None
+    with _on_device(dev):
+        rc = lib.sot_w1d_loss(ctypes.byref(pr), row_loss.data_ptr(), float(B if denom is None else denom),
+                              0 if hinge is None else 1, 0.0 if hinge is None else float(hinge), mean.data_ptr(),
+                              _ptr(total), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
+    check(rc, p)
+    return mean, row_loss, total
 
 
 def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False):
@@ -190,14 +231,15 @@ def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False):
     B = row_loss.numel()
     mean = torch.empty((), dtype=torch.float32, device=dev)
     total = torch.empty((), dtype=torch.float64, device=dev) if want_sum else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib.sot_w1d_reduce_mean(row_loss.data_ptr(), B, float(B if denom is None else denom),
                                       0 if hinge is None else 1, 0.0 if hinge is None else float(hinge),
                                       mean.data_ptr(), _ptr(total), stream_ptr(dev)))
     return (mean, total) if want_sum else mean
 
 
-def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=True, plan=None):
+def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=True, plan=None, grad_scale=1.0):
+    """grad_row: [B] tensor, or a 0-d / 1-element tensor that is broadcast to every row (stride 0)."""
     lib = load()
     dev = x.device
     B, n = x.shape
@@ -208,8 +250,11 @@ def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=Tr
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
     g = grad_row.contiguous()
-    with torch.cuda.device(dev):
-        rc = lib.sot_w1d_backward(ctypes.byref(pr), g.data_ptr(), _ptr(gx), _ptr(gy), _ptr(ws),
+    stride = 0 if g.numel() == 1 else 1
+    if stride == 1 and g.numel() != B:
+        raise RuntimeError(f"grad_row has {g.numel()} elements for {B} rows")
+    with _on_device(dev):
+        rc = lib.sot_w1d_backward(ctypes.byref(pr), g.data_ptr(), stride, float(grad_scale), _ptr(gx), _ptr(gy), _ptr(ws),
                                   ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return gx, gy
@@ -229,7 +274,7 @@ def quantiles(x, y, xpos, ypos, p, flags, plan=None):
     pr = make_problem(x, y, xpos, ypos, p, flags, plan)
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.sot_w1d_quantiles(ctypes.byref(pr), uq.data_ptr(), vq.data_ptr(), Q.data_ptr(), U.data_ptr(),
                                    V.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
@@ -244,7 +289,7 @@ def segmented_sort(keys: torch.Tensor):
     B, n = keys.shape
     vals = torch.empty(B, n, dtype=torch.float32, device=keys.device)
     idx = torch.empty(B, n, dtype=torch.int64, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         check(lib.sot_segmented_sort(keys.data_ptr(), B, n, keys.stride(0) if B > 1 else n, vals.data_ptr(),
                                      idx.data_ptr(), stream_ptr(keys.device)))
     return vals, idx

@@ -31,7 +31,7 @@ struct RowLayout {
     int colbuf;          // 2 x 32 column totals of the row masses (16-B aligned)
     int wtot;            // 2 * NW doubles (float offset, 8-B aligned)
     int red;             // NW floats + 2 floats (S_x, S_y)
-    int grad;            // backward only: GU (nU floats) | GV (nV floats)
+    int grad;            // backward only: offset of the gradient arrays from U / V (regions mirror [U|V])
     int row_floats;      // total, multiple of 4
 };
 
@@ -64,7 +64,7 @@ __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpo
     const int NW = G / kWave;
     L.red = L.wtot + 4 * NW;  // 2 arrays * NW doubles = 4*NW floats
     L.grad = align4(L.red + NW + 2);
-    L.row_floats = with_grad ? L.grad + L.nU + L.nV : L.grad;
+    L.row_floats = with_grad ? L.grad + L.nU + L.nV : L.grad;  // GU = U + grad, GV = V + grad
     return L;
 }
 
@@ -160,7 +160,7 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     c.colbuf = c.base + c.L.colbuf;
     c.wtot = reinterpret_cast<double*>(c.base + c.L.wtot);
     c.red = c.base + c.L.red;
-    c.GU = c.base + c.L.grad; c.GV = c.GU + c.L.nU;
+    c.GU = c.U + c.L.grad; c.GV = c.V + c.L.grad;  // same offset from U and from V
     c.prenorm = a.flags & SOT_FLAG_PRENORMALIZED;
     c.sq = !c.prenorm && (a.flags & SOT_FLAG_SQUARE);
     c.dn = c.prenorm || (a.flags & SOT_FLAG_DONT_NORMALIZE);
@@ -263,18 +263,18 @@ __device__ __forceinline__ void rowpos_prepare(const FwdArgs& a, const RowCtx<G>
     }
     __syncthreads();
     if (t == 0) { c.PX[n] = c.PX[n - 1]; c.PY[m] = c.PY[m - 1]; }
-    for (int e = t; e < c.pad; e += G) { c.PX[e - c.pad] = 0.0f; c.U[e - c.pad] = 0.0f; }  // the sort scratch overwrote them
+    for (int e = t; e < c.pad; e += G) { c.PX[e - c.pad] = c.PX[0]; c.U[e - c.pad] = 0.0f; }  // pads sit at the first position
 }
 
 // ---- P2-P3: row masses, safe_divide, weight gather, fp64-accumulated CDFs -----------------------------
 // Entry: U/V hold the raw weights in ORIGINAL column order (a barrier has been passed since they were
 // written).  Exit (after its final barrier): U/V hold the CDFs.  Each thread owns the CPT contiguous
 // elements [t*CPT, t*CPT + CPT) of each array in sorted order; wx/wy receive their ORIGINAL (unsquared)
-// weights and sidx/sidy their original column (both only consumed by the backward kernel).
+// weights (only consumed by the backward kernel).
 template <int G, int CPT, bool ROWPOS>
 __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c, const int (&ix)[CPT], const int (&iy)[CPT],
-                                           float (&wx)[CPT], float (&wy)[CPT], int (&sidx)[CPT], int (&sidy)[CPT],
-                                           float& Sx_out, float& Sy_out, const bool stamp_on = false)
+                                           float (&wx)[CPT], float (&wy)[CPT], float& Sx_out, float& Sy_out,
+                                           const bool stamp_on = false)
 {
     (void)stamp_on;
     constexpr int NW = G / kWave;
@@ -346,7 +346,6 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         for (int k = 0; k < CPT; k += 4) {
             const float4 v = *reinterpret_cast<const float4*>(U + e0 + k);
             wx[k] = v.x; wx[k + 1] = v.y; wx[k + 2] = v.z; wx[k + 3] = v.w;
-            sidx[k] = e0 + k; sidx[k + 1] = e0 + k + 1; sidx[k + 2] = e0 + k + 2; sidx[k + 3] = e0 + k + 3;
         }
     } else {
 #pragma unroll
@@ -355,7 +354,6 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             int sx = e;
             if (ROWPOS) sx = ix[k]; else if (x_perm && e < n) sx = a.xperm[e];
             wx[k] = (e < n) ? U[sx] : 0.0f;
-            sidx[k] = sx;
         }
     }
     if (!y_perm && fully) {
@@ -363,7 +361,6 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         for (int k = 0; k < CPT; k += 4) {
             const float4 v = *reinterpret_cast<const float4*>(V + e0 + k);
             wy[k] = v.x; wy[k + 1] = v.y; wy[k + 2] = v.z; wy[k + 3] = v.w;
-            sidy[k] = e0 + k; sidy[k + 1] = e0 + k + 1; sidy[k + 2] = e0 + k + 2; sidy[k + 3] = e0 + k + 3;
         }
     } else {
 #pragma unroll
@@ -372,7 +369,6 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             int sy = e;
             if (ROWPOS) sy = iy[k]; else if (y_perm && e < m) sy = a.yperm[e];
             wy[k] = (e < m) ? V[sy] : 0.0f;
-            sidy[k] = sy;
         }
     }
     double px[CPT], py[CPT];
@@ -497,12 +493,12 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         }
         __syncthreads();
         SOT_STAMP(1);
-        float wx[CPT], wy[CPT]; int sidx[CPT], sidy[CPT];
+        float wx[CPT], wy[CPT];
         float Sx, Sy;
 #ifdef SOT_STAMPS
-        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, sidx, sidy, Sx, Sy, stamp_on);
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy, stamp_on);
 #else
-        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, sidx, sidy, Sx, Sy);
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy);
 #endif
         SOT_STAMP(5);
 
@@ -595,11 +591,13 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
 // ---------------------------------------------------------------------------------------------
 struct BwdArgs {
     FwdArgs f;
-    const float* grad_row;
+    const float* grad_row;     // dL/d(row_loss): [B] (stride 1) or one broadcast scalar (stride 0)
+    int64_t grad_row_stride;
+    float grad_scale;          // multiplies every upstream gradient (1/B of the batch mean)
     float* gx; float* gy;
 };
 
-template <int G, int CPT, bool ROWPOS, int PM>
+template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
 __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const BwdArgs b)
 {
     constexpr int BLOCK = (G < 256 ? 256 : G);
@@ -609,75 +607,89 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
     const FwdArgs& a = b.f;
     const RowCtx<G> c = make_ctx<G, ROWPOS>(a, smem, true);
     const int rg = threadIdx.x / G;
-    const int n = c.n, m = c.m, K = c.K, t = c.t;
+    const int n = c.n, m = c.m, t = c.t;
     float* const U = c.U; float* const V = c.V; float* const PX = c.PX; float* const PY = c.PY;
 
     const int64_t row_step = (int64_t)gridDim.x * RPW;
-    for (int64_t row0 = (int64_t)blockIdx.x * RPW; row0 < a.B; row0 += row_step) {
+    int64_t row0 = (int64_t)blockIdx.x * RPW;
+    float rx[CPT], ry[CPT];
+    if (row0 < a.B) {
+        const int64_t r = min(row0 + rg, a.B - 1);
+        load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
+        load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
+    }
+    for (; row0 < a.B; row0 += row_step) {
         const int64_t row = row0 + rg;
         const bool valid = row < a.B;
         const int64_t rowc = valid ? row : a.B - 1;
         int ix[CPT], iy[CPT];
         if (ROWPOS) rowpos_prepare<G, CPT>(a, c, rowc, ix, iy);
-        {
-            float rx[CPT], ry[CPT];
-            load_row<G, CPT, false>(a.x + rowc * a.xs, n, t, rx);
-            load_row<G, CPT, false>(a.y + rowc * a.ys, m, t, ry);
-            store_row<G, CPT, false>(U, n, t, rx);
-            store_row<G, CPT, false>(V, m, t, ry);
+        store_row<G, CPT, VEC>(U, n, t, rx);
+        store_row<G, CPT, VEC>(V, m, t, ry);
+        if (row0 + row_step < a.B) {
+            const int64_t r = min(row0 + row_step + rg, a.B - 1);
+            load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
+            load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
         }
         __syncthreads();
-        float wx[CPT], wy[CPT]; int sidx[CPT], sidy[CPT];
+        float wx[CPT], wy[CPT];
         float Sx, Sy;
-        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, sidx, sidy, Sx, Sy);
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy);
 
-        // ---- merge walk: route each run's gradient to its last member --------------------------------
-        {
-            const int D0 = min(t * c.E, K), D1 = min(D0 + c.E, K);
-            if (D0 < D1) {
-                int i = merge_path(U, V, n, m, D0);
-                int j = D0 - i;
-                float qprev = 0.0f;
-                if (i > 0) qprev = U[i - 1];
-                if (j > 0) qprev = fmaxf(qprev, V[j - 1]);
-                float ua = U[i], vb = V[j], xa = PX[i], yb = PY[j];
-                float dcur = 0.0f;
-                {   // cost of the run the first element belongs to
-                    const float q0 = fminf(ua, vb);
-                    if (D0 > 0 && q0 == qprev) {  // we start inside a run: use the run's first member's ranks
-                        const float cst = transport_cost<PM>(PX[lower_rank(U, n, q0)], PY[lower_rank(V, m, q0)], c.p);
-                        dcur = (c.lim && q0 > 1.0f) ? 0.0f : cst;
-                    }
-                }
-                for (int k = D0; k < D1; ++k) {
-                    const bool tu = ua <= vb;
-                    const float q = tu ? ua : vb;
-                    if (k == 0 || q != qprev) {  // a new run starts here: its cost uses the running counts
-                        const float cst = transport_cost<PM>(xa, yb, c.p);
-                        dcur = (c.lim && q > 1.0f) ? 0.0f : cst;
-                    }
-                    qprev = q;
-                    const int voff = (int)(V - U);           // V[j] == U[voff + j], PX/PY sit c.L.poff further
-                    const int slot = tu ? i : (c.L.nU + j);  // GU[i] or GV[j]  (GV = GU + nU)
-                    const int idx = tu ? ++i : (voff + ++j);
-                    const float nv = U[idx];
-                    const float np = U[idx + c.L.poff];
-                    ua = tu ? nv : ua;
-                    xa = tu ? np : xa;
-                    vb = tu ? vb : nv;
-                    yb = tu ? yb : np;
-                    float g = 0.0f;
-                    if (k + 1 == K) {
-                        g = dcur;
-                    } else {
-                        const float qn = fminf(ua, vb);
-                        if (qn != q) {
-                            const float cn = transport_cost<PM>(xa, yb, c.p);
-                            g = dcur - ((c.lim && qn > 1.0f) ? 0.0f : cn);
-                        }
-                    }
-                    c.GU[slot] = g;
-                }
+        // ---- merge walk over (pad zero levels ++ U, V), exactly E steps per thread.  The gradient of a level
+        //      is known one step later (it is non-zero only if the NEXT level starts a new run), so the store
+        //      of element k-1 happens at step k; the thread's last element is closed by peeking at level D0+E.
+        if (t < c.Ga) {
+            const float* const Uw = U - c.pad;
+            const float* const PXw = PX - c.pad;
+            const int nw = n + c.pad;
+            const int D0 = t * c.E;
+            const int i0 = merge_path(Uw, V, nw, m, D0);
+            const int j0 = D0 - i0;
+            float qprev = 0.0f;
+            if (i0 > 0) qprev = Uw[i0 - 1];
+            if (j0 > 0) qprev = fmaxf(qprev, V[j0 - 1]);
+            float ua = Uw[i0], vb = V[j0], xa = PXw[i0], yb = PY[j0];
+            float dcur = 0.0f;
+            if (D0 == 0) {
+                qprev = __int_as_float(0x7fc00000);  // NaN: the very first level always starts a run
+            } else if (fminf(ua, vb) == qprev) {      // we start inside a run: cost at its first member's ranks
+                const float q0 = qprev;
+                const float cst = transport_cost<PM>(PX[lower_rank(U, n, q0)], PY[lower_rank(V, m, q0)], c.p);
+                dcur = (LIM && q0 > 1.0f) ? 0.0f : cst;
+            }
+            char* const lb = reinterpret_cast<char*>(const_cast<float*>(Uw));
+            const uint32_t poff4 = 4u * (uint32_t)c.L.poff;
+            const uint32_t goff4 = 4u * (uint32_t)c.L.grad;
+            const int voff = (int)(V - Uw);
+            uint32_t iu = (uint32_t)i0;
+            uint32_t prev_off = 4u * (uint32_t)(c.pad + n);  // U[n]'s gradient slot: a scratch target for "no element yet"
+            for (int s = 0; s < c.E; ++s) {
+                const bool tu = ua <= vb;
+                const float q = tu ? ua : vb;
+                float cst = transport_cost<PM>(xa, yb, c.p);
+                if (LIM && q > 1.0f) cst = 0.0f;
+                const bool new_run = !(q == qprev);
+                *reinterpret_cast<float*>(lb + prev_off + goff4) = new_run ? (dcur - cst) : 0.0f;
+                dcur = new_run ? cst : dcur;
+                qprev = q;
+                const uint32_t vk = (uint32_t)(voff + D0 + s);
+                prev_off = 4u * (tu ? iu : (vk - iu));  // slot of the element consumed now
+                iu += tu ? 1u : 0u;
+                const uint32_t off = prev_off + 4u;  // the consumed side's next element
+                const float nv = *reinterpret_cast<const float*>(lb + off);
+                const float np = *reinterpret_cast<const float*>(lb + off + poff4);
+                ua = tu ? nv : ua;
+                xa = tu ? np : xa;
+                vb = tu ? vb : nv;
+                yb = tu ? yb : np;
+            }
+            {   // close the last element with the level that follows this thread's range (0 cost past the end)
+                const float qn = fminf(ua, vb);
+                float cn = transport_cost<PM>(xa, yb, c.p);
+                if ((LIM && qn > 1.0f) || (t == c.Ga - 1)) cn = 0.0f;
+                const bool new_run = !(qn == qprev) || (t == c.Ga - 1);
+                *reinterpret_cast<float*>(lb + prev_off + goff4) = new_run ? (dcur - cn) : 0.0f;
             }
         }
         __syncthreads();
@@ -694,11 +706,12 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
             ga[k] = runx;
             gb[k] = runy;
         }
-        const double inx = wave_suffix_incl_scan(runx), iny = wave_suffix_incl_scan(runy);
-        double exx = __shfl_down(inx, 1), exy = __shfl_down(iny, 1);
-        if (c.lane == kWave - 1) { exx = 0.0; exy = 0.0; }
+        // exclusive suffix over lanes = wave total - inclusive prefix (fp64: the cancellation is harmless)
+        const double pinx = wave_incl_scan(runx), piny = wave_incl_scan(runy);
+        const double totwx = wave_last(pinx), totwy = wave_last(piny);
+        double exx = totwx - pinx, exy = totwy - piny;
         if (NW > 1) {
-            if (c.lane == 0) { c.wtot[c.wv] = inx; c.wtot[NW + c.wv] = iny; }
+            if (c.lane == 0) { c.wtot[c.wv] = totwx; c.wtot[NW + c.wv] = totwy; }
             __syncthreads();
             double ox = 0.0, oy = 0.0;
             for (int w = NW - 1; w > c.wv; --w) { ox += c.wtot[w]; oy += c.wtot[NW + w]; }
@@ -719,29 +732,60 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         }
         dotx = wave_sum(dotx);
         doty = wave_sum(doty);
-        if (NW > 1) __syncthreads();  // wtot is reused below
-        if (c.lane == 0) { c.wtot[c.wv] = dotx; c.wtot[NW + c.wv] = doty; }
-        __syncthreads();
-        double totx = 0.0, toty = 0.0;
-        for (int w = 0; w < NW; ++w) { totx += c.wtot[w]; toty += c.wtot[NW + w]; }
+        double totx = dotx, toty = doty;
+        if (NW > 1) {
+            __syncthreads();  // wtot is reused
+            if (c.lane == 0) { c.wtot[c.wv] = dotx; c.wtot[NW + c.wv] = doty; }
+            __syncthreads();
+            totx = 0.0; toty = 0.0;
+            for (int w = 0; w < NW; ++w) { totx += c.wtot[w]; toty += c.wtot[NW + w]; }
+        }
         const double dx = (double)guard_mass(Sx), dy = (double)guard_mass(Sy);
+        const double rdx = 1.0 / dx, rdy = 1.0 / dy;
         double gSx = -totx, gSy = -toty;
         if (c.dn) { gSx += gSy; gSy = 0.0; }
-        gSx = (!c.prenorm && Sx > kMassEps) ? gSx / (dx * dx) : 0.0;
-        gSy = (!c.prenorm && Sy > kMassEps) ? gSy / (dy * dy) : 0.0;
-        const double gr = (double)b.grad_row[rowc];
+        gSx = (!c.prenorm && Sx > kMassEps) ? gSx * rdx * rdx : 0.0;
+        gSy = (!c.prenorm && Sy > kMassEps) ? gSy * rdy * rdy : 0.0;
+        const double gr = (double)b.grad_row[rowc * b.grad_row_stride] * (double)b.grad_scale;
         if (valid) {
+            const bool x_perm = ROWPOS ? c.do_sort : !c.x_ident;
+            const bool y_perm = ROWPOS ? c.do_sort : !c.y_ident;
+            float ox[CPT], oy[CPT];
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
-                if (b.gx && (e0 + k < n)) {
-                    double g = ga[k] / dx + gSx;
-                    if (c.sq) g *= 2.0 * (double)wx[k];
-                    b.gx[row * (int64_t)n + sidx[k]] = (float)(g * gr);
+                double g = ga[k] * rdx + gSx;
+                if (c.sq) g *= 2.0 * (double)wx[k];
+                ox[k] = (float)(g * gr);
+                double h = gb[k] * rdy + gSy;
+                if (c.sq) h *= 2.0 * (double)wy[k];
+                oy[k] = (float)(h * gr);
+            }
+            if (b.gx) {
+                float* dst = b.gx + row * (int64_t)n;
+                if (VEC && !x_perm && (e0 + CPT <= n)) {
+#pragma unroll
+                    for (int k = 0; k < CPT; k += 4)
+                        *reinterpret_cast<float4*>(dst + e0 + k) = make_float4(ox[k], ox[k + 1], ox[k + 2], ox[k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        const int e = e0 + k;
+                        if (e < n) dst[ROWPOS ? (x_perm ? ix[k] : e) : (x_perm ? a.xperm[e] : e)] = ox[k];
+                    }
                 }
-                if (b.gy && (e0 + k < m)) {
-                    double g = gb[k] / dy + gSy;
-                    if (c.sq) g *= 2.0 * (double)wy[k];
-                    b.gy[row * (int64_t)m + sidy[k]] = (float)(g * gr);
+            }
+            if (b.gy) {
+                float* dst = b.gy + row * (int64_t)m;
+                if (VEC && !y_perm && (e0 + CPT <= m)) {
+#pragma unroll
+                    for (int k = 0; k < CPT; k += 4)
+                        *reinterpret_cast<float4*>(dst + e0 + k) = make_float4(oy[k], oy[k + 1], oy[k + 2], oy[k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        const int e = e0 + k;
+                        if (e < m) dst[ROWPOS ? (y_perm ? iy[k] : e) : (y_perm ? a.yperm[e] : e)] = oy[k];
+                    }
                 }
             }
         }
@@ -1038,10 +1082,10 @@ static int run_forward(const sot_problem* pr, float* row_loss, float* uq, float*
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
-template <int G, int CPT, bool ROWPOS, int PM>
+template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
 static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
 {
-    auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM>;
+    auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM, LIM, VEC>;
     static int grid_cap = 0;
     static size_t grid_lds = 0;
     if (grid_cap == 0 || grid_lds != lds) {
@@ -1055,29 +1099,41 @@ static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, in
     return hipGetLastError();
 }
 
-template <int G, int CPT, bool ROWPOS>
-static hipError_t dispatch_backward_g(int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
+static hipError_t dispatch_backward_pm(int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
 {
     switch (pm) {
-        case 1: return launch_backward<G, CPT, ROWPOS, 1>(b, lds, want, block, s);
-        case 2: return launch_backward<G, CPT, ROWPOS, 2>(b, lds, want, block, s);
-        default: return launch_backward<G, CPT, ROWPOS, 0>(b, lds, want, block, s);
+        case 1: return launch_backward<G, CPT, ROWPOS, 1, LIM, VEC>(b, lds, want, block, s);
+        case 2: return launch_backward<G, CPT, ROWPOS, 2, LIM, VEC>(b, lds, want, block, s);
+        default: return launch_backward<G, CPT, ROWPOS, 0, LIM, VEC>(b, lds, want, block, s);
     }
+}
+
+template <int G, int CPT, bool ROWPOS>
+static hipError_t dispatch_backward_g(int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    const bool lim = b.f.flags & SOT_FLAG_LIMIT_Q;
+    if (ROWPOS || !vec)
+        return lim ? dispatch_backward_pm<G, CPT, ROWPOS, true, false>(pm, b, lds, want, block, s)
+                   : dispatch_backward_pm<G, CPT, ROWPOS, false, false>(pm, b, lds, want, block, s);
+    return lim ? dispatch_backward_pm<G, CPT, false, true, true>(pm, b, lds, want, block, s)
+               : dispatch_backward_pm<G, CPT, false, false, true>(pm, b, lds, want, block, s);
 }
 
 template <bool ROWPOS>
-static hipError_t dispatch_backward(const LaunchCfg& c, int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+static hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block,
+                                    hipStream_t s)
 {
-    if (c.CPT == 16) return dispatch_backward_g<1024, 16, ROWPOS>(pm, b, lds, want, block, s);
+    if (c.CPT == 16) return dispatch_backward_g<1024, 16, ROWPOS>(pm, vec, b, lds, want, block, s);
     switch (c.G) {
-        case 64: return dispatch_backward_g<64, 8, ROWPOS>(pm, b, lds, want, block, s);
-        case 256: return dispatch_backward_g<256, 8, ROWPOS>(pm, b, lds, want, block, s);
-        default: return dispatch_backward_g<1024, 8, ROWPOS>(pm, b, lds, want, block, s);
+        case 64: return dispatch_backward_g<64, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
+        case 256: return dispatch_backward_g<256, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
+        default: return dispatch_backward_g<1024, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
     }
 }
 
-static int run_backward(const sot_problem* pr, const float* grad_row, float* gx, float* gy, void* workspace,
-                        size_t workspace_bytes, void* stream)
+static int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx,
+                        float* gy, void* workspace, size_t workspace_bytes, void* stream)
 {
     Launch l;
     int rc = setup_launch(pr, true, workspace, workspace_bytes, stream, &l);
@@ -1085,9 +1141,9 @@ static int run_backward(const sot_problem* pr, const float* grad_row, float* gx,
     if (pr->B == 0 || (gx == nullptr && gy == nullptr)) return SOT_OK;
     if (grad_row == nullptr) return SOT_ERR_NULL_POINTER;
     BwdArgs b{};
-    b.f = l.a; b.grad_row = grad_row; b.gx = gx; b.gy = gy;
-    const hipError_t e = l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, b, l.lds, l.want, l.block, l.s)
-                                  : dispatch_backward<false>(l.cfg, l.pm, b, l.lds, l.want, l.block, l.s);
+    b.f = l.a; b.grad_row = grad_row; b.grad_row_stride = grad_row_stride; b.grad_scale = grad_scale; b.gx = gx; b.gy = gy;
+    const hipError_t e = l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s)
+                                  : dispatch_backward<false>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -1162,10 +1218,23 @@ int sot_w1d_reduce_mean(const float* row_loss, int64_t B, double denom, int appl
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
-int sot_w1d_backward(const sot_problem* prob, const float* grad_row, float* grad_x, float* grad_y, void* workspace,
-                     size_t workspace_bytes, void* stream)
+int sot_w1d_backward(const sot_problem* prob, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* grad_x,
+                     float* grad_y, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return sot::run_backward(prob, grad_row, grad_x, grad_y, workspace, workspace_bytes, stream);
+    if (grad_row_stride != 0 && grad_row_stride != 1) return SOT_ERR_BAD_SHAPE;
+    return sot::run_backward(prob, grad_row, grad_row_stride, grad_scale, grad_x, grad_y, workspace, workspace_bytes, stream);
+}
+
+int sot_w1d_loss(const sot_problem* prob, float* row_loss, double denom, int apply_hinge, float hinge_threshold, float* mean_out,
+                 double* sum_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (prob != nullptr && prob->B > 0 && row_loss == nullptr) return SOT_ERR_NULL_POINTER;
+    if (mean_out == nullptr && sum_out == nullptr) return SOT_ERR_NULL_POINTER;
+    if (prob != nullptr && prob->B == 0) return SOT_ERR_BAD_SHAPE;  // the mean of zero rows is undefined
+    const int rc = sot::run_forward(prob, row_loss, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes,
+                                    stream);
+    if (rc != SOT_OK) return rc;
+    return sot_w1d_reduce_mean(row_loss, prob->B, denom, apply_hinge, hinge_threshold, mean_out, sum_out, stream);
 }
 
 int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stride, float* sorted_keys, int64_t* indices,

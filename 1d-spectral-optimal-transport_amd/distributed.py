@@ -71,5 +71,5 @@ def sharded_sot_loss(loss_module, x_local, y_local, x_pos=None, y_pos=None, grou
     the module on the concatenated batch (dims=None): local kernel -> local fp64 sum -> all-reduce of
     ONE scalar -> divide by the global row count."""
     rows = loss_module.row_losses(x_local, y_local, x_pos=x_pos, y_pos=y_pos, **kwargs)
-    local_sum = _RowSum.apply(rows)
+    local_sum = _RowSum.apply(rows)  # differentiable; bench.py uses the fused no-grad form (nat.loss_fused)
     return global_mean_from_local_sum(local_sum, rows.numel(), group)

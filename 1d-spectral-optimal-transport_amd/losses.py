@@ -54,6 +54,28 @@ class _RowLoss(torch.autograd.Function):
         return gx, gy, None, None, None, None, None
 
 
+class _FusedMeanLoss(torch.autograd.Function):
+    """losses.py:129-211 with dims=None behind ONE native call (forward kernel + fixed-order batch-mean kernel); the backward feeds the
+    scalar upstream gradient to the HIP backward kernel as a broadcast value scaled by 1/B."""
+
+    @staticmethod
+    def forward(ctx, x, y, xpos, ypos, p, flags, plan):
+        mean, _, _ = nat.loss_fused(x, y, xpos, ypos, p, flags, plan)
+        ctx.save_for_backward(x, y, xpos, ypos)
+        ctx.p, ctx.flags, ctx.plan = p, flags, plan
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, xpos, ypos = ctx.saved_tensors
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise NotImplementedError("gradients w.r.t. support positions are not implemented "
+                                      "(no reference call site uses them)")
+        gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, g.float(), need_gx=ctx.needs_input_grad[0],
+                                   need_gy=ctx.needs_input_grad[1], plan=ctx.plan, grad_scale=1.0 / x.shape[0])
+        return gx, gy, None, None, None, None, None
+
+
 class _RowMean(torch.autograd.Function):
     """losses.py:211 with dims=None: fixed-order fp64 accumulation on the GPU."""
 
@@ -199,7 +221,10 @@ class Wasserstein1D(torch.nn.Module):
         """Flat [rows] tensor of W_p^p per spectrum pair (after the optional hinge, before the mean):
         what losses.py:186-205 holds before its reshape/mean.  Used by the row-sharded multi-GPU path."""
         x, y, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
-        loss = _RowLoss.apply(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+            loss = _RowLoss.apply(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
+        else:
+            loss = nat.forward_rows(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
         if self.hinge:
             loss = torch.nn.functional.relu(loss - kwargs.get("hinge", 0.0))
         return loss
@@ -211,8 +236,14 @@ class Wasserstein1D(torch.nn.Module):
             return [t.reshape(original_shape + (-1,)) for t in out]
 
         original_shape = x.shape[:-1]
-        loss = self.row_losses(x, y, x_pos, y_pos, **kwargs)
         dims = kwargs.get("dims", None)
+        if dims is None and not self.hinge:
+            # default reduction: forward and the mean over every row (losses.py:211) in one native call
+            x2, y2, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
+            if torch.is_grad_enabled() and (x2.requires_grad or y2.requires_grad):
+                return _FusedMeanLoss.apply(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
+            return nat.loss_fused(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)[0]
+        loss = self.row_losses(x, y, x_pos, y_pos, **kwargs)
         if dims is None:
             return _RowMean.apply(loss)  # torch.mean over every row -> 0-d tensor (losses.py:211)
         loss = loss.reshape(original_shape)

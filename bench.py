@@ -52,29 +52,35 @@ def parse():
 
 
 def cpu_baseline(mode, n, rows, seed):
-    """The reference's CPU PyTorch path (op-for-op restatement), all host cores, bounded sample."""
+    """The reference's CPU PyTorch path (op-for-op restatement) on this host's cores, bounded sample.
+    ATen's intra-op scaling on this problem saturates well below a big host's core count, so a few thread
+    counts are tried (within a ~25 s budget) and the best is reported with the count actually used."""
     from oracle import torch_restatement as tr
     from oracle.inputs import gen_inputs
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     x, y = gen_inputs("uniform", rows, n, n, seed)
     pos = torch.linspace(0, 1, n)
     c = MODES[mode]
     kw = dict(p=c.get("p", 1), square_dist=c.get("square_dist", False), dont_normalize=c.get("dont_normalize", False),
               limit_quantile_range=c.get("limit_quantile_range", False))
-    with torch.no_grad():
-        tr.sot_loss(x, y, pos, pos.clone(), **kw)  # warm-up
-        best = float("inf")
-        t_end = time.perf_counter() + 20.0
-        reps = 0
-        while reps < 5 and time.perf_counter() < t_end:
-            t0 = time.perf_counter()
-            val = tr.sot_loss(x, y, pos, pos.clone(), **kw)
-            best = min(best, time.perf_counter() - t0)
-            reps += 1
-    return {"value": rows / best, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": f"{rows} rows x N={n}, mode {mode}, best of {reps} calls of oracle/torch_restatement.sot_loss "
-                      f"(torch {torch.__version__} CPU, {cores} threads)", "scalar": float(val)}
+    best, best_threads, val, tried = float("inf"), 1, 0.0, []
+    t_end = time.perf_counter() + 25.0
+    for threads in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
+        if time.perf_counter() > t_end:
+            break
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            tr.sot_loss(x, y, pos, pos.clone(), **kw)  # warm-up
+            for _ in range(2):
+                t0 = time.perf_counter()
+                val = tr.sot_loss(x, y, pos, pos.clone(), **kw)
+                dt = time.perf_counter() - t0
+                if dt < best:
+                    best, best_threads = dt, threads
+        tried.append(threads)
+    return {"value": rows / best, "unit": "rows/s", "cores": best_threads, "kind": "port",
+            "sample": f"{rows} rows x N={n}, mode {mode}: best call of oracle/torch_restatement.sot_loss over thread counts "
+                      f"{tried} on a {ncpu}-cpu host (torch {torch.__version__} CPU)", "scalar": float(val)}
 
 
 def main():
@@ -112,21 +118,19 @@ def main():
     def step(i, profile=None):
         x, y = sets[i % len(sets)]
         with torch.no_grad():
-            if world == 1:
-                if profile is not None:
-                    a, b = profile
-                    a.record()
-                rows = mod.row_losses(x, y, x_pos=pos_x, y_pos=pos_y)
-                if profile is not None:
-                    b.record()
-                return nat.reduce_mean(rows)
             if profile is not None:
                 a, b = profile
                 a.record()
-            rows = mod.row_losses(x, y, x_pos=pos_x, y_pos=pos_y)
+            if world == 1:
+                out = mod(x, y, x_pos=pos_x, y_pos=pos_y)  # one native call: forward kernel + batch-mean kernel
+                if profile is not None:
+                    b.record()
+                return out
+            # N > 1: local kernel (+ fused local fp64 sum) -> ONE all-reduce of (sum, rows) -> global mean
+            x2, y2, xp, yp, flags, plan, _ = mod._marshal(x, y, pos_x, pos_y, {})
+            _, _, local_sum = nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, want_sum=True)
             if profile is not None:
                 b.record()
-            _, local_sum = nat.reduce_mean(rows, want_sum=True)
             return global_mean_from_local_sum(local_sum, B)
 
     def barrier():

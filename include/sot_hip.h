@@ -113,14 +113,26 @@ int sot_w1d_reduce_mean(const float *row_loss, int64_t B, double denom, int appl
 /*
  * Backward of the forward above w.r.t. the weights (closed form of the autograd graph of
  * losses.py:172-313; positions receive no gradient, as in every reference call site).
- * grad_row[r] = dL/d(row_loss[r]).  grad_x and/or grad_y may be NULL (trainer.py only needs
+ * dL/d(row_loss[r]) = grad_scale * grad_row[r * grad_row_stride].  grad_x and/or grad_y may be NULL (trainer.py only needs
  * grad_y: x is the target spectrum).  Row strides of the gradients equal n and m.
  * Tie convention: gradients of a run of equal quantile levels go to the run's last member in
  * stable-sort order (U before V, lower index first).
  */
-int sot_w1d_backward(const sot_problem *prob, const float *grad_row /* [B] */,
+int sot_w1d_backward(const sot_problem *prob,
+                     const float *grad_row /* [B] if grad_row_stride == 1; ONE scalar if grad_row_stride == 0 */,
+                     int64_t grad_row_stride, float grad_scale /* multiplies grad_row, e.g. 1/B of the batch mean */,
                      float *grad_x /* [B,n] or NULL */, float *grad_y /* [B,m] or NULL */,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Forward + batch reduction in ONE call: enqueues sot_w1d_forward and sot_w1d_reduce_mean back to back on
+ * `stream`.  This is the whole of Wasserstein1D.forward with dims=None (losses.py:129-211) behind a single
+ * FFI crossing (the reduction is a separate 4-us kernel on purpose: reducing inside the forward kernel's last
+ * workgroup leaves the chip idle for longer than the kernel boundary costs).
+ */
+int sot_w1d_loss(const sot_problem *prob, float *row_loss /* [B] */, double denom, int apply_hinge,
+                 float hinge_threshold, float *mean_out, double *sum_out,
+                 void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * return_quantiles=True (losses.py:198-201, 299-300): the five tensors the reference returns,
