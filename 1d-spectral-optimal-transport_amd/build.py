@@ -17,8 +17,12 @@ LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 
 # -ffp-contract=off / -fno-fast-math: the kernels rely on IEEE fp32 division and unfused
 # multiply/add to stay bit-compatible with the reference's CPU arithmetic.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off", "-fno-fast-math", "-Wall"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# sot_hip.hip is compiled in parts (-DSOT_PART=<bit>) in parallel and linked into one shared library:
+# forward/shared positions, forward/per-row positions, backward/shared, backward/per-row, everything else.
+PARTS = (1, 2, 4, 8, 16)
+OBJ_DIR = os.path.join(PKG_DIR, "csrc", "obj")
 
 
 def hipcc_path() -> str:
@@ -35,17 +39,35 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not is_stale():
-        return LIB
-    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-o", LIB + ".tmp", SRC]
+def _compile_part(part: int, extra_flags, verbose: bool) -> str:
+    obj = os.path.join(OBJ_DIR, f"sot_part{part}.o")
+    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-DSOT_PART={part}", "-c", "-o", obj, SRC]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+        raise RuntimeError(f"hipcc failed on part {part}:\n" + res.stdout + res.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile every kernel instantiation for gfx950 and link libsot_hip.so (parts built in parallel)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = out or LIB
+    if not force and out is None and not is_stale():
+        return lib
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    workers = max(1, min(len(PARTS), (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose), PARTS))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":

@@ -18,6 +18,13 @@
 #include "../../include/sot_hip.h"
 #include "sot_device.hpp"
 
+// The file can be compiled whole (default) or in parts that are linked into one library, so that the many
+// kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
+// positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI).
+#ifndef SOT_PART
+#define SOT_PART 31
+#endif
+
 namespace sot {
 
 // ---------------------------------------------------------------------------------------------
@@ -71,7 +78,7 @@ __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpo
 // Diagnostic build only (-DSOT_STAMPS -> libsot_hip_stamps.so): workgroup 0 stamps the shader clock at the
 // phase boundaries of its second row into a buffer of its own; no output value depends on a stamp.
 #ifdef SOT_STAMPS
-__device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_stamps[64];
 #define SOT_STAMP(i) do { if (stamp_on) { __builtin_amdgcn_sched_barrier(0); g_stamps[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define SOT_STAMP(i) do { } while (0)
@@ -89,42 +96,6 @@ struct FwdArgs {
     // optional outputs of the quantile variant
     float* oUq; float* oVq; float* oQ; float* oU; float* oV;
 };
-
-// ---------------------------------------------------------------------------------------------
-// Shared-position preparation (losses.py:287-288 for row-invariant positions): one workgroup per
-// array checks sortedness and, if needed, sorts (position, index) pairs in LDS.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
-    const float* __restrict__ xpos, const float* __restrict__ ypos, int n, int m,
-    float* __restrict__ sx, float* __restrict__ sy, int* __restrict__ px, int* __restrict__ py,
-    int* __restrict__ ident)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int which = blockIdx.x;
-    const float* pos = which ? ypos : xpos;
-    const int len = which ? m : n;
-    float* spos = which ? sy : sx;
-    int* perm = which ? py : px;
-    const int npad = next_pow2(len);
-    float* key = smem;
-    int* idx = reinterpret_cast<int*>(smem + npad);
-    int* const unsorted_flag = reinterpret_cast<int*>(smem + 2 * npad);  // all LDS is dynamic (16-B aligned carve)
-    const int t = threadIdx.x, T = blockDim.x;
-    if (t == 0) *unsorted_flag = 0;
-    for (int i = t; i < npad; i += T) {
-        key[i] = (i < len) ? pos[i] : INFINITY;
-        idx[i] = (i < len) ? i : INT_MAX;
-    }
-    __syncthreads();
-    int bad = 0;
-    for (int i = t; i + 1 < len; i += T) bad |= (key[i] > key[i + 1]);
-    if (bad) *unsorted_flag = 1;
-    __syncthreads();
-    const bool need_sort = *unsorted_flag != 0;
-    if (need_sort) bitonic_sort_kv(key, idx, npad, t, T, [] { __syncthreads(); });
-    for (int i = t; i < len; i += T) { spos[i] = key[i]; perm[i] = idx[i]; }
-    if (t == 0) ident[which] = need_sort ? 0 : 1;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Per-row-group context shared by the forward and backward kernels
@@ -460,6 +431,12 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
     constexpr int RPW = BLOCK / G;   // rows processed concurrently by one workgroup
     constexpr int NW = G / kWave;    // wavefronts per row
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef SOT_STAMPS
+    const bool wg_stamp = (threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    unsigned long long* const wgs = g_stamps + (blockIdx.x == 0 ? 32 : 48);
+    int wg_row = 0;
+    if (wg_stamp) wgs[0] = __builtin_readcyclecounter();
+#endif
     const RowCtx<G> c = make_ctx<G, ROWPOS>(a, smem, false);
     const int rg = threadIdx.x / G;
     const int n = c.n, m = c.m, K = c.K, t = c.t;
@@ -473,6 +450,9 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
         load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
     }
+#ifdef SOT_STAMPS
+    if (wg_stamp) wgs[1] = __builtin_readcyclecounter();
+#endif
     for (; row0 < a.B; row0 += row_step) {
         const int64_t row = row0 + rg;
         const bool valid = row < a.B;
@@ -577,6 +557,9 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             }
         }
         SOT_STAMP(8);
+#ifdef SOT_STAMPS
+        if (wg_stamp && wg_row < 12) wgs[2 + wg_row++] = __builtin_readcyclecounter();
+#endif
     }
 }
 
@@ -794,6 +777,293 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// Allow a kernel to use up to the CU's full 160 KiB of dynamic LDS; leaves no sticky error behind.
+static inline void allow_full_lds(const void* kernel)
+{
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
+        (void)hipGetLastError();
+}
+
+static inline int device_cu_count()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+// Experiment knob (never set in production): SOT_DEBUG_EXTRA_LDS=<bytes> pads the dynamic LDS request of the
+// forward kernel to throttle its occupancy, which separates latency-bound from issue-bound behaviour.
+static inline size_t debug_extra_lds()
+{
+    const char* e = getenv("SOT_DEBUG_EXTRA_LDS");
+    return e ? (size_t)atol(e) : 0;
+}
+
+struct LaunchCfg { int G, CPT; };
+
+// Row-group geometries: (threads per row, contiguous elements per thread).  G*CPT >= max(n, m).
+// (128,12) serves the paper's row lengths just above 1024 (n_fft 2048 -> 1025 bins): two rows per workgroup.
+static inline bool pick_cfg(int n, int m, bool rowpos, bool with_grad, LaunchCfg* cfg, size_t* lds_bytes, int* block, int* rpw)
+{
+    const int N = n > m ? n : m;
+    static const LaunchCfg table[] = {{64, 8}, {128, 12}, {256, 8}, {1024, 8}, {1024, 16}};
+    for (int ci = 0; ci < 5; ++ci) {
+        const LaunchCfg& c = table[ci];
+        if ((int64_t)c.G * c.CPT < N) continue;
+        const int blk = c.G < 256 ? 256 : c.G;
+        const int r = blk / c.G;
+        const RowLayout L = make_layout(n, m, c.G, rowpos, with_grad);
+        const size_t bytes = (size_t)r * L.row_floats * sizeof(float);
+        if (bytes > kLdsLimit) continue;
+        *cfg = c; *lds_bytes = bytes; *block = blk; *rpw = r;
+        return true;
+    }
+    return false;
+}
+
+// Persistent grid: exactly as many workgroups as are co-resident (registers, LDS and wave slots all
+// taken into account by the occupancy query), never more than there are row groups.
+template <typename Kernel>
+static inline int resident_grid(Kernel kern, int block, size_t lds, int64_t want)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    const int64_t cap = (int64_t)device_cu_count() * per_cu;
+    return (int)(want < cap ? want : cap);
+}
+
+static inline int validate(const sot_problem* pr)
+{
+    if (pr == nullptr) return SOT_ERR_NULL_POINTER;
+    if (!(pr->p >= 1.0f)) return SOT_ERR_INVALID_P;
+    if (pr->B < 0 || pr->n < 1 || pr->m < 1) return SOT_ERR_BAD_SHAPE;
+    if (pr->x_row_stride < pr->n || pr->y_row_stride < pr->m) return SOT_ERR_BAD_SHAPE;
+    if (pr->xpos_row_stride != 0 && pr->xpos_row_stride < pr->n) return SOT_ERR_BAD_SHAPE;
+    if (pr->ypos_row_stride != 0 && pr->ypos_row_stride < pr->m) return SOT_ERR_BAD_SHAPE;
+    if ((pr->xpos_row_stride == 0) != (pr->ypos_row_stride == 0)) return SOT_ERR_BAD_SHAPE;
+    if (pr->B > 0 && (!pr->x || !pr->y || !pr->xpos || !pr->ypos)) return SOT_ERR_NULL_POINTER;
+    return SOT_OK;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout { size_t sx, sy, px, py, ident, total; };
+static inline WsLayout ws_layout(int n, int m)
+{
+    WsLayout w;
+    size_t o = 0;
+    w.sx = o; o = align_up(o + sizeof(float) * (size_t)n, 256);
+    w.sy = o; o = align_up(o + sizeof(float) * (size_t)m, 256);
+    w.px = o; o = align_up(o + sizeof(int) * (size_t)n, 256);
+    w.py = o; o = align_up(o + sizeof(int) * (size_t)m, 256);
+    w.ident = o; o = align_up(o + 2 * sizeof(int), 256);
+    w.total = o;
+    return w;
+}
+
+// ---- cross-part host interface (the parts are linked into one shared library) ---------------------------
+struct Launch {
+    FwdArgs a;
+    LaunchCfg cfg;
+    size_t lds;
+    int block;
+    int64_t want;  // row groups' worth of workgroups
+    bool rowpos, vec;
+    int pm;        // cost specialisation: 1 -> p == 1, 2 -> p == 2, 0 -> general
+    hipStream_t s;
+};
+
+template <bool ROWPOS>
+hipError_t dispatch_forward(const LaunchCfg& c, bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block,
+                            hipStream_t s);
+template <bool ROWPOS>
+hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block,
+                             hipStream_t s);
+int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
+                   hipStream_t s);
+int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
+int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V, bool quant,
+                void* workspace, size_t workspace_bytes, void* stream);
+int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx, float* gy,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+#if SOT_PART & 3
+template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
+static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT, PM, LIM, VEC>;
+    static const size_t extra_lds = debug_extra_lds();
+    lds += extra_lds;
+    static int grid_cap = 0;  // per instantiation; LDS size per (n, m) may differ, so cache per lds value
+    static size_t grid_lds = 0;
+    if (grid_cap == 0 || grid_lds != lds) {
+        allow_full_lds(reinterpret_cast<const void*>(kern));
+        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
+        grid_lds = lds;
+    }
+    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
+static hipError_t dispatch_forward_pm(int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    switch (pm) {
+        case 1: return launch_forward<G, CPT, ROWPOS, false, 1, LIM, VEC>(a, lds, want, block, s);
+        case 2: return launch_forward<G, CPT, ROWPOS, false, 2, LIM, VEC>(a, lds, want, block, s);
+        default: return launch_forward<G, CPT, ROWPOS, false, 0, LIM, VEC>(a, lds, want, block, s);
+    }
+}
+
+template <int G, int CPT, bool ROWPOS>
+static hipError_t dispatch_forward_g(bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    const bool lim = a.flags & SOT_FLAG_LIMIT_Q;
+    if (quant)  // rare path: one generic build per cutoff flavour
+        return lim ? launch_forward<G, CPT, ROWPOS, true, 0, true, false>(a, lds, want, block, s)
+                   : launch_forward<G, CPT, ROWPOS, true, 0, false, false>(a, lds, want, block, s);
+    if (ROWPOS || !vec)
+        return lim ? dispatch_forward_pm<G, CPT, ROWPOS, true, false>(pm, a, lds, want, block, s)
+                   : dispatch_forward_pm<G, CPT, ROWPOS, false, false>(pm, a, lds, want, block, s);
+    return lim ? dispatch_forward_pm<G, CPT, false, true, true>(pm, a, lds, want, block, s)
+               : dispatch_forward_pm<G, CPT, false, false, true>(pm, a, lds, want, block, s);
+}
+
+template <bool ROWPOS>
+hipError_t dispatch_forward(const LaunchCfg& c, bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block,
+                            hipStream_t s)
+{
+    if (c.CPT == 16) return dispatch_forward_g<1024, 16, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+    switch (c.G) {
+        case 64: return dispatch_forward_g<64, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+        case 128: return dispatch_forward_g<128, 12, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+        case 256: return dispatch_forward_g<256, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+        default: return dispatch_forward_g<1024, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
+    }
+}
+
+#if SOT_PART & 1
+template hipError_t dispatch_forward<false>(const LaunchCfg&, bool, int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t);
+#endif
+#if SOT_PART & 2
+template hipError_t dispatch_forward<true>(const LaunchCfg&, bool, int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t);
+#endif
+#endif  // forward parts
+
+#if SOT_PART & 12
+template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
+static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM, LIM, VEC>;
+    static int grid_cap = 0;
+    static size_t grid_lds = 0;
+    if (grid_cap == 0 || grid_lds != lds) {
+        allow_full_lds(reinterpret_cast<const void*>(kern));
+        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
+        grid_lds = lds;
+    }
+    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
+    return hipGetLastError();
+}
+
+template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
+static hipError_t dispatch_backward_pm(int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    switch (pm) {
+        case 1: return launch_backward<G, CPT, ROWPOS, 1, LIM, VEC>(b, lds, want, block, s);
+        case 2: return launch_backward<G, CPT, ROWPOS, 2, LIM, VEC>(b, lds, want, block, s);
+        default: return launch_backward<G, CPT, ROWPOS, 0, LIM, VEC>(b, lds, want, block, s);
+    }
+}
+
+template <int G, int CPT, bool ROWPOS>
+static hipError_t dispatch_backward_g(int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    const bool lim = b.f.flags & SOT_FLAG_LIMIT_Q;
+    if (ROWPOS || !vec)
+        return lim ? dispatch_backward_pm<G, CPT, ROWPOS, true, false>(pm, b, lds, want, block, s)
+                   : dispatch_backward_pm<G, CPT, ROWPOS, false, false>(pm, b, lds, want, block, s);
+    return lim ? dispatch_backward_pm<G, CPT, false, true, true>(pm, b, lds, want, block, s)
+               : dispatch_backward_pm<G, CPT, false, false, true>(pm, b, lds, want, block, s);
+}
+
+template <bool ROWPOS>
+hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block,
+                             hipStream_t s)
+{
+    if (c.CPT == 16) return dispatch_backward_g<1024, 16, ROWPOS>(pm, vec, b, lds, want, block, s);
+    switch (c.G) {
+        case 64: return dispatch_backward_g<64, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
+        case 128: return dispatch_backward_g<128, 12, ROWPOS>(pm, vec, b, lds, want, block, s);
+        case 256: return dispatch_backward_g<256, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
+        default: return dispatch_backward_g<1024, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
+    }
+}
+
+#if SOT_PART & 4
+template hipError_t dispatch_backward<false>(const LaunchCfg&, int, bool, const BwdArgs&, size_t, int64_t, int, hipStream_t);
+#endif
+#if SOT_PART & 8
+template hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, const BwdArgs&, size_t, int64_t, int, hipStream_t);
+#endif
+#endif  // backward parts
+
+#if SOT_PART & 16
+// ---------------------------------------------------------------------------------------------
+// Shared-position preparation (losses.py:287-288 for row-invariant positions): one workgroup per
+// array checks sortedness and, if needed, sorts (position, index) pairs in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
+    const float* __restrict__ xpos, const float* __restrict__ ypos, int n, int m,
+    float* __restrict__ sx, float* __restrict__ sy, int* __restrict__ px, int* __restrict__ py,
+    int* __restrict__ ident)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int which = blockIdx.x;
+    const float* pos = which ? ypos : xpos;
+    const int len = which ? m : n;
+    float* spos = which ? sy : sx;
+    int* perm = which ? py : px;
+    const int npad = next_pow2(len);
+    float* key = smem;
+    int* idx = reinterpret_cast<int*>(smem + npad);
+    int* const unsorted_flag = reinterpret_cast<int*>(smem + 2 * npad);  // all LDS is dynamic (16-B aligned carve)
+    const int t = threadIdx.x, T = blockDim.x;
+    if (t == 0) *unsorted_flag = 0;
+    for (int i = t; i < npad; i += T) {
+        key[i] = (i < len) ? pos[i] : INFINITY;
+        idx[i] = (i < len) ? i : INT_MAX;
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int i = t; i + 1 < len; i += T) bad |= (key[i] > key[i + 1]);
+    if (bad) *unsorted_flag = 1;
+    __syncthreads();
+    const bool need_sort = *unsorted_flag != 0;
+    if (need_sort) bitonic_sort_kv(key, idx, npad, t, T, [] { __syncthreads(); });
+    for (int i = t; i < len; i += T) { spos[i] = key[i]; perm[i] = idx[i]; }
+    if (t == 0) ident[which] = need_sort ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batch mean (losses.py:203-211): optional hinge, fixed-order fp64 accumulation, one workgroup.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sot_reduce_mean_kernel(const float* __restrict__ row_loss, int64_t B, double denom,
@@ -843,160 +1113,7 @@ __global__ __launch_bounds__(256) void sot_segmented_sort_kernel(const float* __
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Host side
-// ---------------------------------------------------------------------------------------------
-constexpr size_t kLdsLimit = 160 * 1024;
-
-// Allow a kernel to use up to the CU's full 160 KiB of dynamic LDS; leaves no sticky error behind.
-static void allow_full_lds(const void* kernel)
-{
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
-        (void)hipGetLastError();
-}
-
-static int device_cu_count()
-{
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        else
-            cus = 256;
-    }
-    return cus;
-}
-
-// Experiment knob (never set in production): SOT_DEBUG_EXTRA_LDS=<bytes> pads the dynamic LDS request of the
-// forward kernel to throttle its occupancy, which separates latency-bound from issue-bound behaviour.
-static size_t debug_extra_lds()
-{
-    const char* e = getenv("SOT_DEBUG_EXTRA_LDS");
-    return e ? (size_t)atol(e) : 0;
-}
-
-struct LaunchCfg { int G, CPT; };
-
-// Row-group geometries: (threads per row, contiguous elements per thread).  G*CPT >= max(n, m).
-static bool pick_cfg(int n, int m, bool rowpos, bool with_grad, LaunchCfg* cfg, size_t* lds_bytes, int* block, int* rpw)
-{
-    const int N = n > m ? n : m;
-    static const LaunchCfg table[] = {{64, 8}, {256, 8}, {1024, 8}, {1024, 16}};
-    for (int ci = 0; ci < 4; ++ci) {
-        const LaunchCfg& c = table[ci];
-        if ((int64_t)c.G * c.CPT < N) continue;
-        const int blk = c.G < 256 ? 256 : c.G;
-        const int r = blk / c.G;
-        const RowLayout L = make_layout(n, m, c.G, rowpos, with_grad);
-        const size_t bytes = (size_t)r * L.row_floats * sizeof(float);
-        if (bytes > kLdsLimit) continue;
-        *cfg = c; *lds_bytes = bytes; *block = blk; *rpw = r;
-        return true;
-    }
-    return false;
-}
-
-// Persistent grid: exactly as many workgroups as are co-resident (registers, LDS and wave slots all
-// taken into account by the occupancy query), never more than there are row groups.
-template <typename Kernel>
-static int resident_grid(Kernel kern, int block, size_t lds, int64_t want)
-{
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, lds) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 1;
-    }
-    const int64_t cap = (int64_t)device_cu_count() * per_cu;
-    return (int)(want < cap ? want : cap);
-}
-
-template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
-static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
-{
-    auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT, PM, LIM, VEC>;
-    static const size_t extra_lds = debug_extra_lds();
-    lds += extra_lds;
-    static int grid_cap = 0;  // per instantiation; LDS size per (n, m) may differ, so cache per lds value
-    static size_t grid_lds = 0;
-    if (grid_cap == 0 || grid_lds != lds) {
-        allow_full_lds(reinterpret_cast<const void*>(kern));
-        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
-        grid_lds = lds;
-    }
-    const int grid = (int)(want < grid_cap ? want : grid_cap);
-    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
-    return hipGetLastError();
-}
-
-template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
-static hipError_t dispatch_forward_pm(int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
-{
-    switch (pm) {
-        case 1: return launch_forward<G, CPT, ROWPOS, false, 1, LIM, VEC>(a, lds, want, block, s);
-        case 2: return launch_forward<G, CPT, ROWPOS, false, 2, LIM, VEC>(a, lds, want, block, s);
-        default: return launch_forward<G, CPT, ROWPOS, false, 0, LIM, VEC>(a, lds, want, block, s);
-    }
-}
-
-template <int G, int CPT, bool ROWPOS>
-static hipError_t dispatch_forward_g(bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
-{
-    const bool lim = a.flags & SOT_FLAG_LIMIT_Q;
-    if (quant)  // rare path: one generic build per cutoff flavour
-        return lim ? launch_forward<G, CPT, ROWPOS, true, 0, true, false>(a, lds, want, block, s)
-                   : launch_forward<G, CPT, ROWPOS, true, 0, false, false>(a, lds, want, block, s);
-    if (ROWPOS || !vec)
-        return lim ? dispatch_forward_pm<G, CPT, ROWPOS, true, false>(pm, a, lds, want, block, s)
-                   : dispatch_forward_pm<G, CPT, ROWPOS, false, false>(pm, a, lds, want, block, s);
-    return lim ? dispatch_forward_pm<G, CPT, false, true, true>(pm, a, lds, want, block, s)
-               : dispatch_forward_pm<G, CPT, false, false, true>(pm, a, lds, want, block, s);
-}
-
-template <bool ROWPOS>
-static hipError_t dispatch_forward(const LaunchCfg& c, bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want,
-                                   int block, hipStream_t s)
-{
-    if (c.CPT == 16) return dispatch_forward_g<1024, 16, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
-    switch (c.G) {
-        case 64: return dispatch_forward_g<64, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
-        case 256: return dispatch_forward_g<256, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
-        default: return dispatch_forward_g<1024, 8, ROWPOS>(quant, pm, vec, a, lds, want, block, s);
-    }
-}
-
-static int validate(const sot_problem* pr)
-{
-    if (pr == nullptr) return SOT_ERR_NULL_POINTER;
-    if (!(pr->p >= 1.0f)) return SOT_ERR_INVALID_P;
-    if (pr->B < 0 || pr->n < 1 || pr->m < 1) return SOT_ERR_BAD_SHAPE;
-    if (pr->x_row_stride < pr->n || pr->y_row_stride < pr->m) return SOT_ERR_BAD_SHAPE;
-    if (pr->xpos_row_stride != 0 && pr->xpos_row_stride < pr->n) return SOT_ERR_BAD_SHAPE;
-    if (pr->ypos_row_stride != 0 && pr->ypos_row_stride < pr->m) return SOT_ERR_BAD_SHAPE;
-    if ((pr->xpos_row_stride == 0) != (pr->ypos_row_stride == 0)) return SOT_ERR_BAD_SHAPE;
-    if (pr->B > 0 && (!pr->x || !pr->y || !pr->xpos || !pr->ypos)) return SOT_ERR_NULL_POINTER;
-    return SOT_OK;
-}
-
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-struct WsLayout { size_t sx, sy, px, py, ident, total; };
-static WsLayout ws_layout(int n, int m)
-{
-    WsLayout w;
-    size_t o = 0;
-    w.sx = o; o = align_up(o + sizeof(float) * (size_t)n, 256);
-    w.sy = o; o = align_up(o + sizeof(float) * (size_t)m, 256);
-    w.px = o; o = align_up(o + sizeof(int) * (size_t)n, 256);
-    w.py = o; o = align_up(o + sizeof(int) * (size_t)m, 256);
-    w.ident = o; o = align_up(o + 2 * sizeof(int), 256);
-    w.total = o;
-    return w;
-}
-
-static int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
+int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                           hipStream_t s)
 {
     const int npad = next_pow2(n > m ? n : m);
@@ -1012,19 +1129,8 @@ static int launch_prepare(const float* xpos, const float* ypos, int n, int m, fl
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
-struct Launch {
-    FwdArgs a;
-    LaunchCfg cfg;
-    size_t lds;
-    int block;
-    int64_t want;  // row groups' worth of workgroups
-    bool rowpos, vec;
-    int pm;        // cost specialisation: 1 -> p == 1, 2 -> p == 2, 0 -> general
-    hipStream_t s;
-};
-
 // validation, config choice, optional position preparation, persistent-grid sizing
-static int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out)
+int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out)
 {
     int rc = validate(pr);
     if (rc != SOT_OK) return rc;
@@ -1068,7 +1174,7 @@ static int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, 
     return SOT_OK;
 }
 
-static int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V,
+int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V,
                        bool quant, void* workspace, size_t workspace_bytes, void* stream)
 {
     Launch l;
@@ -1082,57 +1188,7 @@ static int run_forward(const sot_problem* pr, float* row_loss, float* uq, float*
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
-template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
-static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
-{
-    auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM, LIM, VEC>;
-    static int grid_cap = 0;
-    static size_t grid_lds = 0;
-    if (grid_cap == 0 || grid_lds != lds) {
-        allow_full_lds(reinterpret_cast<const void*>(kern));
-        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
-        grid_lds = lds;
-    }
-    const int grid = (int)(want < grid_cap ? want : grid_cap);
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
-    return hipGetLastError();
-}
-
-template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
-static hipError_t dispatch_backward_pm(int pm, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
-{
-    switch (pm) {
-        case 1: return launch_backward<G, CPT, ROWPOS, 1, LIM, VEC>(b, lds, want, block, s);
-        case 2: return launch_backward<G, CPT, ROWPOS, 2, LIM, VEC>(b, lds, want, block, s);
-        default: return launch_backward<G, CPT, ROWPOS, 0, LIM, VEC>(b, lds, want, block, s);
-    }
-}
-
-template <int G, int CPT, bool ROWPOS>
-static hipError_t dispatch_backward_g(int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
-{
-    const bool lim = b.f.flags & SOT_FLAG_LIMIT_Q;
-    if (ROWPOS || !vec)
-        return lim ? dispatch_backward_pm<G, CPT, ROWPOS, true, false>(pm, b, lds, want, block, s)
-                   : dispatch_backward_pm<G, CPT, ROWPOS, false, false>(pm, b, lds, want, block, s);
-    return lim ? dispatch_backward_pm<G, CPT, false, true, true>(pm, b, lds, want, block, s)
-               : dispatch_backward_pm<G, CPT, false, false, true>(pm, b, lds, want, block, s);
-}
-
-template <bool ROWPOS>
-static hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block,
-                                    hipStream_t s)
-{
-    if (c.CPT == 16) return dispatch_backward_g<1024, 16, ROWPOS>(pm, vec, b, lds, want, block, s);
-    switch (c.G) {
-        case 64: return dispatch_backward_g<64, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
-        case 256: return dispatch_backward_g<256, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
-        default: return dispatch_backward_g<1024, 8, ROWPOS>(pm, vec, b, lds, want, block, s);
-    }
-}
-
-static int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx,
+int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx,
                         float* gy, void* workspace, size_t workspace_bytes, void* stream)
 {
     Launch l;
@@ -1147,11 +1203,14 @@ static int run_backward(const sot_problem* pr, const float* grad_row, int64_t gr
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
+#endif  // misc part
+
 }  // namespace sot
 
 // =============================================================================================
 // C ABI (include/sot_hip.h)
 // =============================================================================================
+#if SOT_PART & 16
 extern "C" {
 
 int sot_abi_version(void) { return SOT_ABI_VERSION; }
@@ -1160,7 +1219,7 @@ int sot_abi_version(void) { return SOT_ABI_VERSION; }
 // diagnostic build only: copies the phase stamps of workgroup 0's second row to the host (synchronises)
 int sot_debug_read_stamps(unsigned long long* host_out, int count)
 {
-    if (count > 32) count = 32;
+    if (count > 64) count = 64;
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sot::g_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -1261,3 +1320,4 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
 }
 
 }  // extern "C"
+#endif  // SOT_PART & 16

@@ -19,6 +19,25 @@ if len(sys.argv) > 1:
     CASES = [tuple(int(v) if v.isdigit() else v for v in a.split(",")) for a in sys.argv[1:]]
 
 
+def timeit_graph(fn, iters):
+    """GPU-side time per call: `iters` calls captured into one HIP graph and replayed (no host launch cost)."""
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(iters):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
 def timeit(fn, iters):
     for i in range(5):
         fn(i)
@@ -32,7 +51,7 @@ def timeit(fn, iters):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-print(f"{'B':>6} {'N':>5} {'mode':>7} | {'fwd us':>8} {'Mrows/s':>8} {'GB/s':>7} {'%8TB/s':>6} | {'f+b(y) us':>9} {'Mrows/s':>8} {'GB/s':>7} {'%8TB/s':>6} | {'f+b(xy) us':>10}")
+print(f"{'B':>6} {'N':>5} {'mode':>7} | {'gpu us':>7} | {'fwd us':>8} {'Mrows/s':>8} {'GB/s':>7} {'%8TB/s':>6} | {'f+b(y) us':>9} {'Mrows/s':>8} {'GB/s':>7} {'%8TB/s':>6} | {'f+b(xy) us':>10}")
 for B, N, mode in CASES:
     nsets = max(2, min(8, int(600e6 / (B * N * 8)) + 1))
     g = torch.Generator(device=dev).manual_seed(1)
@@ -64,6 +83,7 @@ for B, N, mode in CASES:
         mod(x, y, x_pos=pos, y_pos=pos2).backward()
 
     tf = timeit(fwd, iters)
+    tg = timeit_graph(fwd, 20)
     try:
         tb = timeit(fb_y, iters)
         tbb = timeit(fb_xy, iters)
@@ -71,5 +91,5 @@ for B, N, mode in CASES:
         tb = tbb = float("nan")
     bf = (8 * N + 4) * B
     bb = (12 * N + 4) * B  # fwd reads x,y; bwd reads x,y again and writes grad_y: 4(n+m) + 4(n+m) + 4m ... report fwd+bwd(y) algorithmic = 4(n+m)+4m+4
-    print(f"{B:6d} {N:5d} {mode:>7} | {tf * 1e6:8.1f} {B / tf / 1e6:8.2f} {bf / tf / 1e9:7.0f} {100 * bf / tf / 8e12:6.1f} | "
+    print(f"{B:6d} {N:5d} {mode:>7} | {tg * 1e6:7.1f} | {tf * 1e6:8.1f} {B / tf / 1e6:8.2f} {bf / tf / 1e9:7.0f} {100 * bf / tf / 8e12:6.1f} | "
           f"{tb * 1e6:9.1f} {B / tb / 1e6:8.2f} {bb / tb / 1e9:7.0f} {100 * bb / tb / 8e12:6.1f} | {tbb * 1e6:10.1f}")
