@@ -48,6 +48,8 @@ EXPORTS = {
                                     _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_quantiles": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, _vp, _vp,
                                          ctypes.c_size_t, _vp]),
+    "sot_w1d_forward_csr": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_uint32, _vp, _vp]),
     "sot_segmented_sort": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
 }
 
@@ -279,6 +281,29 @@ def quantiles(x, y, xpos, ypos, p, flags, plan=None):
                                    V.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return uq, vq, Q, U, V
+
+
+def forward_rows_csr(xw, xp, xoff, yw, yp, yoff, max_n, max_m, p, flags):
+    """row_loss[B] for ragged supports in CSR form (sot_w1d_forward_csr); offsets are int64 [B+1] on the device."""
+    require_hip(xw, xp, yw, yp)
+    lib = load()
+    dev = xw.device
+    for t in (xoff, yoff):
+        if not t.is_cuda or t.dtype != torch.int64:
+            raise TypeError("CSR offsets must be int64 tensors on the GPU")
+    B = xoff.numel() - 1
+    if yoff.numel() - 1 != B:
+        raise RuntimeError("x and y offsets describe different numbers of rows")
+    if xw.numel() != xp.numel() or yw.numel() != yp.numel():
+        raise RuntimeError("weights and positions must have the same number of entries")
+    xw, xp, yw, yp, xoff, yoff = (t.contiguous() for t in (xw, xp, yw, yp, xoff, yoff))
+    row_loss = torch.empty(B, dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        rc = lib.sot_w1d_forward_csr(xw.data_ptr(), xp.data_ptr(), xoff.data_ptr(), xw.numel(), yw.data_ptr(), yp.data_ptr(),
+                                     yoff.data_ptr(), yw.numel(), B, int(max_n), int(max_m), float(p), int(flags),
+                                     row_loss.data_ptr(), stream_ptr(dev))
+    check(rc, p)
+    return row_loss
 
 
 def segmented_sort(keys: torch.Tensor):

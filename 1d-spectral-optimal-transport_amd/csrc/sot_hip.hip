@@ -20,9 +20,10 @@
 
 // The file can be compiled whole (default) or in parts that are linked into one library, so that the many
 // kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
-// positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI).
+// positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI),
+// bit 5 the CSR (ragged) forward.
 #ifndef SOT_PART
-#define SOT_PART 31
+#define SOT_PART 63
 #endif
 
 namespace sot {
@@ -95,6 +96,9 @@ struct FwdArgs {
     float* row_loss;
     // optional outputs of the quantile variant
     float* oUq; float* oVq; float* oQ; float* oU; float* oV;
+    // CSR (ragged) input form: row r owns entries [off[r], off[r+1]) of the concatenated weights/positions;
+    // n, m above are then the MAXIMUM row lengths (LDS is sized for them)
+    const int64_t* xoff; const int64_t* yoff;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -160,6 +164,19 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     return c;
 }
 
+// per-row support sizes (CSR form): everything derived from n, m is recomputed; the LDS layout stays that of
+// the maximum lengths.  E (and with it pad < E) can only shrink, so the front padding still fits.
+template <int G>
+__device__ __forceinline__ void set_row_lengths(RowCtx<G>& c, int n, int m)
+{
+    c.n = n; c.m = m;
+    c.mpx = make_mass_plan(n); c.mpy = make_mass_plan(m);
+    c.K = n + m;
+    c.E = merge_steps(c.K, G);
+    c.Ga = (c.K + c.E - 1) / c.E;
+    c.pad = c.Ga * c.E - c.K;
+}
+
 // ---- global -> register -> LDS staging of one row (VEC: 16 B per lane, rows 16-B aligned) ------------
 template <int G, int CPT, bool VEC>
 __device__ __forceinline__ void load_row(const float* __restrict__ src, int len, int t, float (&r)[CPT])
@@ -206,31 +223,35 @@ __device__ __forceinline__ void store_row(float* dst, int len, int t, const floa
 // On return ix/iy hold, for the CPT contiguous elements this thread owns in SORTED order, their
 // original column.  Ends with a barrier (U/V may be overwritten by the weights afterwards).
 template <int G, int CPT>
-__device__ __forceinline__ void rowpos_prepare(const FwdArgs& a, const RowCtx<G>& c, int64_t rowc, int (&ix)[CPT], int (&iy)[CPT])
+__device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* xp, const float* yp, int nmax, int mmax,
+                                               int (&ix)[CPT], int (&iy)[CPT])
 {
     const int n = c.n, m = c.m, t = c.t;
-    const float* xp = a.xpos + rowc * a.xps;
-    const float* yp = a.ypos + rowc * a.yps;
+    int* const IX = reinterpret_cast<int*>(c.U);  // index payloads alias U/V until the weights arrive
+    int* const IY = reinterpret_cast<int*>(c.V);
+    // barriers are workgroup-wide, so the sort network is sized by the maximum lengths (identical for every
+    // row group of the workgroup); rows whose positions are already sorted skip it altogether
+    const int npx = next_pow2(nmax), npy = next_pow2(mmax);
+    int unsorted = 0;
     if (c.do_sort) {
-        int* const IX = reinterpret_cast<int*>(c.U);  // index payloads alias U/V until the weights arrive
-        int* const IY = reinterpret_cast<int*>(c.V);
-        const int npx = next_pow2(n), npy = next_pow2(m);
         for (int e = t; e < npx; e += G) { c.PX[e] = (e < n) ? xp[e] : INFINITY; IX[e] = (e < n) ? e : INT_MAX; }
         for (int e = t; e < npy; e += G) { c.PY[e] = (e < m) ? yp[e] : INFINITY; IY[e] = (e < m) ? e : INT_MAX; }
-        __syncthreads();
-        bitonic_sort_kv(c.PX, IX, npx, t, G, [] { __syncthreads(); });
-        bitonic_sort_kv(c.PY, IY, npy, t, G, [] { __syncthreads(); });
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int e = t * CPT + k;
-            ix[k] = (e < n) ? IX[e] : 0;
-            iy[k] = (e < m) ? IY[e] : 0;
-        }
+        for (int e = t; e + 1 < n; e += G) unsorted |= (xp[e] > xp[e + 1]);
+        for (int e = t; e + 1 < m; e += G) unsorted |= (yp[e] > yp[e + 1]);
     } else {
         for (int e = t; e < n; e += G) c.PX[e] = xp[e];
         for (int e = t; e < m; e += G) c.PY[e] = yp[e];
+    }
+    const bool need_sort = __syncthreads_or(unsorted) != 0;  // also the barrier after the loads
+    if (need_sort) {
+        bitonic_sort_kv(c.PX, IX, npx, t, G, [] { __syncthreads(); });
+        bitonic_sort_kv(c.PY, IY, npy, t, G, [] { __syncthreads(); });
+    }
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { ix[k] = t * CPT + k; iy[k] = t * CPT + k; }
+    for (int k = 0; k < CPT; ++k) {
+        const int e = t * CPT + k;
+        ix[k] = (need_sort && e < n) ? IX[e] : e;
+        iy[k] = (need_sort && e < m) ? IY[e] : e;
     }
     __syncthreads();
     if (t == 0) { c.PX[n] = c.PX[n - 1]; c.PY[m] = c.PY[m - 1]; }
@@ -424,9 +445,10 @@ __device__ __forceinline__ int lower_rank(const float* A, int len, float q)
 // Row pipeline: the NEXT row's weights are fetched into registers while the current row is being
 // processed in LDS, so HBM latency overlaps the scan/merge work of the same workgroup.
 // ---------------------------------------------------------------------------------------------
-template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
+template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, bool CSR = false>
 __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const FwdArgs a)
 {
+    static_assert(!CSR || (ROWPOS && !VEC && !QUANT), "the CSR form has per-row positions and unaligned rows");
     constexpr int BLOCK = (G < 256 ? 256 : G);
     constexpr int RPW = BLOCK / G;   // rows processed concurrently by one workgroup
     constexpr int NW = G / kWave;    // wavefronts per row
@@ -437,18 +459,18 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
     int wg_row = 0;
     if (wg_stamp) wgs[0] = __builtin_readcyclecounter();
 #endif
-    const RowCtx<G> c = make_ctx<G, ROWPOS>(a, smem, false);
+    RowCtx<G> c = make_ctx<G, ROWPOS>(a, smem, false);
     const int rg = threadIdx.x / G;
-    const int n = c.n, m = c.m, K = c.K, t = c.t;
+    const int t = c.t;
     float* const U = c.U; float* const V = c.V; float* const PX = c.PX; float* const PY = c.PY;
 
     const int64_t row_step = (int64_t)gridDim.x * RPW;
     int64_t row0 = (int64_t)blockIdx.x * RPW;
     float rx[CPT], ry[CPT];
-    if (row0 < a.B) {
+    if (!CSR && row0 < a.B) {
         const int64_t r = min(row0 + rg, a.B - 1);
-        load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
-        load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
+        load_row<G, CPT, VEC>(a.x + r * a.xs, c.n, t, rx);
+        load_row<G, CPT, VEC>(a.y + r * a.ys, c.m, t, ry);
     }
 #ifdef SOT_STAMPS
     if (wg_stamp) wgs[1] = __builtin_readcyclecounter();
@@ -461,12 +483,27 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         const bool stamp_on = (blockIdx.x == 0) && (threadIdx.x == 0) && (row0 == row_step);
 #endif
         SOT_STAMP(0);
+        const float* xp = nullptr; const float* yp = nullptr;
+        bool bad_row = false;  // CSR: empty or over-long support -> NaN
+        if (CSR) {
+            const int64_t xo = a.xoff[rowc], xe = a.xoff[rowc + 1], yo = a.yoff[rowc], ye = a.yoff[rowc + 1];
+            const int64_t nr = xe - xo, mr = ye - yo;
+            bad_row = (nr < 1) || (mr < 1) || (nr > a.n) || (mr > a.m);
+            set_row_lengths(c, bad_row ? 1 : (int)nr, bad_row ? 1 : (int)mr);
+            const int64_t xb = bad_row ? 0 : xo, yb = bad_row ? 0 : yo;  // entry 0 exists (nnz >= 1 is checked on the host)
+            xp = a.xpos + xb; yp = a.ypos + yb;
+            load_row<G, CPT, false>(a.x + xb, c.n, t, rx);
+            load_row<G, CPT, false>(a.y + yb, c.m, t, ry);
+        } else if (ROWPOS) {
+            xp = a.xpos + rowc * a.xps; yp = a.ypos + rowc * a.yps;
+        }
+        const int n = c.n, m = c.m, K = c.K;
         int ix[CPT], iy[CPT];
-        if (ROWPOS) rowpos_prepare<G, CPT>(a, c, rowc, ix, iy);
+        if (ROWPOS) rowpos_prepare<G, CPT>(c, xp, yp, a.n, a.m, ix, iy);
         // ---- P1: registers -> LDS (original column order), then fetch the next row into the registers --
         store_row<G, CPT, VEC>(U, n, t, rx);
         store_row<G, CPT, VEC>(V, m, t, ry);
-        if (row0 + row_step < a.B) {
+        if (!CSR && row0 + row_step < a.B) {
             const int64_t r = min(row0 + row_step + rg, a.B - 1);
             load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
             load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
@@ -544,6 +581,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         }
         SOT_STAMP(7);
         acc = wave_sum(acc);
+        if (CSR && bad_row) acc = __int_as_float(0x7fc00000);
         if (NW == 1) {
             if (t == 0 && valid && a.row_loss) a.row_loss[row] = acc;
             __syncthreads();  // this row's LDS reads are done before the next row's staging
@@ -553,7 +591,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             if (t == 0 && valid && a.row_loss) {
                 float tot = c.red[0];
                 for (int w = 1; w < NW; ++w) tot += c.red[w];
-                a.row_loss[row] = tot;
+                a.row_loss[row] = tot;  // NaN propagates from any wave of a bad CSR row
             }
         }
         SOT_STAMP(8);
@@ -606,7 +644,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         const bool valid = row < a.B;
         const int64_t rowc = valid ? row : a.B - 1;
         int ix[CPT], iy[CPT];
-        if (ROWPOS) rowpos_prepare<G, CPT>(a, c, rowc, ix, iy);
+        if (ROWPOS) rowpos_prepare<G, CPT>(c, a.xpos + rowc * a.xps, a.ypos + rowc * a.yps, a.n, a.m, ix, iy);
         store_row<G, CPT, VEC>(U, n, t, rx);
         store_row<G, CPT, VEC>(V, m, t, ry);
         if (row0 + row_step < a.B) {
@@ -1205,6 +1243,70 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 
 #endif  // misc part
 
+#if SOT_PART & 32
+// ---- CSR (ragged) forward: BASELINE config 4's second input form ---------------------------------------------
+template <int G, int CPT, int PM, bool LIM>
+static hipError_t launch_forward_csr(const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    auto kern = sot_forward_kernel<G, CPT, true, false, PM, LIM, false, true>;
+    static int grid_cap = 0;
+    static size_t grid_lds = 0;
+    if (grid_cap == 0 || grid_lds != lds) {
+        allow_full_lds(reinterpret_cast<const void*>(kern));
+        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
+        grid_lds = lds;
+    }
+    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int G, int CPT>
+static hipError_t dispatch_forward_csr_g(int pm, bool lim, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    if (lim) {
+        switch (pm) {
+            case 1: return launch_forward_csr<G, CPT, 1, true>(a, lds, want, block, s);
+            case 2: return launch_forward_csr<G, CPT, 2, true>(a, lds, want, block, s);
+            default: return launch_forward_csr<G, CPT, 0, true>(a, lds, want, block, s);
+        }
+    }
+    switch (pm) {
+        case 1: return launch_forward_csr<G, CPT, 1, false>(a, lds, want, block, s);
+        case 2: return launch_forward_csr<G, CPT, 2, false>(a, lds, want, block, s);
+        default: return launch_forward_csr<G, CPT, 0, false>(a, lds, want, block, s);
+    }
+}
+
+int run_forward_csr(const float* xw, const float* xp, const int64_t* xoff, int64_t x_nnz, const float* yw, const float* yp,
+                    const int64_t* yoff, int64_t y_nnz, int64_t B, int max_n, int max_m, float p, uint32_t flags, float* row_loss,
+                    void* stream)
+{
+    if (!(p >= 1.0f)) return SOT_ERR_INVALID_P;
+    if (B < 0 || max_n < 1 || max_m < 1 || x_nnz < 1 || y_nnz < 1) return SOT_ERR_BAD_SHAPE;
+    if (B == 0) return SOT_OK;
+    if (!xw || !xp || !xoff || !yw || !yp || !yoff || !row_loss) return SOT_ERR_NULL_POINTER;
+    LaunchCfg cfg; size_t lds = 0; int block = 0, rpw = 1;
+    if (!pick_cfg(max_n, max_m, true, false, &cfg, &lds, &block, &rpw)) return SOT_ERR_UNSUPPORTED_SIZE;
+    FwdArgs a{};
+    a.x = xw; a.y = yw; a.xpos = xp; a.ypos = yp; a.xoff = xoff; a.yoff = yoff;
+    a.B = B; a.n = max_n; a.m = max_m;
+    a.p = p; a.flags = flags; a.row_loss = row_loss;
+    const int pm = (p == 1.0f) ? 1 : ((p == 2.0f) ? 2 : 0);
+    const bool lim = flags & SOT_FLAG_LIMIT_Q;
+    const int64_t want = (B + rpw - 1) / rpw;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (cfg.CPT == 16) e = dispatch_forward_csr_g<1024, 16>(pm, lim, a, lds, want, block, s);
+    else if (cfg.G == 64) e = dispatch_forward_csr_g<64, 8>(pm, lim, a, lds, want, block, s);
+    else if (cfg.G == 128) e = dispatch_forward_csr_g<128, 12>(pm, lim, a, lds, want, block, s);
+    else if (cfg.G == 256) e = dispatch_forward_csr_g<256, 8>(pm, lim, a, lds, want, block, s);
+    else e = dispatch_forward_csr_g<1024, 8>(pm, lim, a, lds, want, block, s);
+    return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+#endif  // CSR part
+
 }  // namespace sot
 
 // =============================================================================================
@@ -1321,3 +1423,13 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
 
 }  // extern "C"
 #endif  // SOT_PART & 16
+
+#if SOT_PART & 32
+extern "C" int sot_w1d_forward_csr(const float* x_weights, const float* x_positions, const int64_t* x_offsets, int64_t x_nnz,
+                                   const float* y_weights, const float* y_positions, const int64_t* y_offsets, int64_t y_nnz,
+                                   int64_t B, int32_t max_n, int32_t max_m, float p, uint32_t flags, float* row_loss, void* stream)
+{
+    return sot::run_forward_csr(x_weights, x_positions, x_offsets, x_nnz, y_weights, y_positions, y_offsets, y_nnz, B, max_n,
+                                max_m, p, flags, row_loss, stream);
+}
+#endif

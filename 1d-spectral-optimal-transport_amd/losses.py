@@ -15,7 +15,7 @@ import torch
 
 from . import _native as nat
 
-__all__ = ["Wasserstein1D", "wasserstein_1d", "quantile_function", "MixOfLosses", "safe_divide"]
+__all__ = ["Wasserstein1D", "wasserstein_1d", "wasserstein_1d_csr", "quantile_function", "MixOfLosses", "safe_divide"]
 
 FLAG_PRENORMALIZED = 16  # weights are used as given (the functional form wasserstein_1d)
 
@@ -170,6 +170,19 @@ def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, requ
     if return_quantiles:
         return nat.quantiles(x, y, upos, vpos, p, flags, plan)
     return _RowLoss.apply(x, y, upos, vpos, float(p), flags, plan)
+
+
+def wasserstein_1d_csr(x_weights, x_positions, x_offsets, y_weights, y_positions, y_offsets, max_n, max_m, p=1,
+                       square_dist=False, dont_normalize=False, limit_quantile_range=False, require_sort=True,
+                       prenormalized=False):
+    """Per-row SOT loss for RAGGED supports in CSR form (no reference counterpart: the reference is fed zero-masked
+    dense rows, which give the same value because zero-weight points are inert -- BASELINE config 4).
+    Row r owns entries [offsets[r], offsets[r+1]); normalisation etc. follow Wasserstein1D's keyword arguments.
+    Returns the [rows] tensor of W_p^p (forward only)."""
+    assert p >= 1, f"The OT loss is only valid for p>=1, {p} was given"
+    flags = _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized)
+    return nat.forward_rows_csr(x_weights, x_positions, x_offsets, y_weights, y_positions, y_offsets, max_n, max_m,
+                                float(p), flags)
 
 
 class Wasserstein1D(torch.nn.Module):

@@ -135,6 +135,19 @@ int sot_w1d_loss(const sot_problem *prob, float *row_loss /* [B] */, double deno
                  void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Forward for RAGGED supports in CSR form (BASELINE config 4: spectra after a per-row amplitude cutoff, where
+ * the reference would be fed zero-masked dense rows; zero-weight points are inert, so both forms agree).
+ * Row r owns entries [offsets[r], offsets[r+1]) of the concatenated weights/positions arrays; every row needs
+ * 1 <= length <= max_n (resp. max_m), otherwise its loss is NaN.  x_nnz / y_nnz are offsets[B].  Positions are
+ * per row; with SOT_FLAG_REQUIRE_SORT a row is sorted in LDS only if it is not already sorted.  The LDS footprint
+ * is that of (max_n, max_m).  Semantics per row are those of sot_w1d_forward.
+ */
+int sot_w1d_forward_csr(const float *x_weights, const float *x_positions, const int64_t *x_offsets /* [B+1] */, int64_t x_nnz,
+                        const float *y_weights, const float *y_positions, const int64_t *y_offsets /* [B+1] */, int64_t y_nnz,
+                        int64_t B, int32_t max_n, int32_t max_m, float p, uint32_t flags, float *row_loss /* [B] */,
+                        void *stream);
+
+/*
  * return_quantiles=True (losses.py:198-201, 299-300): the five tensors the reference returns,
  * uq/vq/Q: [B, n+m], U: [B, n], V: [B, m]; any output pointer may be NULL.
  */
