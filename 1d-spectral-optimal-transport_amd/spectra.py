@@ -1,0 +1,66 @@
+"""Producers of the hot path's inputs for BASELINE config 5 (the training-step slice): a harmonic batch
+generator and the magnitude STFT that `trainer.py:199-200` applies before the loss.
+
+This is host-side PLUMBING on torch ops (torch.stft -> rocFFT), not part of the hand-written HIP path: SURVEY
+§8(f) lists the STFT producer as the *next* row to fuse.  It mirrors, without copying, the behaviour of
+  * features.TorchSTFT / compute_mag / stft (features.py:85-113, 191-237): window from scipy.signal.get_window,
+    `normalized=True`, `center=False`, end-padding so that every sample is covered (utils.pad_for_stft,
+    utils.py:252-275), magnitude, output [batch, frames, bins];
+  * synthetic_data.SimpleSinusoidDataset's signal distribution (synthetic_data.py:331-345): f0 ~ U[40,1950] Hz,
+    up to 8 harmonic partials with amplitudes ~ U[0.4,1], 4096 samples @ 16 kHz, peak-normalised to 0.9.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def end_padded(signal: torch.Tensor, frame_size: int, hop: int) -> torch.Tensor:
+    """Pad so that the window slides until it is completely beyond the signal (tf.stft(pad_end=True) semantics)."""
+    length = signal.shape[1]
+    frames = -(-length // hop)
+    missing = max(0, frame_size + hop * (frames - 1) - length)
+    return signal if missing == 0 else torch.nn.functional.pad(signal, (0, missing))
+
+
+def analysis_window(name, n_fft: int, device) -> torch.Tensor:
+    if name is None:
+        return torch.hann_window(n_fft, device=device)
+    from scipy.signal import get_window
+    return torch.as_tensor(get_window(name, n_fft), dtype=torch.float32, device=device)
+
+
+def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop") -> torch.Tensor:
+    """[batch, samples] -> contiguous [batch, frames, n_fft/2+1] magnitudes, as the reference's TorchSTFT."""
+    audio = end_padded(audio.float(), n_fft, hop)
+    spec = torch.stft(audio, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=analysis_window(window, n_fft, audio.device),
+                      center=False, normalized=True, return_complex=True)
+    return spec.abs().permute(0, 2, 1).contiguous()
+
+
+def unit_frequencies(n_fft: int, sample_rate: float, device) -> torch.Tensor:
+    """rfftfreq / max: the support positions trainer.py:192-197 passes as x_pos (y_pos = clone)."""
+    f = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate)
+    return (f / f.max()).float().to(device)
+
+
+def harmonic_batch(batch: int, n_samples: int = 4096, sample_rate: float = 16000.0, generator=None, device="cuda"):
+    """Random harmonic clips on `device`: f0 ~ U[40,1950] Hz, n_active ~ U{1..8} partials, amplitudes ~ U[0.4,1]."""
+    dev = torch.device(device)
+    f0 = 40 + (1950 - 40) * torch.rand(batch, 1, 1, generator=generator, device=dev)
+    amps = 0.4 + 0.6 * torch.rand(batch, 8, 1, generator=generator, device=dev)
+    n_active = torch.randint(1, 9, (batch, 1, 1), generator=generator, device=dev)
+    k = torch.arange(1, 9, device=dev).view(1, 8, 1)
+    t = torch.arange(n_samples, device=dev).view(1, 1, -1) / sample_rate
+    keep = ((k <= n_active) & (f0 * k < sample_rate / 2)).float()
+    sig = (amps * keep * torch.sin(2 * torch.pi * f0 * k * t)).sum(1)
+    return 0.9 * sig / sig.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
+
+
+def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate: torch.Tensor, n_fft: int = 2048, hop: int = 256,
+                        sample_rate: float = 16000.0, window="flattop"):
+    """One step of the slice trainer.py:192-221 runs around the loss: spectra of target and estimate, unit-scaled
+    frequency positions, SOT loss (forward).  The caller backpropagates into `audio_estimate`."""
+    spec_x = stft_magnitude(audio_target, n_fft, hop, window)
+    spec_y = stft_magnitude(audio_estimate, n_fft, hop, window)
+    pos = unit_frequencies(n_fft, sample_rate, spec_x.device)
+    return loss_module(spec_x, spec_y, x_pos=pos, y_pos=pos.clone())

@@ -60,3 +60,21 @@ def sha256_of(*tensors) -> str:
     for t in tensors:
         h.update(np.ascontiguousarray(t.numpy()).tobytes())
     return h.hexdigest()
+
+
+def harmonic_audio_pair(nb=2, seed=11, n_samples=4096, sr=16000.0):
+    """Two batches of additive harmonic clips (f0 ~ U[40,1950] Hz, 8 partials, amps ~ U[0.4,1], partials above
+    Nyquist muted, peak 0.9): the signal distribution of the reference's synthetic_data.py:331-345.  This exact
+    code produced the audio behind tests/golden/inputs_harmonic_stft.npz (oracle/make_golden.py, section 8)."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n_samples) / sr
+    k = torch.arange(1, 9).view(1, 8, 1)
+
+    def additive():
+        f0 = 40 + (1950 - 40) * torch.rand(nb, 1, 1, generator=g)
+        amps = 0.4 + 0.6 * torch.rand(nb, 8, 1, generator=g)
+        audible = (f0 * k < sr / 2).float()
+        sig = (amps * audible * torch.sin(2 * torch.pi * f0 * k * t.view(1, 1, -1))).sum(1)
+        return 0.9 * sig / sig.abs().amax(dim=1, keepdim=True)
+
+    return additive(), additive()

@@ -211,20 +211,11 @@ def main():
     # 8. harmonic spectra: own additive generator (f0 ~ U[40,1950] Hz, 8 partials, amps ~ U[0.4,1],
     #    4096 samples @ 16 kHz, peak 0.9: the distribution of synthetic_data.py:331-345) fed through the
     #    REFERENCE's TorchSTFT (features.py:85-113: n_fft 2048, hop 256, flattop, normalized, end-padded)
-    g = torch.Generator().manual_seed(11)
-    nb = 2
-    t = torch.arange(4096) / 16000.0
-    k = torch.arange(1, 9).view(1, 8, 1)
-
-    def additive():
-        f0 = 40 + (1950 - 40) * torch.rand(nb, 1, 1, generator=g)
-        amps = 0.4 + 0.6 * torch.rand(nb, 8, 1, generator=g)
-        audible = (f0 * k < 8000).float()
-        sig = (amps * audible * torch.sin(2 * torch.pi * f0 * k * t.view(1, 1, -1))).sum(1)
-        return 0.9 * sig / sig.abs().amax(dim=1, keepdim=True)
+    from oracle.inputs import harmonic_audio_pair
+    audio_x, audio_y = harmonic_audio_pair(nb=2, seed=11)
 
     tfm = features.get_transform({"type": "stft", "n_fft": 2048, "hop_length": 256, "window": "flattop"}, 16000)
-    sx, sy = tfm(additive()).contiguous(), tfm(additive()).contiguous()
+    sx, sy = tfm(audio_x).contiguous(), tfm(audio_y).contiguous()
     pos = tfm.get_frequencies()
     pos = (pos / pos.max()).float()
     print("harmonic STFT spectra", tuple(sx.shape), sx.dtype)

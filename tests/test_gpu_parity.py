@@ -445,3 +445,38 @@ def test_csr_unsorted_rows_and_invalid_rows():
     for r in (0, 1, 2, 3):
         want = so.forward(xw[r][None].numpy(), yw[r][None].numpy(), xp[r].numpy(), yp[r].numpy(), p=1.0, flags=so.make_flags())
         np.testing.assert_allclose(got[r], want[0], rtol=RTOL)
+
+
+def test_training_step_slice_config5(manifest):
+    """BASELINE config 5: harmonic clips -> flattop STFT magnitudes (n_fft 2048, hop 256, 16 frames) -> SOT paper-cutoff
+    forward + backward.  The producer (torch.stft on the GPU) must reproduce the spectra the REFERENCE's TorchSTFT
+    produced for the same audio (fixture), and loss / gradient w.r.t. the estimate's spectrum must match the oracle."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import harmonic_audio_pair
+    from oracle.make_golden import MODES
+    from sot_amd import spectra
+    native()
+    dev = device()
+    fx = dict(np.load(os.path.join(GOLDEN, "inputs_harmonic_stft.npz")))
+    ax, ay = harmonic_audio_pair(nb=2, seed=11)
+    sx = spectra.stft_magnitude(ax.to(dev))
+    sy = spectra.stft_magnitude(ay.to(dev))
+    assert tuple(sx.shape) == fx["x"].shape == (2, 16, 1025) and sx.is_contiguous()
+    for got, want in ((sx, fx["x"]), (sy, fx["y"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+    pos = spectra.unit_frequencies(2048, 16000.0, dev)
+    np.testing.assert_allclose(pos.cpu().numpy(), fx["x_pos"], rtol=0, atol=0)
+    # end to end: gradient reaches the estimate's AUDIO through torch.stft's autograd and our backward kernel
+    ay_d = ay.to(dev).requires_grad_(True)
+    mod = module_for(MODES["cutoff"])
+    loss = spectra.training_step_slice(mod, ax.to(dev), ay_d)
+    loss.backward()
+    assert torch.isfinite(ay_d.grad).all() and float(ay_d.grad.abs().max()) > 0
+    # loss on the fixture spectra == the reference's scalar for those spectra
+    ref = manifest["harmonic_stft_cutoff"]["scalar"]
+    got = float(mod(to_dev(fx["x"]), to_dev(fx["y"]), x_pos=pos, y_pos=pos.clone()))
+    assert abs(got - ref) <= RTOL * abs(ref)
+    # and the generator produces well-formed clips
+    g = torch.Generator(device=dev).manual_seed(3)
+    clips = spectra.harmonic_batch(16, generator=g, device=dev)
+    assert clips.shape == (16, 4096) and abs(float(clips.abs().amax(1).mean()) - 0.9) < 1e-5
