@@ -227,12 +227,14 @@ def loss_fused(x, y, xpos, ypos, p, flags, plan=None, denom=None, hinge=None, wa
     return mean, row_loss, total
 
 
-def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False):
+def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False, sum_out=None):
+    """Fixed-order fp64 batch reduction.  sum_out: optional preallocated fp64 tensor (1 element) for the partial sum."""
     lib = load()
     dev = row_loss.device
     B = row_loss.numel()
     mean = torch.empty((), dtype=torch.float32, device=dev)
-    total = torch.empty((), dtype=torch.float64, device=dev) if want_sum else None
+    total = sum_out if sum_out is not None else (torch.empty((), dtype=torch.float64, device=dev) if want_sum else None)
+    want_sum = want_sum or sum_out is not None
     with _on_device(dev):
         check(lib.sot_w1d_reduce_mean(row_loss.data_ptr(), B, float(B if denom is None else denom),
                                       0 if hinge is None else 1, 0.0 if hinge is None else float(hinge),

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--mode", choices=list(MODES), default="p1")
     ap.add_argument("--sets", type=int, default=6, help="distinct rotating input sets (>= 4 defeats the 256 MiB L3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-steps", action="store_true", help="replay each step from a HIP graph (opt-in)")
     ap.add_argument("--cpu-rows", type=int, default=2048)
     return ap.parse_args()
 
@@ -88,17 +89,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # SOT_BENCH_FORCE_DIST=1 exercises the RCCL branch even with one rank (used to test it on a 1-GPU box)
+    dist_on = world > 1 or (os.environ.get("SOT_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist_on else 0)
     torch.cuda.set_device(dev)
 
     from sot_amd import _native as nat
-    from sot_amd.distributed import global_mean_from_local_sum
     from sot_amd.losses import Wasserstein1D
     from oracle.inputs import gen_inputs
 
@@ -121,45 +123,77 @@ def main():
             if profile is not None:
                 a, b = profile
                 a.record()
-            if world == 1:
-                out = mod(x, y, x_pos=pos_x, y_pos=pos_y)  # one native call: forward kernel + batch-mean kernel
+            if not dist_on:
+                # same two kernels as Wasserstein1D.forward (sot_w1d_loss), issued as two calls so that the HIP
+                # events bracket the dominant kernel (sot_forward_kernel) alone
+                x2, y2, xp, yp, flags, plan, _ = mod._marshal(x, y, pos_x, pos_y, {})
+                rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan)
                 if profile is not None:
                     b.record()
-                return out
-            # N > 1: local kernel (+ fused local fp64 sum) -> ONE all-reduce of (sum, rows) -> global mean
+                return nat.reduce_mean(rows)
+            # N > 1: local kernels -> ONE all-reduce(SUM) of the fp64 partial sum over RCCL -> global mean.
+            # (Eager + synchronous on the stream by default; --graph-steps replays the whole step, collective
+            # included, from a HIP graph: measured 74 vs 83 us/step with one rank, but graph-captured RCCL could only
+            # be validated single-rank on the 1-GPU development box, so it stays opt-in.)
+            import torch.distributed as dist
             x2, y2, xp, yp, flags, plan, _ = mod._marshal(x, y, pos_x, pos_y, {})
-            _, _, local_sum = nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, want_sum=True)
+            rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan)
             if profile is not None:
                 b.record()
-            return global_mean_from_local_sum(local_sum, B)
+            buf = ring[i % len(ring)]           # preallocated fp64 [1]: the reduce kernel writes the local sum into it
+            nat.reduce_mean(rows, sum_out=buf)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            return buf * inv_global_rows
+
+    ring = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(4)]
+    inv_global_rows = 1.0 / float(world * B)   # weak scaling: every rank owns exactly B rows
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
 
     for i in range(args.warmup):
         out = step(i)
-    first = float(step(0))  # parity value on set 0
+    first = float(step(0))  # parity value on set 0 (global mean when N > 1)
     torch.cuda.synchronize()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    graphs = None
+    if args.graph_steps:  # one captured step per rotating input set, replayed in the same order
+        graphs = []
+        for k in range(len(sets)):
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph):
+                out = step(k)
+            graphs.append(gph)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(i, events[i])
+        if graphs is not None:
+            graphs[i % len(graphs)].replay()
+        else:
+            out = step(i, events[i])
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     del out
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps
+    if graphs is not None:  # events cannot sit inside a replay: time the dominant kernel eagerly after the timed region
+        for i in range(min(args.steps, 50)):
+            step(i, events[i])
+        torch.cuda.synchronize()
+        events = events[:min(args.steps, 50)]
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     bytes_per_row = 4 * (N + N) + 4  # fwd, shared positions
     achieved = bytes_per_row * B / (kern_ms * 1e-3) / 1e9
 
@@ -187,7 +221,7 @@ def main():
                                    f"({json.dumps(MODES[args.mode])}), shared linspace positions, {len(sets)} rotating input sets "
                                    f"({len(sets) * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",
                        "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "global_rows": world * B,
-                       "collective": "none" if world == 1 else "one RCCL all-reduce of a 2-element fp64 tensor (sum, rows) per step",
+                       "collective": "none" if not dist_on else "one RCCL all-reduce(SUM) of the fp64 partial sum per step" + (" (HIP-graph replay)" if args.graph_steps else ""),
                        "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "sot_forward_kernel",
@@ -197,7 +231,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(args.mode, N, min(args.cpu_rows, B), 1234)
         print(json.dumps(rec), flush=True)
     barrier()
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 
