@@ -210,9 +210,25 @@ __device__ __forceinline__ double wave_suffix_incl_scan(double v)
 // Merge-path partition: number of U elements among the first D merged elements, with U before V
 // on ties (the order of a stable sort of cat(U, V)).
 // ---------------------------------------------------------------------------------------------
+#ifndef SOT_MERGE_PATH_KARY
+#define SOT_MERGE_PATH_KARY 0
+#endif
 __device__ __forceinline__ int merge_path(const float* U, const float* V, int n, int m, int D)
 {
+    // P(i) := U[i] <= V[D-1-i] is true for i < i0 and false from i0 on; find i0 in [lo, hi].
+    // 4-ary rounds (three pivots, six independent LDS reads per round) halve the number of dependent LDS round
+    // trips of a binary search (6 instead of 12 for 2048 + 2048): the row's critical path is latency-bound.
     int lo = max(0, D - m), hi = min(D, n);
+    while (SOT_MERGE_PATH_KARY && hi - lo >= 4) {
+        const int q = (hi - lo) >> 2;
+        const int m1 = lo + q, m2 = m1 + q, m3 = m2 + q;
+        const bool p1 = U[m1] <= V[D - 1 - m1];
+        const bool p2 = U[m2] <= V[D - 1 - m2];
+        const bool p3 = U[m3] <= V[D - 1 - m3];
+        // monotone predicate: p1 >= p2 >= p3
+        lo = p3 ? (m3 + 1) : (p2 ? (m2 + 1) : (p1 ? (m1 + 1) : lo));
+        hi = p3 ? hi : (p2 ? m3 : (p1 ? m2 : m1));
+    }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (U[mid] <= V[D - 1 - mid]) lo = mid + 1; else hi = mid;

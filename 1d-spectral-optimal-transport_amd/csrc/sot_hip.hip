@@ -289,7 +289,8 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         __syncthreads();
         SOT_STAMP(2);
         // columns + fold by ONE wave per array (wave 0: x, wave 1: y; a single-wave row group does both
-        // in its two half-waves): the 32 column totals are exchanged through this wave's own LDS slots
+        // in its two half-waves): the 32 column totals are exchanged through this wave's own LDS slots.
+        // (Doing this redundantly in every wave to save the barrier below was measured 10 % SLOWER.)
         float* const Sv = c.red + NW;
         if (NW >= 2) {
             if (c.wv < 2 && !(c.wv == 1 && c.dn)) {
@@ -376,7 +377,12 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             qx[k] = div_by_row_constant(sq ? wx[k] * wx[k] : wx[k], Sxh, rx, risk);
             qy[k] = div_by_row_constant(sq ? wy[k] * wy[k] : wy[k], Syh, ry, risk);
         }
-        if (risk < kFastDivMinBits || !(Sxh <= 0x1p40f) || !(Syh <= 0x1p40f)) {
+        // Rare fallback, taken by the whole wave if any lane needs it.  The ballot makes the branch wave-uniform and
+        // the asm statement keeps hipcc from if-converting it (it would otherwise execute the 16 IEEE divisions
+        // unconditionally and select afterwards: +176 VALU per thread per row, seen in the ISA).
+        const bool slow = (risk < kFastDivMinBits) || !(Sxh <= 0x1p40f) || !(Syh <= 0x1p40f);
+        if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {
+            asm volatile("; IEEE division fallback" ::: "memory");
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 qx[k] = (sq ? wx[k] * wx[k] : wx[k]) / Sxh;  // IEEE division (built without fast-math)
