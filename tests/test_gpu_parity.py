@@ -480,3 +480,24 @@ def test_training_step_slice_config5(manifest):
     g = torch.Generator(device=dev).manual_seed(3)
     clips = spectra.harmonic_batch(16, generator=g, device=dev)
     assert clips.shape == (16, 4096) and abs(float(clips.abs().amax(1).mean()) - 0.9) < 1e-5
+
+
+def test_sharded_loss_single_rank_equals_module():
+    """sot_amd.distributed.sharded_sot_loss with one rank (no process group): value and gradient equal the module's;
+    the N>1 reduction logic itself is covered by the gloo world-size-2 CPU test and by bench.py's RCCL path."""
+    from oracle.inputs import gen_inputs
+    from sot_amd.distributed import sharded_sot_loss
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    x, y = gen_inputs("peaky", 300, 257, 257, 77)
+    pos = torch.linspace(0, 1, 257, device=dev)
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+    y1 = y.to(dev).requires_grad_(True)
+    y2 = y.to(dev).requires_grad_(True)
+    a = mod(x.to(dev), y1, x_pos=pos, y_pos=pos)
+    b = sharded_sot_loss(mod, x.to(dev), y2, x_pos=pos, y_pos=pos)
+    a.backward()
+    b.backward()
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+    torch.testing.assert_close(y1.grad, y2.grad, rtol=1e-5, atol=1e-12)
