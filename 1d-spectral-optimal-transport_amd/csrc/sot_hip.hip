@@ -25,6 +25,11 @@
 #ifndef SOT_PART
 #define SOT_PART 63
 #endif
+// Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
+// search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
+#ifndef SOT_ABLATE
+#define SOT_ABLATE 0
+#endif
 
 namespace sot {
 
@@ -278,7 +283,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     // ---- P2: row masses in ATen order (losses.py:177,184; the reference sums BEFORE it sorts, so the
     //      staged row is still in its original column order here) -----------------------------------
     float Sx = 1.0f, Sy = 1.0f;  // prenormalised: w / 1.0f == w exactly, weights enter the CDF unchanged
-    if (!c.prenorm) {
+    if (!(SOT_ABLATE & 4) && !c.prenorm) {
         if (sq) {
             mass_chunk_sums<G, true>(U, c.partx, c.mpx, t);
             if (!c.dn) mass_chunk_sums<G, true>(V, c.party, c.mpy, (t + G / 2) & (G - 1));
@@ -374,6 +379,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         uint32_t risk = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
+            if (SOT_ABLATE & 8) { qx[k] = wx[k] * rx; qy[k] = wy[k] * ry; continue; }
             qx[k] = div_by_row_constant(sq ? wx[k] * wx[k] : wx[k], Sxh, rx, risk);
             qy[k] = div_by_row_constant(sq ? wy[k] * wy[k] : wy[k], Syh, ry, risk);
         }
@@ -398,8 +404,8 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             py[k] = runy;
         }
     }
-    const double inx = wave_incl_scan(runx), iny = wave_incl_scan(runy);
-    double exx = wave_shift_right1(inx), exy = wave_shift_right1(iny);
+    const double inx = (SOT_ABLATE & 16) ? runx : wave_incl_scan(runx), iny = (SOT_ABLATE & 16) ? runy : wave_incl_scan(runy);
+    double exx = (SOT_ABLATE & 16) ? 0.0 : wave_shift_right1(inx), exy = (SOT_ABLATE & 16) ? 0.0 : wave_shift_right1(iny);
     if (NW > 1 && c.lane == kWave - 1) { c.wtot[c.wv] = inx; c.wtot[NW + c.wv] = iny; }
     SOT_STAMP(4);
     __syncthreads();  // every raw weight has been read (also through permutations) before U/V are rewritten
@@ -534,7 +540,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             const float* const PXw = PX - c.pad;
             const int nw = n + c.pad;
             const int D0 = t * c.E;
-            const int i0 = merge_path(Uw, V, nw, m, D0);
+            const int i0 = (SOT_ABLATE & 2) ? min(D0 >> 1, nw) : merge_path(Uw, V, nw, m, D0);
             SOT_STAMP(6);
             const int j0 = D0 - i0;
             float qprev = 0.0f;  // Q_0 := 0 (the pad of losses.py:301)
@@ -546,7 +552,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             const uint32_t poff4 = 4u * (uint32_t)c.L.poff;
             const int voff = (int)(V - Uw);
             uint32_t iu = (uint32_t)i0;
-            for (int s = 0; s < c.E; ++s) {
+            for (int s = 0; s < ((SOT_ABLATE & 1) ? 1 : c.E); ++s) {
                 const bool tu = ua <= vb;
                 const float q = tu ? ua : vb;
                 const float cost = transport_cost<PM>(xa, yb, c.p);
@@ -944,6 +950,29 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
                 void* workspace, size_t workspace_bytes, void* stream);
 int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx, float* gy,
                  void* workspace, size_t workspace_bytes, void* stream);
+int run_forward_csr(const float* xw, const float* xp, const int64_t* xoff, int64_t x_nnz, const float* yw, const float* yp,
+                    const int64_t* yoff, int64_t y_nnz, int64_t B, int max_n, int max_m, float p, uint32_t flags, float* row_loss,
+                    void* stream);
+
+#ifdef SOT_STUB_MISSING_PARTS
+// diagnostic single-file builds (stamps / ablation) compile a subset of the parts: resolve the rest with stubs
+#if !(SOT_PART & 1)
+template <> hipError_t dispatch_forward<false>(const LaunchCfg&, bool, int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+#endif
+#if !(SOT_PART & 2)
+template <> hipError_t dispatch_forward<true>(const LaunchCfg&, bool, int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+#endif
+#if !(SOT_PART & 4)
+template <> hipError_t dispatch_backward<false>(const LaunchCfg&, int, bool, const BwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+#endif
+#if !(SOT_PART & 8)
+template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, const BwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+#endif
+#if !(SOT_PART & 32)
+int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const float*, const float*, const int64_t*, int64_t, int64_t, int,
+                    int, float, uint32_t, float*, void*) { return SOT_ERR_LAUNCH; }
+#endif
+#endif  // SOT_STUB_MISSING_PARTS
 
 #if SOT_PART & 3
 template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
@@ -1249,6 +1278,7 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 
 #endif  // misc part
 
+
 #if SOT_PART & 32
 // ---- CSR (ragged) forward: BASELINE config 4's second input form ---------------------------------------------
 template <int G, int CPT, int PM, bool LIM>
@@ -1430,7 +1460,7 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
 }  // extern "C"
 #endif  // SOT_PART & 16
 
-#if SOT_PART & 32
+#if (SOT_PART & 32) || defined(SOT_STUB_MISSING_PARTS)
 extern "C" int sot_w1d_forward_csr(const float* x_weights, const float* x_positions, const int64_t* x_offsets, int64_t x_nnz,
                                    const float* y_weights, const float* y_positions, const int64_t* y_offsets, int64_t y_nnz,
                                    int64_t B, int32_t max_n, int32_t max_m, float p, uint32_t flags, float* row_loss, void* stream)

@@ -16,7 +16,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "p1"
 B, N = 8192, int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 lib = os.path.join(ROOT, "gpurun_out", "libsot_hip_stamps.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.run([sot_amd.build.hipcc_path(), *sot_amd.build.HIPCC_FLAGS, "-shared", "-DSOT_STAMPS", "-DSOT_PART=17", "-o", lib,
+subprocess.run([sot_amd.build.hipcc_path(), *sot_amd.build.HIPCC_FLAGS, "-shared", "-DSOT_STAMPS", "-DSOT_PART=17", "-DSOT_STUB_MISSING_PARTS", "-o", lib,
                 sot_amd.build.SRC], check=True)  # whole-file diagnostic build: shared-position forward + misc only
 sot_amd.build.LIB = lib
 nat._lib = None
