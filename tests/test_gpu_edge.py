@@ -1,0 +1,100 @@
+"""-m gpu: edge cases of the boundary (sizes, module plumbing, error behaviour) through the public Python API."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import device, native
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_rows(x, y, pos, **kw):
+    from oracle import sot_oracle as so
+    flags = so.make_flags(kw.get("square_dist", False), kw.get("dont_normalize", False), kw.get("limit_quantile_range", False), True)
+    return so.forward(x.cpu().numpy(), y.cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=float(kw.get("p", 1)), flags=flags)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 255, 257, 1023, 1025, 4097])
+@pytest.mark.parametrize("N", [1, 3, 8, 31, 33, 64, 65, 513, 1537, 2049])
+def test_row_and_length_boundaries(B, N):
+    """row counts around the workgroup/row-group multiples and lengths around every geometry switch (64x8, 128x12, 256x8, 1024x8)"""
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    if B * N > 3_000_000:
+        pytest.skip("kept small: the oracle is single-threaded")
+    g = torch.Generator().manual_seed(B * 7919 + N)
+    x, y = torch.rand(B, N, generator=g) ** 3, torch.rand(B, N, generator=g) ** 3
+    pos = torch.linspace(0, 1, N)
+    kw = dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    mod = Wasserstein1D(**kw).to(dev)
+    rows = mod(x.to(dev)[:, None, :], y.to(dev)[:, None, :], x_pos=pos.to(dev), y_pos=pos.to(dev), dims=[1]).cpu().numpy()
+    want = _oracle_rows(x, y, pos, **kw)
+    np.testing.assert_allclose(rows, want, rtol=1e-5, atol=1e-12)
+
+
+def test_many_short_rows():
+    """1M rows of 257 bins: the persistent grid strides many times; checked on a sample and through properties"""
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    B, N = 1 << 20, 257
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.rand(B, N, device=dev, generator=g)
+    y = torch.rand(B, N, device=dev, generator=g)
+    pos = torch.linspace(0, 1, N, device=dev)
+    mod = Wasserstein1D(p=1).to(dev)
+    rows = mod(x[:, None, :], y[:, None, :], x_pos=pos, y_pos=pos, dims=[1])
+    assert rows.shape == (B,) and torch.isfinite(rows).all() and float(rows.min()) >= 0
+    idx = torch.arange(0, B, B // 64, device=dev)
+    want = _oracle_rows(x[idx], y[idx], pos, p=1)
+    np.testing.assert_allclose(rows[idx].cpu().numpy(), want, rtol=1e-5)
+    scalar = mod(x, y, x_pos=pos, y_pos=pos)
+    torch.testing.assert_close(scalar, rows.double().mean().float(), rtol=1e-6, atol=0)
+
+
+def test_module_plumbing():
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    m = Wasserstein1D(p=2, fixed_x=64)
+    assert m.fixed_x.device.type == "cpu"
+    m = m.to(dev)
+    assert m.fixed_x.is_cuda                                   # the buffer follows .to(device) (metrics.py:148)
+    sd = m.state_dict()
+    m2 = Wasserstein1D(p=2, fixed_x=64).to(dev)
+    m2.load_state_dict(sd)
+    x, y = torch.rand(4, 64, device=dev), torch.rand(4, 64, device=dev)
+    assert torch.equal(m(x, y), m2(x, y))
+    # empty batch: mean of zero rows is NaN in the reference too (torch.mean of an empty tensor)
+    e = m(x[:0][:, None, :], y[:0][:, None, :], dims=[1])
+    assert e.shape == (0,)
+    # requires_grad on positions is rejected loudly at backward time
+    xp = torch.linspace(0, 1, 64, device=dev, requires_grad=True)
+    yy = y.clone().requires_grad_(True)
+    loss = Wasserstein1D(p=1).to(dev)(x, yy, x_pos=xp, y_pos=xp.detach().clone())
+    with pytest.raises(NotImplementedError):
+        loss.backward()
+    # half precision is refused rather than silently upcast
+    with pytest.raises(TypeError):
+        m(x.half(), y.half())
+    # mismatched feature sizes
+    with pytest.raises(RuntimeError):
+        Wasserstein1D(p=1).to(dev)(x, y, x_pos=xp.detach()[:10], y_pos=xp.detach())
+
+
+def test_gradients_only_where_requested():
+    """trainer.py differentiates only w.r.t. the estimate (y): grad_x must not be computed or allocated"""
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    x = torch.rand(16, 1025, device=dev)
+    y = torch.rand(16, 1025, device=dev, requires_grad=True)
+    pos = torch.linspace(0, 1, 1025, device=dev)
+    mod = Wasserstein1D(p=2, square_dist=True).to(dev)
+    (mod(x, y, x_pos=pos, y_pos=pos) * 3.0).backward()       # MixOfLosses-style weight on the loss
+    assert x.grad is None and y.grad is not None and torch.isfinite(y.grad).all()
+    g3 = y.grad.clone()
+    y.grad = None
+    mod(x, y, x_pos=pos, y_pos=pos).backward()
+    torch.testing.assert_close(g3, 3.0 * y.grad, rtol=1e-6, atol=0)
