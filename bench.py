@@ -201,7 +201,7 @@ def main():
         parity = None
         try:
             man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
-            if (B, N) == (8192, 2048):
+            if (B, N) == (8192, 2048) and world == 1:  # the stored scalar is that of seed 1234 alone
                 want = man["_config2_b8192n2048_seed1234"][f"uniform_{args.mode}"]
                 parity = abs(first - want) / abs(want)
         except Exception:
