@@ -149,6 +149,8 @@ def make_problem(x, y, xpos, ypos, p, flags, plan=None) -> SotProblem:
     B, n = x.shape
     m = y.shape[1]
     pr = SotProblem()
+    if plan is not None:
+        plan.use_on_current_stream(x.device)
     pr.x, pr.y = x.data_ptr(), y.data_ptr()
     pr.B, pr.n, pr.m = B, n, m
     pr.x_row_stride = x.stride(0) if B > 1 else n
@@ -182,9 +184,18 @@ class PositionPlan:
         self.ident = torch.empty(2, dtype=torch.int32, device=dev)
         xp, yp = xpos.contiguous(), ypos.contiguous()
         with _on_device(dev):
+            self.stream = stream_ptr(dev)
             check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
                                             self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
-                                            self.yperm.data_ptr(), self.ident.data_ptr(), stream_ptr(dev)))
+                                            self.yperm.data_ptr(), self.ident.data_ptr(), self.stream))
+            # the plan is cached and may be consumed from other streams: they wait on this event (see use_plan)
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(dev))
+
+    def use_on_current_stream(self, device):
+        """Order the current stream after the kernel that produced this plan (no-op on the producing stream)."""
+        if stream_ptr(device) != self.stream:
+            torch.cuda.current_stream(device).wait_event(self.ready)
 
 
 def workspace(pr: SotProblem, device) -> torch.Tensor:

@@ -353,7 +353,18 @@ def test_streams_and_graph_capture():
     pos = torch.linspace(0, 1, N, device=dev)
     mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
     with torch.no_grad():
+        # first use of a fresh module happens on a SIDE stream: the plan is created there and the default stream's
+        # call right after must wait for it (plan.ready event), without any host synchronisation in between
+        fresh = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            first = fresh(x, y, x_pos=pos, y_pos=pos)
+        second = fresh(x, y, x_pos=pos, y_pos=pos)
+        torch.cuda.synchronize()
+        assert torch.equal(first, second)
         want = mod(x, y, x_pos=pos, y_pos=pos).clone()
+        assert torch.equal(first, want)
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         outs = []
         for s in (s1, s2, s1, s2):
