@@ -1146,10 +1146,25 @@ __global__ __launch_bounds__(1024) void sot_reduce_mean_kernel(const float* __re
     __shared__ double wsum[16];
     const int t = threadIdx.x;
     double acc = 0.0;
-    for (int64_t r = t; r < B; r += blockDim.x) {
-        float v = row_loss[r];
-        if (apply_hinge) v = fmaxf(v - hinge, 0.0f);
-        acc += (double)v;
+    // Fixed summation order (independent of timing): thread t accumulates rows [8t + 8192k, 8t + 8192k + 8) for k = 0, 1, ...
+    // in ascending order; the loads of one chunk are independent 16-B loads, so the loop is not a chain of L2 round trips.
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(row_loss) & 15) == 0;
+    for (int64_t base = (int64_t)t * 8; base < B; base += (int64_t)blockDim.x * 8) {
+        float v[8];
+        if (vec_ok && base + 8 <= B) {
+            const float4 a = *reinterpret_cast<const float4*>(row_loss + base);
+            const float4 b = *reinterpret_cast<const float4*>(row_loss + base + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (base + k < B) ? row_loss[base + k] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float w = v[k];
+            if (apply_hinge) w = (base + k < B) ? fmaxf(w - hinge, 0.0f) : 0.0f;
+            acc += (double)w;
+        }
     }
     acc = wave_sum(acc);
     if ((t & 63) == 0) wsum[t >> 6] = acc;
