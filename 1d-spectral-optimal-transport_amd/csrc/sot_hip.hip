@@ -30,6 +30,11 @@
 #ifndef SOT_ABLATE
 #define SOT_ABLATE 0
 #endif
+// Waves inside the partition search + merge walk (dependent LDS chains) run at raised priority so that they win issue
+// slots over co-resident waves in throughput phases: measured -2.7 % kernel time (interleaved A/B, steady state).
+#ifndef SOT_WALK_PRIO
+#define SOT_WALK_PRIO 1
+#endif
 
 namespace sot {
 
@@ -534,6 +539,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         // ---- P4: merge of the two CDFs = sort(cat(U,V)) + searchsorted + take_along_dim -----------
         //      (losses.py:295-298), level widths, cutoff mask, |.|^p, weighted sum (:301-313)
         float acc = 0.0f;
+        __builtin_amdgcn_s_setprio(SOT_WALK_PRIO);
         if (t < c.Ga) {
             // Walk over (Uw, V) where Uw = pad zero levels ++ U: exactly E steps for every thread.
             const float* const Uw = U - c.pad;
@@ -592,6 +598,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             if (a.oV) for (int e = t; e < m; e += G) a.oV[row * (int64_t)m + e] = V[e];
         }
         SOT_STAMP(7);
+        __builtin_amdgcn_s_setprio(0);
         acc = wave_sum(acc);
         if (CSR && bad_row) acc = __int_as_float(0x7fc00000);
         if (NW == 1) {

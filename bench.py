@@ -40,8 +40,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md "Chip-level parameters": HBM3E 8.0 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--prewarm", type=int, default=400,
+                    help="untimed steps before the W warm-up steps: the first few hundred launches run ~10 %% slower (clock ramp)")
     ap.add_argument("--rows", type=int, default=8192, help="rows (spectrum pairs) per GPU")
     ap.add_argument("--nfft", type=int, default=2048, help="row length N")
     ap.add_argument("--mode", choices=list(MODES), default="p1")
@@ -153,7 +155,7 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    for i in range(args.warmup):
+    for i in range(args.prewarm + args.warmup):
         out = step(i)
     first = float(step(0))  # parity value on set 0 (global mean when N > 1)
     torch.cuda.synchronize()
@@ -258,7 +260,7 @@ def main():
             "config": {"workload": f"SOT-2048 config: B={B} rows/GPU x N_fft={N} fp32 spectrum pairs, forward, mode {args.mode} "
                                    f"({json.dumps(MODES[args.mode])}), shared linspace positions, {len(sets)} rotating input sets "
                                    f"({len(sets) * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",
-                       "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "global_rows": world * B,
+                       "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "prewarm_steps": args.prewarm, "global_rows": world * B,
                        "collective": "none" if not dist_on else "one RCCL all-reduce(SUM) of the fp64 partial sum per step" + (" (HIP-graph replay)" if args.graph_steps else ""),
                        "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
