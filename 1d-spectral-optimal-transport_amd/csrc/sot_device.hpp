@@ -49,6 +49,9 @@ __device__ __forceinline__ MassPlan make_mass_plan(int n)
 template <bool SQ>
 __device__ __forceinline__ float ldw(const float* raw, int e) { const float w = raw[e]; return SQ ? w * w : w; }
 
+#ifndef SOT_CHUNK_UNROLL
+#define SOT_CHUNK_UNROLL 1
+#endif
 template <int G, bool SQ>
 __device__ __forceinline__ void mass_chunk_sums(const float* raw, float* part, const MassPlan& mp, int t)
 {
@@ -58,7 +61,7 @@ __device__ __forceinline__ void mass_chunk_sums(const float* raw, float* part, c
         const int s0 = h << 4;
         const int s1 = min(s0 + 16, mp.steps);
         float acc = 0.0f;
-        if (s1 - s0 == 16) {  // full chunk: issue the 16 LDS reads back to back, then the ordered adds
+        if (SOT_CHUNK_UNROLL && s1 - s0 == 16) {  // full chunk: issue the 16 LDS reads back to back, then the ordered adds
             float v[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) v[s] = ldw<SQ>(raw, ((s0 + s) << 5) + c);
@@ -74,6 +77,9 @@ __device__ __forceinline__ void mass_chunk_sums(const float* raw, float* part, c
 // Phase B: executed by 32 consecutive lanes (c = 0..31), one per column: cascade of the chunk sums
 // plus the left-over 8-lane vectors (which ATen adds to ILP group 0).  Returns the column total.
 // For n < 8 (ATen's scalar_inner_sum path) lane c == 0 returns the complete row sum instead.
+#ifndef SOT_COLUMN_PREFETCH
+#define SOT_COLUMN_PREFETCH 1   /* -0.3 us */
+#endif
 template <bool SQ>
 __device__ __forceinline__ float mass_column(const float* raw, const float* part, const MassPlan& mp, int c)
 {
@@ -87,9 +93,20 @@ __device__ __forceinline__ float mass_column(const float* raw, const float* part
     }
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     const int nfull = mp.steps >> 4;
+#if SOT_COLUMN_PREFETCH
+    // the first four chunk sums (all of them for n <= 2048) are fetched together: one LDS round trip instead of a
+    // dependent load -> add chain inside the serial mass fold
+    float pre[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) pre[h] = (h < nfull) ? part[(h << 5) + c] : 0.0f;
+#endif
     int i = 0;
     for (int h = 0; h < nfull; ++h) {
+#if SOT_COLUMN_PREFETCH
+        a0 = (h < 4) ? pre[h & 3] : part[(h << 5) + c];
+#else
         a0 = part[(h << 5) + c];
+#endif
         i += 16;
         a1 += a0; a0 = 0.0f;
         if ((i & (15 << 4)) == 0) {

@@ -35,6 +35,31 @@
 #ifndef SOT_WALK_PRIO
 #define SOT_WALK_PRIO 1
 #endif
+#ifndef SOT_MASS_PRIO
+#define SOT_MASS_PRIO 2
+#endif
+// tuning knobs of the A/B harness (tools/ab_probe.py); the defaults are the measured best
+#ifndef SOT_SCAN_PRIO
+#define SOT_SCAN_PRIO 0
+#endif
+#ifndef SOT_E_MODE
+#define SOT_E_MODE 0   /* 0: ceil(K/G) forced odd (58.45 us with walk unroll 2); 1: plain (59.2); 2: even with odd half */
+#endif
+#ifndef SOT_WALK_UNROLL
+#define SOT_WALK_UNROLL 2  /* 0: compiler's choice (x4): 59.45 us; 1: 59.95; 2: 58.85 */
+#endif
+#ifndef SOT_POS_BATCH
+#define SOT_POS_BATCH 1
+#endif
+#ifndef SOT_LDS_SKEW
+#define SOT_LDS_SKEW 0   /* 4 / 8 / 16: no effect (the regions are already 24 floats off a bank period) */
+#endif
+#ifndef SOT_ONE_TRIP
+#define SOT_ONE_TRIP 0
+#endif
+#ifndef SOT_LDS_SKEW2
+#define SOT_LDS_SKEW2 0
+#endif
 
 namespace sot {
 
@@ -58,7 +83,13 @@ __host__ __device__ inline int next_pow2(int v) { int p = 1; while (p < v) p <<=
 
 // merged elements handled by one thread: ceil(K / G) forced odd, so that the per-lane LDS address stride of
 // the merge walk (~E/2 floats) is not a multiple of the 32-bank period on regular data
-__host__ __device__ inline int merge_steps(int K, int G) { return ((K + G - 1) / G) | 1; }
+__host__ __device__ inline int merge_steps(int K, int G)
+{
+    const int e = (K + G - 1) / G;
+    if (SOT_E_MODE == 1) return e;
+    if (SOT_E_MODE == 2) return ((e + 1) & ~3) + 2;  // E/2 odd: 2, 6, 10, 14, 18, ...
+    return e | 1;
+}
 
 __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpos, bool with_grad = false)
 {
@@ -66,8 +97,8 @@ __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpo
     // The U and PX regions start with `padcap` spare floats: the forward walk prepends pad < E zero-valued
     // levels to U (zero width => zero contribution) so that every thread walks exactly E merged elements.
     L.padcap = align4(merge_steps(n + m, G));
-    L.nU = L.padcap + align4(n + 1);
-    L.nV = align4(m + 1);
+    L.nU = L.padcap + align4(n + 1) + SOT_LDS_SKEW;  // skew: keeps U[i] and V[i] (and PX / PY) off the same LDS banks
+    L.nV = align4(m + 1) + SOT_LDS_SKEW2;
     if (rowpos) {  // per-row position sort needs power-of-two scratch for the bitonic network
         L.nU = max(L.nU, L.padcap + next_pow2(n));
         L.nV = max(L.nV, next_pow2(m));
@@ -81,7 +112,7 @@ __host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpo
     L.wtot = L.colbuf + 64;
     const int NW = G / kWave;
     L.red = L.wtot + 4 * NW;  // 2 arrays * NW doubles = 4*NW floats
-    L.grad = align4(L.red + NW + 2);
+    L.grad = align4(L.red + NW + 4);  // red[NW] | S_x, S_y | 1/S_x^, 1/S_y^ (guarded masses' reciprocals)
     L.row_floats = with_grad ? L.grad + L.nU + L.nV : L.grad;  // GU = U + grad, GV = V + grad
     return L;
 }
@@ -161,8 +192,28 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     c.x_ident = true; c.y_ident = true;
     if (!ROWPOS) {
         if (a.ident != nullptr) { c.x_ident = a.ident[0] != 0; c.y_ident = a.ident[1] != 0; }
+#if SOT_POS_BATCH
+        // issue every position load before the first LDS store (independent loads: one memory round trip, not one per
+        // element), in batches of 8 per array so that any row length is covered
+        for (int e0 = 0; e0 < max(c.n, c.m); e0 += 8 * G) {
+            float px[8], py[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + c.t + k * G;
+                px[k] = (e < c.n) ? a.xpos[e] : 0.0f;
+                py[k] = (e < c.m) ? a.ypos[e] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + c.t + k * G;
+                if (e < c.n) c.PX[e] = px[k];
+                if (e < c.m) c.PY[e] = py[k];
+            }
+        }
+#else
         for (int e = c.t; e < c.n; e += G) c.PX[e] = a.xpos[e];
         for (int e = c.t; e < c.m; e += G) c.PY[e] = a.ypos[e];
+#endif
         for (int e = c.t; e < c.pad; e += G) c.PX[e - c.pad] = a.xpos[0];  // any finite value: the width is 0
         if (c.t == 0) {
             c.PX[c.n] = a.xpos[c.n - 1];  // clamp of losses.py:220: ranks beyond the last index reuse it
@@ -288,6 +339,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     // ---- P2: row masses in ATen order (losses.py:177,184; the reference sums BEFORE it sorts, so the
     //      staged row is still in its original column order here) -----------------------------------
     float Sx = 1.0f, Sy = 1.0f;  // prenormalised: w / 1.0f == w exactly, weights enter the CDF unchanged
+    float rSx = 1.0f, rSy = 1.0f;  // reciprocals of the guarded masses (computed once per row by the fold waves)
     if (!(SOT_ABLATE & 4) && !c.prenorm) {
         if (sq) {
             mass_chunk_sums<G, true>(U, c.partx, c.mpx, t);
@@ -302,6 +354,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         // in its two half-waves): the 32 column totals are exchanged through this wave's own LDS slots.
         // (Doing this redundantly in every wave to save the barrier below was measured 10 % SLOWER.)
         float* const Sv = c.red + NW;
+        __builtin_amdgcn_s_setprio(SOT_MASS_PRIO);
         if (NW >= 2) {
             if (c.wv < 2 && !(c.wv == 1 && c.dn)) {
                 const float* raw = c.wv ? V : U;
@@ -313,7 +366,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const float S = sq ? mass_fold<true>(raw, cb, mp.n) : mass_fold<false>(raw, cb, mp.n);
-                if (c.lane == 0) Sv[c.wv] = S;
+                if (c.lane == 0) { Sv[c.wv] = S; Sv[2 + c.wv] = 1.0f / guard_mass(S); }  // IEEE reciprocal, once per row
             }
         } else {
             const int half = c.lane >> 5, col = c.lane & 31;
@@ -327,17 +380,21 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const float S = sq ? mass_fold<true>(raw, cb, mp.n) : mass_fold<false>(raw, cb, mp.n);
-            if (col == 0) Sv[half] = S;
+            if (col == 0) { Sv[half] = S; Sv[2 + half] = 1.0f / guard_mass(S); }
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         SOT_STAMP(3);
         Sx = Sv[0];
         Sy = c.dn ? Sx : Sv[1];
+        rSx = Sv[2];
+        rSy = c.dn ? rSx : Sv[3];
     }
     Sx_out = Sx; Sy_out = Sy;
 
     // ---- P3: safe_divide (utils.py:135-142), weight gather by the position sort (losses.py:289-290)
     //      and fp64-accumulated CDFs (losses.py:292-293) --------------------------------------------
+    __builtin_amdgcn_s_setprio(SOT_SCAN_PRIO);
     const float Sxh = guard_mass(Sx);
     const float Syh = guard_mass(Sy);
     const bool x_perm = ROWPOS ? c.do_sort : !c.x_ident;
@@ -379,7 +436,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     {
         // quotients: reciprocal + FMA residual correction (exact, see div_by_row_constant); the chunk is
         // redone with the IEEE sequence if an operand was small enough for the residual to underflow
-        const float rx = 1.0f / Sxh, ry = 1.0f / Syh;
+        const float rx = rSx, ry = rSy;
         float qx[CPT], qy[CPT];
         uint32_t risk = 0xFFFFFFFFu;
 #pragma unroll
@@ -415,8 +472,18 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     SOT_STAMP(4);
     __syncthreads();  // every raw weight has been read (also through permutations) before U/V are rewritten
     if (NW > 1) {
+#if SOT_ONE_TRIP
+        // all wave totals are fetched in one LDS round trip (independent reads) and summed in wave order
+        double tx[NW], ty[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { tx[w] = c.wtot[w]; ty[w] = c.wtot[NW + w]; }
+        double ox = 0.0, oy = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { ox += (w < c.wv) ? tx[w] : 0.0; oy += (w < c.wv) ? ty[w] : 0.0; }
+#else
         double ox = 0.0, oy = 0.0;
         for (int w = 0; w < c.wv; ++w) { ox += c.wtot[w]; oy += c.wtot[NW + w]; }
+#endif
         exx += ox;
         exy += oy;
     }
@@ -439,6 +506,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
         for (int k = 0; k < CPT; ++k) if (e0 + k < m) V[e0 + k] = (float)(exy + py[k]);
     }
     if (ROWPOS && t == 0) { U[n] = INFINITY; V[m] = INFINITY; }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 }
 
@@ -558,6 +626,9 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             const uint32_t poff4 = 4u * (uint32_t)c.L.poff;
             const int voff = (int)(V - Uw);
             uint32_t iu = (uint32_t)i0;
+#if SOT_WALK_UNROLL > 0
+#pragma unroll SOT_WALK_UNROLL
+#endif
             for (int s = 0; s < ((SOT_ABLATE & 1) ? 1 : c.E); ++s) {
                 const bool tu = ua <= vb;
                 const float q = tu ? ua : vb;
@@ -679,6 +750,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         // ---- merge walk over (pad zero levels ++ U, V), exactly E steps per thread.  The gradient of a level
         //      is known one step later (it is non-zero only if the NEXT level starts a new run), so the store
         //      of element k-1 happens at step k; the thread's last element is closed by peeking at level D0+E.
+        __builtin_amdgcn_s_setprio(SOT_WALK_PRIO);
         if (t < c.Ga) {
             const float* const Uw = U - c.pad;
             const float* const PXw = PX - c.pad;
@@ -732,6 +804,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
                 *reinterpret_cast<float*>(lb + prev_off + goff4) = new_run ? (dcur - cn) : 0.0f;
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
 
         // ---- reverse cumsums (fp64), normalisation terms, scatter to the original columns -------------
