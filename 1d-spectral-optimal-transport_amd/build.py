@@ -21,7 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # sot_hip.hip is compiled in parts (-DSOT_PART=<bit>) in parallel and linked into one shared library:
 # forward/shared positions, forward/per-row positions, backward/shared, backward/per-row, everything else, CSR forward.
-PARTS = (1, 2, 4, 8, 16, 32)
+PARTS = (1, 64, 2, 4, 8, 16, 32)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "obj")
 
 

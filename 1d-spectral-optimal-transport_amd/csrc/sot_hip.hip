@@ -21,9 +21,10 @@
 // The file can be compiled whole (default) or in parts that are linked into one library, so that the many
 // kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
 // positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI),
-// bit 5 the CSR (ragged) forward.
+// bit 5 the CSR (ragged) forward, bit 6 the cutoff (limit_quantile_range) family of forward/shared positions (bit 0 then
+// holds the no-cutoff family).
 #ifndef SOT_PART
-#define SOT_PART 63
+#define SOT_PART 127
 #endif
 // Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
 // search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
@@ -324,7 +325,8 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
 // written).  Exit (after its final barrier): U/V hold the CDFs.  Each thread owns the CPT contiguous
 // elements [t*CPT, t*CPT + CPT) of each array in sorted order; wx/wy receive their ORIGINAL (unsquared)
 // weights (only consumed by the backward kernel).
-template <int G, int CPT, bool ROWPOS>
+// SQM: square_dist known at compile time (0 = no, 1 = yes) or read from the flags (2)
+template <int G, int CPT, bool ROWPOS, int SQM = 2>
 __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c, const int (&ix)[CPT], const int (&iy)[CPT],
                                            float (&wx)[CPT], float (&wy)[CPT], float& Sx_out, float& Sy_out,
                                            const bool stamp_on = false)
@@ -333,7 +335,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     constexpr int NW = G / kWave;
     const int n = c.n, m = c.m, t = c.t;
     float* const U = c.U; float* const V = c.V;
-    const bool sq = c.sq;
+    const bool sq = (SQM == 2) ? c.sq : (SQM == 1);
     const int e0 = t * CPT;
 
     // ---- P2: row masses in ATen order (losses.py:177,184; the reference sums BEFORE it sorts, so the
@@ -527,10 +529,11 @@ __device__ __forceinline__ int lower_rank(const float* A, int len, float q)
 //   PM     cost specialisation: 1 -> p == 1, 2 -> p == 2, 0 -> powf
 //   LIM    limit_quantile_range: levels Q_k > 1 contribute nothing
 //   VEC    rows are 16-B aligned and n, m multiples of 4: 16-B-per-lane global loads
+//   SQM    square_dist at compile time (0 / 1) in the specialised p = 1 / p = 2 variants (-2.8 % kernel time), 2 = runtime flag
 // Row pipeline: the NEXT row's weights are fetched into registers while the current row is being
 // processed in LDS, so HBM latency overlaps the scan/merge work of the same workgroup.
 // ---------------------------------------------------------------------------------------------
-template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, bool CSR = false>
+template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, bool CSR = false, int SQM = 2>
 __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const FwdArgs a)
 {
     static_assert(!CSR || (ROWPOS && !VEC && !QUANT), "the CSR form has per-row positions and unaligned rows");
@@ -598,9 +601,9 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         float wx[CPT], wy[CPT];
         float Sx, Sy;
 #ifdef SOT_STAMPS
-        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy, stamp_on);
+        build_cdfs<G, CPT, ROWPOS, SQM>(a, c, ix, iy, wx, wy, Sx, Sy, stamp_on);
 #else
-        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy);
+        build_cdfs<G, CPT, ROWPOS, SQM>(a, c, ix, iy, wx, wy, Sx, Sy);
 #endif
         SOT_STAMP(5);
 
@@ -1054,11 +1057,11 @@ int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const f
 #endif
 #endif  // SOT_STUB_MISSING_PARTS
 
-#if SOT_PART & 3
-template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC>
+#if SOT_PART & 67
+template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, int SQM = 2>
 static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
 {
-    auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT, PM, LIM, VEC>;
+    auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT, PM, LIM, VEC, false, SQM>;
     static const size_t extra_lds = debug_extra_lds();
     lds += extra_lds;
     static int grid_cap = 0;  // per instantiation; LDS size per (n, m) may differ, so cache per lds value
@@ -1077,12 +1080,41 @@ static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int
 template <int G, int CPT, bool ROWPOS, bool LIM, bool VEC>
 static hipError_t dispatch_forward_pm(int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
 {
+    // p = 1 and p = 2 get square_dist at compile time as well (one multiply + select per element less); any other p
+    // goes through the generic variant (powf, runtime flag)
+    const bool sq = (a.flags & SOT_FLAG_SQUARE) && !(a.flags & SOT_FLAG_PRENORMALIZED);
     switch (pm) {
-        case 1: return launch_forward<G, CPT, ROWPOS, false, 1, LIM, VEC>(a, lds, want, block, s);
-        case 2: return launch_forward<G, CPT, ROWPOS, false, 2, LIM, VEC>(a, lds, want, block, s);
-        default: return launch_forward<G, CPT, ROWPOS, false, 0, LIM, VEC>(a, lds, want, block, s);
+        case 1: return sq ? launch_forward<G, CPT, ROWPOS, false, 1, LIM, VEC, 1>(a, lds, want, block, s)
+                          : launch_forward<G, CPT, ROWPOS, false, 1, LIM, VEC, 0>(a, lds, want, block, s);
+        case 2: return sq ? launch_forward<G, CPT, ROWPOS, false, 2, LIM, VEC, 1>(a, lds, want, block, s)
+                          : launch_forward<G, CPT, ROWPOS, false, 2, LIM, VEC, 0>(a, lds, want, block, s);
+        default: return launch_forward<G, CPT, ROWPOS, false, 0, LIM, VEC, 2>(a, lds, want, block, s);
     }
 }
+
+template <int G, int CPT, bool LIM>
+hipError_t forward_shared(int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    return vec ? dispatch_forward_pm<G, CPT, false, LIM, true>(pm, a, lds, want, block, s)
+               : dispatch_forward_pm<G, CPT, false, LIM, false>(pm, a, lds, want, block, s);
+}
+// explicit instantiation of one LIM family per build part; the other family is an external symbol of this part
+#define SOT_FWD_SHARED_ALL(PREFIX, LIMV)                                                                              \
+    PREFIX template hipError_t forward_shared<64, 8, LIMV>(int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t);   \
+    PREFIX template hipError_t forward_shared<128, 12, LIMV>(int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t); \
+    PREFIX template hipError_t forward_shared<256, 8, LIMV>(int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t);  \
+    PREFIX template hipError_t forward_shared<1024, 8, LIMV>(int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t); \
+    PREFIX template hipError_t forward_shared<1024, 16, LIMV>(int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t);
+#if SOT_PART & 1
+SOT_FWD_SHARED_ALL(, false)
+#else
+SOT_FWD_SHARED_ALL(extern, false)
+#endif
+#if SOT_PART & 64
+SOT_FWD_SHARED_ALL(, true)
+#else
+SOT_FWD_SHARED_ALL(extern, true)
+#endif
 
 template <int G, int CPT, bool ROWPOS>
 static hipError_t dispatch_forward_g(bool quant, int pm, bool vec, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
@@ -1091,11 +1123,18 @@ static hipError_t dispatch_forward_g(bool quant, int pm, bool vec, const FwdArgs
     if (quant)  // rare path: one generic build per cutoff flavour
         return lim ? launch_forward<G, CPT, ROWPOS, true, 0, true, false>(a, lds, want, block, s)
                    : launch_forward<G, CPT, ROWPOS, true, 0, false, false>(a, lds, want, block, s);
-    if (ROWPOS || !vec)
+    if constexpr (ROWPOS) {
         return lim ? dispatch_forward_pm<G, CPT, ROWPOS, true, false>(pm, a, lds, want, block, s)
                    : dispatch_forward_pm<G, CPT, ROWPOS, false, false>(pm, a, lds, want, block, s);
-    return lim ? dispatch_forward_pm<G, CPT, false, true, true>(pm, a, lds, want, block, s)
-               : dispatch_forward_pm<G, CPT, false, false, true>(pm, a, lds, want, block, s);
+    } else {
+        // shared positions: the cutoff (LIM) and no-cutoff families are compiled in different build parts
+#if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 64)
+        if (lim) return hipErrorInvalidDeviceFunction;  // diagnostic build without the cutoff family
+#else
+        if (lim) return forward_shared<G, CPT, true>(pm, vec, a, lds, want, block, s);
+#endif
+        return forward_shared<G, CPT, false>(pm, vec, a, lds, want, block, s);
+    }
 }
 
 template <bool ROWPOS>
