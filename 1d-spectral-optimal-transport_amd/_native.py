@@ -18,6 +18,7 @@ FLAG_SQUARE = 1
 FLAG_DONT_NORMALIZE = 2
 FLAG_LIMIT_Q = 4
 FLAG_REQUIRE_SORT = 8
+FLAG_NO_SPECIALIZE = 32  # diagnostic: generic forward kernel only (include/sot_hip.h)
 
 SOT_OK = 0
 SOT_ERR_INVALID_P = -1

@@ -11,7 +11,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "sot_hip.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"),
+DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")]
 LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 
@@ -20,8 +20,9 @@ LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # sot_hip.hip is compiled in parts (-DSOT_PART=<bit>) in parallel and linked into one shared library:
-# forward/shared positions, forward/per-row positions, backward/shared, backward/per-row, everything else, CSR forward.
-PARTS = (1, 64, 2, 4, 8, 16, 32)
+# forward/shared positions (no cutoff, cutoff), full-row forward, forward/per-row positions, backward/shared,
+# backward/per-row, everything else, CSR forward.
+PARTS = (1, 64, 128, 2, 4, 8, 16, 32)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "obj")
 
 

@@ -22,9 +22,9 @@
 // kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
 // positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI),
 // bit 5 the CSR (ragged) forward, bit 6 the cutoff (limit_quantile_range) family of forward/shared positions (bit 0 then
-// holds the no-cutoff family).
+// holds the no-cutoff family), bit 7 the full-row forward (n == m == G*CPT, everything at compile time).
 #ifndef SOT_PART
-#define SOT_PART 127
+#define SOT_PART 255
 #endif
 // Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
 // search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
@@ -79,12 +79,13 @@ struct RowLayout {
     int row_floats;      // total, multiple of 4
 };
 
-__host__ __device__ inline int align4(int v) { return (v + 3) & ~3; }
-__host__ __device__ inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+__host__ __device__ constexpr int align4(int v) { return (v + 3) & ~3; }
+__host__ __device__ constexpr int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 // merged elements handled by one thread: ceil(K / G) forced odd, so that the per-lane LDS address stride of
 // the merge walk (~E/2 floats) is not a multiple of the 32-bank period on regular data
-__host__ __device__ inline int merge_steps(int K, int G)
+__host__ __device__ constexpr int merge_steps(int K, int G)
 {
     const int e = (K + G - 1) / G;
     if (SOT_E_MODE == 1) return e;
@@ -92,17 +93,17 @@ __host__ __device__ inline int merge_steps(int K, int G)
     return e | 1;
 }
 
-__host__ __device__ inline RowLayout make_layout(int n, int m, int G, bool rowpos, bool with_grad = false)
+__host__ __device__ constexpr RowLayout make_layout(int n, int m, int G, bool rowpos, bool with_grad = false)
 {
-    RowLayout L;
+    RowLayout L{};
     // The U and PX regions start with `padcap` spare floats: the forward walk prepends pad < E zero-valued
     // levels to U (zero width => zero contribution) so that every thread walks exactly E merged elements.
     L.padcap = align4(merge_steps(n + m, G));
     L.nU = L.padcap + align4(n + 1) + SOT_LDS_SKEW;  // skew: keeps U[i] and V[i] (and PX / PY) off the same LDS banks
     L.nV = align4(m + 1) + SOT_LDS_SKEW2;
     if (rowpos) {  // per-row position sort needs power-of-two scratch for the bitonic network
-        L.nU = max(L.nU, L.padcap + next_pow2(n));
-        L.nV = max(L.nV, next_pow2(m));
+        L.nU = imax(L.nU, L.padcap + next_pow2(n));
+        L.nV = imax(L.nV, next_pow2(m));
     }
     L.poff = L.nU + L.nV;
     const int nchx = (((n >= 8) ? (n >> 5) : 0) + 15) >> 4;
@@ -1026,6 +1027,7 @@ hipError_t dispatch_forward(const LaunchCfg& c, bool quant, int pm, bool vec, co
 template <bool ROWPOS>
 hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block,
                              hipStream_t s);
+hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                    hipStream_t s);
 int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
@@ -1050,6 +1052,9 @@ template <> hipError_t dispatch_backward<false>(const LaunchCfg&, int, bool, con
 #endif
 #if !(SOT_PART & 8)
 template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, const BwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+#endif
+#if !(SOT_PART & 128)
+hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 #endif
 #if !(SOT_PART & 32)
 int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const float*, const float*, const int64_t*, int64_t, int64_t, int,
@@ -1157,6 +1162,10 @@ template hipError_t dispatch_forward<false>(const LaunchCfg&, bool, int, bool, c
 template hipError_t dispatch_forward<true>(const LaunchCfg&, bool, int, bool, const FwdArgs&, size_t, int64_t, int, hipStream_t);
 #endif
 #endif  // forward parts
+
+#if SOT_PART & 128
+#include "sot_forward_full.inc"
+#endif
 
 #if SOT_PART & 12
 template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
@@ -1390,8 +1399,16 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
     if (pr->B == 0) return SOT_OK;
     l.a.row_loss = row_loss;
     l.a.oUq = uq; l.a.oVq = vq; l.a.oQ = Q; l.a.oU = U; l.a.oV = V;
-    const hipError_t e = l.rowpos ? dispatch_forward<true>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s)
-                                  : dispatch_forward<false>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s);
+    // rows that fill their geometry exactly (512, 2048 or 8192 bins) take the fully specialised kernel
+    bool full = !l.rowpos && !quant && l.vec && (l.pm == 1 || l.pm == 2) && pr->n == pr->m &&
+                (int64_t)l.cfg.G * l.cfg.CPT == pr->n && (pr->n % 512) == 0 && l.cfg.CPT == 8 &&
+                !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
+#if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
+    full = false;
+#endif
+    const hipError_t e = full       ? dispatch_forward_full(l.cfg, l.pm, l.a, l.lds, l.want, l.block, l.s)
+                         : l.rowpos ? dispatch_forward<true>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s)
+                                    : dispatch_forward<false>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

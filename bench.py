@@ -10,7 +10,7 @@ scalar partial sum.  Inputs rotate over several distinct sets so that the 256 Mi
 cannot serve them.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     -- dominant kernel (sot_forward_kernel): algorithmic bytes per launch / average launch
+  roofline     -- dominant kernel (sot_forward_full_kernel: the forward specialised for rows that fill their geometry): algorithmic bytes per launch / average launch
                   duration measured with HIP events on the launch stream inside the timed region;
   cpu_baseline -- the op-for-op torch restatement of the reference (oracle/torch_restatement.py,
                   kind "port") timed on this host's cores on a bounded sample of the same workload.
@@ -127,7 +127,7 @@ def main():
                 a.record()
             if not dist_on:
                 # same two kernels as Wasserstein1D.forward (sot_w1d_loss), issued as two calls so that the HIP
-                # events bracket the dominant kernel (sot_forward_kernel) alone
+                # events bracket the dominant kernel (sot_forward_full_kernel: the forward specialised for rows that fill their geometry) alone
                 x2, y2, xp, yp, flags, plan, _ = mod._marshal(x, y, pos_x, pos_y, {})
                 rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan)
                 if profile is not None:
@@ -264,7 +264,7 @@ def main():
                        "collective": "none" if not dist_on else "one RCCL all-reduce(SUM) of the fp64 partial sum per step" + (" (HIP-graph replay)" if args.graph_steps else ""),
                        "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "sot_forward_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "sot_forward_full_kernel",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B},
             "extras": extras,
         }

@@ -47,6 +47,9 @@ typedef enum sot_status {
 #define SOT_FLAG_PRENORMALIZED 16u /* weights are used as given: the functional wasserstein_1d(u_values,
                                       v_values, u_weights, v_weights) of losses.py:223, which does not
                                       normalise (flags SQUARE / DONT_NORMALIZE are then ignored)       */
+#define SOT_FLAG_NO_SPECIALIZE 32u /* diagnostic: always run the generic forward kernel, never the variants
+                                      specialised for rows that fill their launch geometry exactly (results
+                                      are bit-identical either way; the tests compare the two)               */
 
 /* One batch of spectrum pairs.  Mirrors the arguments of Wasserstein1D.forward
  * (losses.py:129) after its [batch,time,N] -> [B,N] reshape (losses.py:157-170). */

@@ -105,6 +105,43 @@ def test_config2_full_size_scalars(kind, mode, manifest):
     assert abs(got - want) <= RTOL * abs(want), (got, want)
 
 
+@pytest.mark.parametrize("N,B", [(512, 1030), (2048, 520), (8192, 70)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0)])
+def test_full_row_kernel_matches_generic(N, B, flags, p):
+    """Rows that fill their launch geometry (n == m == G*CPT) run the fully specialised forward kernel: it must agree
+    bit for bit with the generic kernel (SOT_FLAG_NO_SPECIALIZE) and, on a sample of rows, with the oracle."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    x, y = gen_inputs("peaky", B, N, N, 4321 + N)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.linspace(0, 1, N).to(device())
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
+    gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
+    assert torch.equal(spec, gen), float((spec - gen).abs().max())
+    k = min(B, 24)
+    want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
+    np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
+
+
+def test_full_row_kernel_with_unsorted_shared_positions():
+    """The specialised kernel gathers through the shared sort permutation when the positions arrive unsorted."""
+    nat = native()
+    from oracle.inputs import gen_inputs
+    N, B = 2048, 64
+    x, y = gen_inputs("uniform", B, N, N, 99)
+    x, y = x.to(device()), y.to(device())
+    g = torch.Generator().manual_seed(5)
+    pos = torch.linspace(0, 1, N)[torch.randperm(N, generator=g)].to(device())
+    pos2 = torch.linspace(0, 2, N)[torch.randperm(N, generator=g)].to(device())
+    for flags, p in [(8, 1.0), (1 | 2 | 4 | 8, 2.0)]:
+        spec = nat.forward_rows(x, y, pos, pos2, p, flags)
+        gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE)
+        assert torch.equal(spec, gen)
+
+
 def test_full_size_properties():
     """Size-independent properties at B=8192, N=2048 (no oracle needed)."""
     from oracle.inputs import gen_inputs
