@@ -58,6 +58,9 @@
 #ifndef SOT_ONE_TRIP
 #define SOT_ONE_TRIP 0
 #endif
+#ifndef SOT_POFF_ALIGN
+#define SOT_POFF_ALIGN 1   /* 64: a level and its position are 64-dword multiples apart (one ds_read2st64_b32 fetches both) */
+#endif
 #ifndef SOT_LDS_SKEW2
 #define SOT_LDS_SKEW2 0
 #endif
@@ -105,7 +108,7 @@ __host__ __device__ constexpr RowLayout make_layout(int n, int m, int G, bool ro
         L.nU = imax(L.nU, L.padcap + next_pow2(n));
         L.nV = imax(L.nV, next_pow2(m));
     }
-    L.poff = L.nU + L.nV;
+    L.poff = (L.nU + L.nV + SOT_POFF_ALIGN - 1) / SOT_POFF_ALIGN * SOT_POFF_ALIGN;
     const int nchx = (((n >= 8) ? (n >> 5) : 0) + 15) >> 4;
     const int nchy = (((m >= 8) ? (m >> 5) : 0) + 15) >> 4;
     L.part_x = 2 * L.poff;
