@@ -253,6 +253,38 @@ __device__ __forceinline__ int merge_path(const float* U, const float* V, int n,
     return lo;
 }
 
+// Branch-free form of the same partition search for the hot kernels: a fixed (wave-uniform) number of rounds with the
+// descending steps 2^k + 1, ..., 9, 5, 3, 2, 1 from the lower end of the diagonal's range.  A step is taken when it stays
+// inside the range and the predicate holds at its last element; any step sequence with s_k <= 1 + (sum of the later
+// steps) finds every count up to the sum of all steps.  Compared with the bisection above: no divergent loop, 7 VALU per
+// round instead of 12, and probes of lanes whose searches have diverged by a multiple of 32 elements do not pile up in one
+// LDS bank (steps 2^k do).  Probes outside the range read neighbouring LDS and are masked by the range test.
+// `topk`: see merge_steps_top(); the result is identical to merge_path().
+__host__ __device__ constexpr int merge_steps_top(int range)  // reach of (2^k + 1, ..., 5, 3, 2, 1) = 2^(k+1) + k + 1
+{
+    int k = 1;
+    while ((2 << k) + k + 1 < range) ++k;
+    return k;
+}
+__device__ __forceinline__ int merge_path_steps(const float* U, const float* V, int n, int m, int D, int topk)
+{
+    const int lo = max(0, D - m), hi = min(D, n);
+    int pos = lo;
+    const float* const vd = V + D;  // V[D - cand] = vd[-cand]
+    for (int k = topk; k >= 1; --k) {
+        const int cand = pos + (1 << k) + 1;
+        const int take = (int)(cand <= hi) & (int)(U[cand - 1] <= vd[-cand]);  // bitwise: no branch around the LDS reads
+        pos = take ? cand : pos;
+    }
+#pragma unroll
+    for (int step = 2; step >= 1; --step) {
+        const int cand = pos + step;
+        const int take = (int)(cand <= hi) & (int)(U[cand - 1] <= vd[-cand]);
+        pos = take ? cand : pos;
+    }
+    return pos;
+}
+
 // PM: 1 -> p == 1 (losses.py:311-312: no pow), 2 -> p == 2 (torch.pow(., 2) is an exact square), 0 -> powf
 template <int PM>
 __device__ __forceinline__ float transport_cost(float xa, float yb, float p)

@@ -158,7 +158,7 @@ struct RowCtx {
     float* GU; float* GV;  // backward only
     RowLayout L;
     MassPlan mpx, mpy;
-    int n, m, K, E, Ga, pad;
+    int n, m, K, E, Ga, pad, topk;
     int t, lane, wv;
     bool sq, dn, lim, do_sort, prenorm, x_ident, y_ident;
     float p;
@@ -193,6 +193,7 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     c.E = merge_steps(c.K, G);
     c.Ga = (c.K + c.E - 1) / c.E;       // threads that take part in the walk
     c.pad = c.Ga * c.E - c.K;           // zero-valued levels prepended to U: 0 <= pad < E <= padcap
+    c.topk = merge_steps_top(min(c.n + c.pad, c.m));
     for (int e = c.t; e < c.pad; e += G) c.U[e - c.pad] = 0.0f;
     c.x_ident = true; c.y_ident = true;
     if (!ROWPOS) {
@@ -241,6 +242,7 @@ __device__ __forceinline__ void set_row_lengths(RowCtx<G>& c, int n, int m)
     c.E = merge_steps(c.K, G);
     c.Ga = (c.K + c.E - 1) / c.E;
     c.pad = c.Ga * c.E - c.K;
+    c.topk = merge_steps_top(min(n + c.pad, m));
 }
 
 // ---- global -> register -> LDS staging of one row (VEC: 16 B per lane, rows 16-B aligned) ------------
@@ -621,7 +623,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             const float* const PXw = PX - c.pad;
             const int nw = n + c.pad;
             const int D0 = t * c.E;
-            const int i0 = (SOT_ABLATE & 2) ? min(D0 >> 1, nw) : merge_path(Uw, V, nw, m, D0);
+            const int i0 = (SOT_ABLATE & 2) ? min(D0 >> 1, nw) : merge_path_steps(Uw, V, nw, m, D0, c.topk);
             SOT_STAMP(6);
             const int j0 = D0 - i0;
             float qprev = 0.0f;  // Q_0 := 0 (the pad of losses.py:301)
@@ -633,6 +635,34 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             const uint32_t poff4 = 4u * (uint32_t)c.L.poff;
             const int voff = (int)(V - Uw);
             uint32_t iu = (uint32_t)i0;
+            if (!QUANT) {
+                // "Loser" form of the two-way merge (see sot_forward_full.inc): (w, wp) is the head fetched last, (r, rp) the
+                // head that lost the previous comparison; only the consumed head's stream is read again, so the fetched
+                // level and position become the new (w, wp) without a select.  Equal heads may be consumed in either
+                // order: the pair of heads, hence the consumed level, its width and its cost factor, is the same, and the
+                // second member of a tie has zero width -- the sum is bit-identical to the canonical order's.
+                float w = ua, wp = xa, r = vb, rp = yb;
+                uint32_t pw = 4u * (uint32_t)i0 + 4u, pr = 4u * (uint32_t)(voff + j0) + 4u;
+#if SOT_WALK_UNROLL > 0
+#pragma unroll SOT_WALK_UNROLL
+#endif
+                for (int s = 0; s < ((SOT_ABLATE & 1) ? 1 : c.E); ++s) {
+                    const bool cw = w <= r;
+                    const float q = cw ? w : r;
+                    const float cost = transport_cost<PM>(wp, rp, c.p);
+                    float delta = q - qprev;
+                    if (LIM && q > 1.0f) delta = 0.0f;
+                    acc = fmaf(delta, cost, acc);  // fused: no worse than the reference's separate rounding
+                    qprev = q;
+                    const uint32_t nx = cw ? pw : pr;
+                    pr = cw ? pr : pw;
+                    pw = nx + 4u;
+                    r = cw ? r : w;
+                    rp = cw ? rp : wp;
+                    w = *reinterpret_cast<const float*>(lb + nx);
+                    wp = *reinterpret_cast<const float*>(lb + nx + poff4);
+                }
+            } else
 #if SOT_WALK_UNROLL > 0
 #pragma unroll SOT_WALK_UNROLL
 #endif
@@ -763,7 +793,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
             const float* const PXw = PX - c.pad;
             const int nw = n + c.pad;
             const int D0 = t * c.E;
-            const int i0 = merge_path(Uw, V, nw, m, D0);
+            const int i0 = merge_path_steps(Uw, V, nw, m, D0, c.topk);
             const int j0 = D0 - i0;
             float qprev = 0.0f;
             if (i0 > 0) qprev = Uw[i0 - 1];
