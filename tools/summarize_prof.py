@@ -18,6 +18,18 @@ for f in find("stats/**/*kernel_stats.csv"):
         name = row.get("Name", "")[:90]
         print(f"{name:90s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} total_ns={row.get('TotalDurationNs')} pct={row.get('Percentage')}")
 
+# per-dispatch durations from the kernel trace: the first few hundred launches of a process run ~10 % slower (clock ramp),
+# so the steady-state average (last 30 dispatches = bench.py's timed region in tools/profile_round.sh) is listed as well
+for f in find("stats/**/*kernel_trace.csv"):
+    durs = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        durs[row.get("Kernel_Name", "")[:90]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    print("== steady state (kernel trace, last 30 dispatches of each kernel with >= 60 dispatches) ==")
+    for k, v in durs.items():
+        if len(v) >= 60:
+            tail = v[-30:]
+            print(f"{k:90s} calls={len(v)} avg_ns_all={sum(v) / len(v):.1f} avg_ns_last30={sum(tail) / len(tail):.1f} min_ns={min(v)}")
+
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
