@@ -9,6 +9,7 @@ import os
 import sys
 
 prof_dir, workload, out = sys.argv[1], sys.argv[2], sys.argv[3]
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "sot_forward_full_kernel<256, 8, 1, 1, false, false>"  # the bench workload's variant
 
 
 def mean_counter(sub, counter, kernel_substr):
@@ -20,9 +21,9 @@ def mean_counter(sub, counter, kernel_substr):
     return sum(vals) / len(vals), len(vals)
 
 
-fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", "sot_forward_full_kernel")
-write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", "sot_forward_full_kernel")
-rec = {"workload": workload, "kernel": "sot_forward_full_kernel", "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
+fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", KERNEL)
+write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", KERNEL)
+rec = {"workload": workload, "kernel": KERNEL, "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
        "dispatches": [nf, nw], "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B on 16-B/lane streams)",
        "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {os.path.basename(prof_dir)}"}
