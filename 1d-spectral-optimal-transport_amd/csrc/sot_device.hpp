@@ -294,6 +294,33 @@ __device__ __forceinline__ int merge_path_steps(const float* U, const float* V, 
     return pos;
 }
 
+// 32-bit LDS byte address of an LDS pointer, and a load from such an address (+ immediate): the merge phases keep their
+// address arithmetic in single VGPRs in byte units (no shift and no re-basing add per access).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ float lds_load(uint32_t addr) { return *reinterpret_cast<lds_cfloat*>((uintptr_t)addr); }
+
+// merge_path_steps() on LDS byte addresses (5 VALU per round): ub1 = address of U[-1], vd1 = address of V[D] + ub1;
+// returns the address of U[i0 - 1].
+__device__ __forceinline__ uint32_t merge_path_steps32(uint32_t ub1, uint32_t vd1, int n, int m, int D, int topk)
+{
+    const int lo = max(0, D - m), hi = min(D, n);
+    uint32_t posb = ub1 + 4u * (uint32_t)lo;   // address of U[pos - 1]
+    const uint32_t hib = ub1 + 4u * (uint32_t)hi;
+    for (int k = topk; k >= 1; --k) {
+        const uint32_t candb = posb + (4u << k) + 4u;   // step 2^k + 1
+        const int take = (int)(candb <= hib) & (int)(lds_load(candb) <= lds_load(vd1 - candb));
+        posb = take ? candb : posb;
+    }
+#pragma unroll
+    for (int step = 2; step >= 1; --step) {
+        const uint32_t candb = posb + 4u * (uint32_t)step;
+        const int take = (int)(candb <= hib) & (int)(lds_load(candb) <= lds_load(vd1 - candb));
+        posb = take ? candb : posb;
+    }
+    return posb;
+}
+
 // PM: 1 -> p == 1 (losses.py:311-312: no pow), 2 -> p == 2 (torch.pow(., 2) is an exact square), 0 -> powf
 template <int PM>
 __device__ __forceinline__ float transport_cost(float xa, float yb, float p)

@@ -623,7 +623,9 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             const float* const PXw = PX - c.pad;
             const int nw = n + c.pad;
             const int D0 = t * c.E;
-            const int i0 = (SOT_ABLATE & 2) ? min(D0 >> 1, nw) : merge_path_steps(Uw, V, nw, m, D0, c.topk);
+            const uint32_t ub1 = lds_addr(Uw) - 4u;  // partition search on LDS byte addresses (merge_path_steps32)
+            const int i0 = (SOT_ABLATE & 2) ? min(D0 >> 1, nw)
+                                            : (int)((merge_path_steps32(ub1, lds_addr(V) + 4u * (uint32_t)D0 + ub1, nw, m, D0, c.topk) - ub1) >> 2);
             SOT_STAMP(6);
             const int j0 = D0 - i0;
             float qprev = 0.0f;  // Q_0 := 0 (the pad of losses.py:301)
@@ -642,7 +644,8 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
                 // order: the pair of heads, hence the consumed level, its width and its cost factor, is the same, and the
                 // second member of a tie has zero width -- the sum is bit-identical to the canonical order's.
                 float w = ua, wp = xa, r = vb, rp = yb;
-                uint32_t pw = 4u * (uint32_t)i0 + 4u, pr = 4u * (uint32_t)(voff + j0) + 4u;
+                const uint32_t lb32 = lds_addr(lb);  // 32-bit LDS addresses: one VGPR per stream, no re-basing add per access
+                uint32_t pw = lb32 + 4u * (uint32_t)i0 + 4u, pr = lb32 + 4u * (uint32_t)(voff + j0) + 4u;
 #if SOT_WALK_UNROLL > 0
 #pragma unroll SOT_WALK_UNROLL
 #endif
@@ -659,8 +662,8 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
                     pw = nx + 4u;
                     r = cw ? r : w;
                     rp = cw ? rp : wp;
-                    w = *reinterpret_cast<const float*>(lb + nx);
-                    wp = *reinterpret_cast<const float*>(lb + nx + poff4);
+                    w = lds_load(nx);
+                    wp = lds_load(nx + poff4);
                 }
             } else
 #if SOT_WALK_UNROLL > 0
@@ -793,7 +796,8 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
             const float* const PXw = PX - c.pad;
             const int nw = n + c.pad;
             const int D0 = t * c.E;
-            const int i0 = merge_path_steps(Uw, V, nw, m, D0, c.topk);
+            const uint32_t ub1 = lds_addr(Uw) - 4u;
+            const int i0 = (int)((merge_path_steps32(ub1, lds_addr(V) + 4u * (uint32_t)D0 + ub1, nw, m, D0, c.topk) - ub1) >> 2);
             const int j0 = D0 - i0;
             float qprev = 0.0f;
             if (i0 > 0) qprev = Uw[i0 - 1];
