@@ -126,6 +126,33 @@ def test_full_row_kernel_matches_generic(N, B, flags, p):
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
 
 
+@pytest.mark.parametrize("N,B", [(512, 530), (2048, 200)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0)])
+def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
+    """The specialised backward kernel (rows with n == m == 512 / 2048) gives bit for bit the gradients of the generic
+    kernel, and the oracle's closed form on a sample of rows."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    x, y = gen_inputs("peaky", B, N, N, 977 + N)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.linspace(0, 1, N).to(device())
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    g = torch.linspace(0.5, 1.5, B).to(device())
+    sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g, plan=plan, grad_scale=0.25)
+    gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g, plan=plan, grad_scale=0.25)
+    assert torch.equal(sx, gx) and torch.equal(sy, gy), (float((sx - gx).abs().max()), float((sy - gy).abs().max()))
+    only_y = nat.backward_rows(x, y, pos, pos2, p, flags, g, need_gx=False, plan=plan, grad_scale=0.25)
+    assert only_y[0] is None and torch.equal(only_y[1], sy)
+    k = min(B, 6)
+    wx, wy = so.backward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(),
+                         (0.25 * g[:k]).cpu().numpy(), p=p, flags=flags & 15)
+    for got, want in ((sx[:k].cpu().numpy(), wx), (sy[:k].cpu().numpy(), wy)):
+        scale = np.abs(want).max(axis=1, keepdims=True) + 1e-30
+        assert np.max(np.abs(got - want) / scale) <= 1e-5
+
+
 def test_full_row_kernel_with_unsorted_shared_positions():
     """The specialised kernel gathers through the shared sort permutation when the positions arrive unsorted."""
     nat = native()
@@ -140,6 +167,10 @@ def test_full_row_kernel_with_unsorted_shared_positions():
         spec = nat.forward_rows(x, y, pos, pos2, p, flags)
         gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE)
         assert torch.equal(spec, gen)
+        g = torch.ones(B, device=device())
+        sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g)
+        gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g)
+        assert torch.equal(sx, gx) and torch.equal(sy, gy)
 
 
 def test_full_size_properties():
