@@ -239,8 +239,18 @@ def main():
             yv.grad = None
             cut(sets[i % 2][0], yv, x_pos=pos_x, y_pos=pos_y).backward()
 
+        cm = [cut._marshal(x, y, pos_x, pos_y, {}) for x, y in sets[:2]]
+        one = torch.ones(1, device=dev)
+
+        def fwd_bwd_cutoff_kernels(i):  # the kernels of the autograd step above through the FFI alone (no autograd bookkeeping)
+            x2, y2, xp, yp, flags, plan, _ = cm[i % 2]
+            with torch.no_grad():
+                nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(cut.p), flags, plan))
+                nat.backward_rows(x2, y2, xp, yp, float(cut.p), flags, one, need_gx=False, plan=plan, grad_scale=1.0 / B)
+
         extras["paper_cutoff_mode_forward_ms_per_step"] = timed(fwd_cutoff, n_extra)
-        extras["paper_cutoff_mode_forward_backward_ms_per_step"] = timed(fwd_bwd_cutoff, n_extra)
+        extras["paper_cutoff_mode_forward_backward_ms_per_step"] = timed(fwd_bwd_cutoff, n_extra)  # host-bound (autograd round trip)
+        extras["paper_cutoff_mode_forward_backward_kernels_ms_per_step"] = timed(fwd_bwd_cutoff_kernels, n_extra)
         del ys
     bytes_per_row = 4 * (N + N) + 4  # fwd, shared positions
     achieved = bytes_per_row * B / (kern_ms * 1e-3) / 1e9
