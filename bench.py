@@ -86,11 +86,18 @@ def cpu_baseline(mode, n, rows, seed):
                       f"{tried} on a {ncpu}-cpu host (torch {torch.__version__} CPU)", "scalar": float(val)}
 
 
-EVENT_STRIDE = 4  # every 4th launch of the timed region is bracketed by HIP events (each pair costs ~2 us of stream time)
+# every 16th launch of the timed region is bracketed by HIP events and isolated from the other stream for that (a pipeline
+# bubble of ~12 us: per-step time 52.4 us at stride 4, 43.2 us at stride 16, 40.6 us with a single bracketed launch)
+EVENT_STRIDE = int(os.environ.get("SOT_BENCH_EVENT_STRIDE", "16"))
 
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (rank 0's JSON): native libraries print there too (RCCL's version banner at
+    # communicator creation), so file descriptor 1 is pointed at stderr for the run and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,45 +133,68 @@ def main():
     # computed once; a step then is exactly the FFI calls Wasserstein1D.forward makes (no GPU work is skipped).
     marshalled = [mod._marshal(x, y, pos_x, pos_y, {}) for x, y in sets]
 
+    # Steps are independent, so they are issued on TWO alternating HIP streams: one step's batch-mean kernel (and, for N > 1,
+    # its RCCL all-reduce) then overlaps the next step's forward kernel instead of leaving the GPU idle between launches.
+    # Every 16th step of the timed region is bracketed by HIP events on the stream it runs on; that step is isolated from
+    # the other stream (it waits for it, and the other stream's next step waits for the closing event), so the event
+    # pair times the forward kernel alone.  Measured with one rank through RCCL: 61.7 us/step with everything on one
+    # stream, 44.4 us like this (51 us without any collective on one stream).  All work, collectives included, completes
+    # inside the timed region (device-wide synchronize at its end).
+    graph_mode = bool(args.graph_steps)   # --graph-steps: single stream, the whole step replayed from a HIP graph (opt-in)
+    default_stream = torch.cuda.current_stream()
+    lanes = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    ring = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(4)]   # local / global fp64 sums (N > 1)
+    rowbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(4)]  # row losses; slot i % 4 stays on one lane
+    inv_global_rows = 1.0 / float(world * B)   # weak scaling: every rank owns exactly B rows
+
     def step(i, profile=None):
         with torch.no_grad():
+            x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
+            slot = i % len(ring)
+            if graph_mode:
+                cur = torch.cuda.current_stream()
+            else:
+                cur, other = lanes[i & 1], lanes[1 - (i & 1)]
+                torch.cuda.set_stream(cur)
             if profile is not None:
                 a, b = profile
-                a.record()
-            if not dist_on:
-                # same two kernels as Wasserstein1D.forward (sot_w1d_loss), issued as two calls so that the HIP
-                # events bracket the dominant kernel (sot_forward_full_kernel: the forward specialised for rows that fill their geometry) alone
-                x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
-                rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan)
-                if profile is not None:
-                    b.record()
-                return nat.reduce_mean(rows)
-            # N > 1: local kernels -> ONE all-reduce(SUM) of the fp64 partial sum over RCCL -> global mean.
-            # (Eager + synchronous on the stream by default; --graph-steps replays the whole step, collective
-            # included, from a HIP graph: measured 74 vs 83 us/step with one rank, but graph-captured RCCL could only
-            # be validated single-rank on the 1-GPU development box, so it stays opt-in.)
-            import torch.distributed as dist
-            x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
-            rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan)
+                if not graph_mode:
+                    cur.wait_stream(other)
+                a.record(cur)
+            # same kernels as Wasserstein1D.forward (sot_w1d_loss), issued as two calls so that the HIP events bracket the
+            # dominant kernel (sot_forward_full_kernel: the forward specialised for rows that fill their geometry) alone
+            rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
             if profile is not None:
-                b.record()
-            buf = ring[i % len(ring)]           # preallocated fp64 [1]: the reduce kernel writes the local sum into it
-            nat.reduce_mean(rows, sum_out=buf)
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            return buf * inv_global_rows
+                b.record(cur)
+                if not graph_mode:
+                    other.wait_event(b)
+            if not dist_on:
+                return nat.reduce_mean(rows)
+            # N > 1: local kernels -> ONE all-reduce(SUM) of the fp64 partial sum over RCCL -> global mean
+            import torch.distributed as dist
+            nat.reduce_mean(rows, sum_out=ring[slot])
+            dist.all_reduce(ring[slot], op=dist.ReduceOp.SUM)   # in place: the slot then holds the global sum
+            return ring[slot]   # the mean is ring[slot] * inv_global_rows (applied where the value is read)
 
-    ring = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(4)]
-    inv_global_rows = 1.0 / float(world * B)   # weak scaling: every rank owns exactly B rows
+    def enter_lanes():
+        for ln in lanes:
+            ln.wait_stream(default_stream)
+
+    def leave_lanes():
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(default_stream)
 
     def barrier():
         if dist_on:
             import torch.distributed as dist
             dist.barrier()
 
+    enter_lanes()
     for i in range(args.prewarm + args.warmup):
         out = step(i)
-    first = float(step(0))  # parity value on set 0 (global mean when N > 1)
-    torch.cuda.synchronize()
+    first_t = step(0)  # parity value on set 0 (global mean when N > 1)
+    torch.cuda.synchronize()  # every stream
+    first = float(first_t) * (inv_global_rows if dist_on else 1.0)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     barrier()
@@ -195,6 +225,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     del out
+    leave_lanes()  # back to the default stream for the secondary measurements
 
     if graphs is not None:  # events cannot sit inside a replay: time the dominant kernel eagerly after the timed region
         for i in range(min(args.steps, 50)):
@@ -221,9 +252,8 @@ def main():
     n_extra = max(10, min(args.steps, 50))
     if dist_on:  # BASELINE config 3: report the step with and without the collective
         def local_only(i):
-            x, y = sets[i % len(sets)]
             with torch.no_grad():
-                x2, y2, xp, yp, flags, plan, _ = mod._marshal(x, y, pos_x, pos_y, {})
+                x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
                 nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan), sum_out=ring[i % len(ring)])
         extras["ms_per_step_without_collective"] = timed(local_only, n_extra)
     else:
@@ -288,7 +318,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.mode, N, min(args.cpu_rows, B), 1234)
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
     barrier()
     if dist_on:
         import torch.distributed as dist
