@@ -216,6 +216,7 @@ def main():
             graphs[i % len(graphs)].replay()
         else:
             out = step(i, events[i] if i % EVENT_STRIDE == 0 else None)
+    host_enqueue = time.perf_counter() - t0   # when the host is done issuing work (diagnostic: is the loop host-bound?)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -248,7 +249,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    extras = {}
+    extras = {"host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps}
     n_extra = max(10, min(args.steps, 50))
     if dist_on:  # BASELINE config 3: report the step with and without the collective
         def local_only(i):
