@@ -233,65 +233,21 @@ __device__ __forceinline__ double wave_suffix_incl_scan(double v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Merge-path partition: number of U elements among the first D merged elements, with U before V
-// on ties (the order of a stable sort of cat(U, V)).
+// Merge-path partition: i0 = number of U elements among the first D merged elements, with U before V on ties (the
+// order of a stable sort of cat(U, V)): P(i) := U[i] <= V[D-1-i] is true for i < i0 and false from i0 on.
+// Branch-free search with a fixed (wave-uniform) number of rounds and the descending steps 2^k + 1, ..., 9, 5, 3, 2, 1
+// from the lower end of the diagonal's range: a step is taken when it stays inside the range and the predicate holds
+// at its last element; any step sequence with s_k <= 1 + (sum of the later steps) finds every count up to the sum of
+// all steps.  Compared with a bisection loop: no divergent loop, 5 VALU per round instead of 12, and probes of lanes
+// whose searches have diverged by a multiple of 32 elements do not pile up in one LDS bank (steps 2^k do).  Probes
+// outside the range read neighbouring LDS and are masked by the range test.  (A 4-ary search with three probes per round
+// was slower: the search is bound by LDS reads and bank conflicts, not by its number of dependent rounds.)
 // ---------------------------------------------------------------------------------------------
-#ifndef SOT_MERGE_PATH_KARY
-#define SOT_MERGE_PATH_KARY 0
-#endif
-__device__ __forceinline__ int merge_path(const float* U, const float* V, int n, int m, int D)
-{
-    // P(i) := U[i] <= V[D-1-i] is true for i < i0 and false from i0 on; find i0 in [lo, hi].
-    // 4-ary rounds (three pivots, six independent LDS reads per round) halve the number of dependent LDS round
-    // trips of a binary search (6 instead of 12 for 2048 + 2048): the row's critical path is latency-bound.
-    int lo = max(0, D - m), hi = min(D, n);
-    while (SOT_MERGE_PATH_KARY && hi - lo >= 4) {
-        const int q = (hi - lo) >> 2;
-        const int m1 = lo + q, m2 = m1 + q, m3 = m2 + q;
-        const bool p1 = U[m1] <= V[D - 1 - m1];
-        const bool p2 = U[m2] <= V[D - 1 - m2];
-        const bool p3 = U[m3] <= V[D - 1 - m3];
-        // monotone predicate: p1 >= p2 >= p3
-        lo = p3 ? (m3 + 1) : (p2 ? (m2 + 1) : (p1 ? (m1 + 1) : lo));
-        hi = p3 ? hi : (p2 ? m3 : (p1 ? m2 : m1));
-    }
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (U[mid] <= V[D - 1 - mid]) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// Branch-free form of the same partition search for the hot kernels: a fixed (wave-uniform) number of rounds with the
-// descending steps 2^k + 1, ..., 9, 5, 3, 2, 1 from the lower end of the diagonal's range.  A step is taken when it stays
-// inside the range and the predicate holds at its last element; any step sequence with s_k <= 1 + (sum of the later
-// steps) finds every count up to the sum of all steps.  Compared with the bisection above: no divergent loop, 7 VALU per
-// round instead of 12, and probes of lanes whose searches have diverged by a multiple of 32 elements do not pile up in one
-// LDS bank (steps 2^k do).  Probes outside the range read neighbouring LDS and are masked by the range test.
-// `topk`: see merge_steps_top(); the result is identical to merge_path().
 __host__ __device__ constexpr int merge_steps_top(int range)  // reach of (2^k + 1, ..., 5, 3, 2, 1) = 2^(k+1) + k + 1
 {
     int k = 1;
     while ((2 << k) + k + 1 < range) ++k;
     return k;
-}
-__device__ __forceinline__ int merge_path_steps(const float* U, const float* V, int n, int m, int D, int topk)
-{
-    const int lo = max(0, D - m), hi = min(D, n);
-    int pos = lo;
-    const float* const vd = V + D;  // V[D - cand] = vd[-cand]
-    for (int k = topk; k >= 1; --k) {
-        const int cand = pos + (1 << k) + 1;
-        const int take = (int)(cand <= hi) & (int)(U[cand - 1] <= vd[-cand]);  // bitwise: no branch around the LDS reads
-        pos = take ? cand : pos;
-    }
-#pragma unroll
-    for (int step = 2; step >= 1; --step) {
-        const int cand = pos + step;
-        const int take = (int)(cand <= hi) & (int)(U[cand - 1] <= vd[-cand]);
-        pos = take ? cand : pos;
-    }
-    return pos;
 }
 
 // 32-bit LDS byte address of an LDS pointer, and a load from such an address (+ immediate): the merge phases keep their
@@ -300,7 +256,7 @@ typedef __attribute__((address_space(3))) const float lds_cfloat;
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 __device__ __forceinline__ float lds_load(uint32_t addr) { return *reinterpret_cast<lds_cfloat*>((uintptr_t)addr); }
 
-// merge_path_steps() on LDS byte addresses (5 VALU per round): ub1 = address of U[-1], vd1 = address of V[D] + ub1;
+// The search on LDS byte addresses: ub1 = address of U[-1], vd1 = address of V[D] + ub1, topk = merge_steps_top(min(n, m));
 // returns the address of U[i0 - 1].
 __device__ __forceinline__ uint32_t merge_path_steps32(uint32_t ub1, uint32_t vd1, int n, int m, int D, int topk)
 {

@@ -40,29 +40,11 @@
 #define SOT_MASS_PRIO 2
 #endif
 // tuning knobs of the A/B harness (tools/ab_probe.py); the defaults are the measured best
-#ifndef SOT_SCAN_PRIO
-#define SOT_SCAN_PRIO 0
-#endif
 #ifndef SOT_E_MODE
 #define SOT_E_MODE 0   /* 0: ceil(K/G) forced odd (58.45 us with walk unroll 2); 1: plain (59.2); 2: even with odd half */
 #endif
 #ifndef SOT_WALK_UNROLL
 #define SOT_WALK_UNROLL 2  /* 0: compiler's choice (x4): 59.45 us; 1: 59.95; 2: 58.85 */
-#endif
-#ifndef SOT_POS_BATCH
-#define SOT_POS_BATCH 1
-#endif
-#ifndef SOT_LDS_SKEW
-#define SOT_LDS_SKEW 0   /* 4 / 8 / 16: no effect (the regions are already 24 floats off a bank period) */
-#endif
-#ifndef SOT_ONE_TRIP
-#define SOT_ONE_TRIP 0
-#endif
-#ifndef SOT_POFF_ALIGN
-#define SOT_POFF_ALIGN 1   /* 64: a level and its position are 64-dword multiples apart (one ds_read2st64_b32 fetches both) */
-#endif
-#ifndef SOT_LDS_SKEW2
-#define SOT_LDS_SKEW2 0
 #endif
 
 namespace sot {
@@ -102,13 +84,13 @@ __host__ __device__ constexpr RowLayout make_layout(int n, int m, int G, bool ro
     // The U and PX regions start with `padcap` spare floats: the forward walk prepends pad < E zero-valued
     // levels to U (zero width => zero contribution) so that every thread walks exactly E merged elements.
     L.padcap = align4(merge_steps(n + m, G));
-    L.nU = L.padcap + align4(n + 1) + SOT_LDS_SKEW;  // skew: keeps U[i] and V[i] (and PX / PY) off the same LDS banks
-    L.nV = align4(m + 1) + SOT_LDS_SKEW2;
+    L.nU = L.padcap + align4(n + 1);
+    L.nV = align4(m + 1);
     if (rowpos) {  // per-row position sort needs power-of-two scratch for the bitonic network
         L.nU = imax(L.nU, L.padcap + next_pow2(n));
         L.nV = imax(L.nV, next_pow2(m));
     }
-    L.poff = (L.nU + L.nV + SOT_POFF_ALIGN - 1) / SOT_POFF_ALIGN * SOT_POFF_ALIGN;
+    L.poff = L.nU + L.nV;
     const int nchx = (((n >= 8) ? (n >> 5) : 0) + 15) >> 4;
     const int nchy = (((m >= 8) ? (m >> 5) : 0) + 15) >> 4;
     L.part_x = 2 * L.poff;
@@ -198,7 +180,6 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
     c.x_ident = true; c.y_ident = true;
     if (!ROWPOS) {
         if (a.ident != nullptr) { c.x_ident = a.ident[0] != 0; c.y_ident = a.ident[1] != 0; }
-#if SOT_POS_BATCH
         // issue every position load before the first LDS store (independent loads: one memory round trip, not one per
         // element), in batches of 8 per array so that any row length is covered
         for (int e0 = 0; e0 < max(c.n, c.m); e0 += 8 * G) {
@@ -216,10 +197,6 @@ __device__ __forceinline__ RowCtx<G> make_ctx(const FwdArgs& a, float* smem, boo
                 if (e < c.m) c.PY[e] = py[k];
             }
         }
-#else
-        for (int e = c.t; e < c.n; e += G) c.PX[e] = a.xpos[e];
-        for (int e = c.t; e < c.m; e += G) c.PY[e] = a.ypos[e];
-#endif
         for (int e = c.t; e < c.pad; e += G) c.PX[e - c.pad] = a.xpos[0];  // any finite value: the width is 0
         if (c.t == 0) {
             c.PX[c.n] = a.xpos[c.n - 1];  // clamp of losses.py:220: ranks beyond the last index reuse it
@@ -402,7 +379,6 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
 
     // ---- P3: safe_divide (utils.py:135-142), weight gather by the position sort (losses.py:289-290)
     //      and fp64-accumulated CDFs (losses.py:292-293) --------------------------------------------
-    __builtin_amdgcn_s_setprio(SOT_SCAN_PRIO);
     const float Sxh = guard_mass(Sx);
     const float Syh = guard_mass(Sy);
     const bool x_perm = ROWPOS ? c.do_sort : !c.x_ident;
@@ -480,18 +456,8 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     SOT_STAMP(4);
     __syncthreads();  // every raw weight has been read (also through permutations) before U/V are rewritten
     if (NW > 1) {
-#if SOT_ONE_TRIP
-        // all wave totals are fetched in one LDS round trip (independent reads) and summed in wave order
-        double tx[NW], ty[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { tx[w] = c.wtot[w]; ty[w] = c.wtot[NW + w]; }
-        double ox = 0.0, oy = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { ox += (w < c.wv) ? tx[w] : 0.0; oy += (w < c.wv) ? ty[w] : 0.0; }
-#else
         double ox = 0.0, oy = 0.0;
         for (int w = 0; w < c.wv; ++w) { ox += c.wtot[w]; oy += c.wtot[NW + w]; }
-#endif
         exx += ox;
         exy += oy;
     }

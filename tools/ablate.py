@@ -11,7 +11,7 @@ if sys.argv[1] == "build":
     from concurrent.futures import ThreadPoolExecutor
     def one(v):
         out = os.path.join(LIBDIR, f"libsot_ablate_{v}.so")
-        subprocess.run([sot_amd.build.hipcc_path(), *sot_amd.build.HIPCC_FLAGS, "-shared", f"-DSOT_ABLATE={v}", "-DSOT_PART=17", "-DSOT_STUB_MISSING_PARTS", "-o", out,
+        subprocess.run([sot_amd.build.hipcc_path(), *sot_amd.build.HIPCC_FLAGS, "-shared", f"-DSOT_ABLATE={v}", "-DSOT_PART=145", "-DSOT_STUB_MISSING_PARTS", "-o", out,
                         sot_amd.build.SRC], check=True)
         return out
     with ThreadPoolExecutor(4) as ex:
