@@ -153,6 +153,30 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
         assert np.max(np.abs(got - want) / scale) <= 1e-5
 
 
+@pytest.mark.parametrize("N,B", [(2048, 1), (2048, 3), (512, 5), (8192, 2)])
+def test_full_row_kernels_strided_rows_and_tiny_batches(N, B):
+    """Row strides larger than the row length, batches smaller than a workgroup's row count, broadcast upstream gradient."""
+    from oracle.inputs import gen_inputs
+    nat = native()
+    x, y = gen_inputs("uniform", B, N, N, 31 + B)
+    pad = 64
+    xs = torch.zeros(B, N + pad, device=device())
+    ys = torch.zeros(B, N + pad, device=device())
+    xs[:, :N] = x.to(device()); ys[:, :N] = y.to(device())
+    xv, yv = xs[:, :N], ys[:, :N]          # non-contiguous views: row stride N + 64
+    pos = torch.linspace(0, 1, N).to(device()); pos2 = pos.clone()
+    for flags, p in [(0, 1.0), (1 | 2 | 4, 2.0)]:
+        pr_spec = nat.forward_rows(xv, yv, pos, pos2, p, flags)
+        pr_gen = nat.forward_rows(xv, yv, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE)
+        pr_contig = nat.forward_rows(xv.contiguous(), yv.contiguous(), pos, pos2, p, flags)
+        assert torch.equal(pr_spec, pr_gen) and torch.equal(pr_spec, pr_contig)
+        if N <= 2048:
+            one = torch.ones(1, device=device())
+            sx, sy = nat.backward_rows(xv, yv, pos, pos2, p, flags, one, grad_scale=1.0 / B)
+            gx, gy = nat.backward_rows(xv, yv, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, one, grad_scale=1.0 / B)
+            assert torch.equal(sx, gx) and torch.equal(sy, gy)
+
+
 def test_full_row_kernel_with_unsorted_shared_positions():
     """The specialised kernel gathers through the shared sort permutation when the positions arrive unsorted."""
     nat = native()
