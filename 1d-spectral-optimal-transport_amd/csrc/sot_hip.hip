@@ -1032,6 +1032,7 @@ hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs
                              hipStream_t s);
 hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
 hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, hipStream_t s);
+bool forward_full_supports(int n, bool aligned16);
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                    hipStream_t s);
 int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
@@ -1060,6 +1061,7 @@ template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, cons
 #if !(SOT_PART & 128)
 hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+bool forward_full_supports(int, bool) { return false; }
 #endif
 #if !(SOT_PART & 32)
 int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const float*, const float*, const int64_t*, int64_t, int64_t, int,
@@ -1404,9 +1406,8 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
     if (pr->B == 0) return SOT_OK;
     l.a.row_loss = row_loss;
     l.a.oUq = uq; l.a.oVq = vq; l.a.oQ = Q; l.a.oU = U; l.a.oV = V;
-    // rows that fill their geometry exactly (512, 2048 or 8192 bins) take the fully specialised kernel
-    bool full = !l.rowpos && !quant && l.vec && (l.pm == 1 || l.pm == 2) && pr->n == pr->m &&
-                (int64_t)l.cfg.G * l.cfg.CPT == pr->n && (pr->n % 512) == 0 && l.cfg.CPT == 8 &&
+    // row lengths with a compile-time kernel (512 / 2048 / 8192 bins, and the paper's 257 / 513 / 1025) take it
+    bool full = !l.rowpos && !quant && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && forward_full_supports(pr->n, l.vec) &&
                 !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;

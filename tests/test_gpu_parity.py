@@ -153,6 +153,47 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
         assert np.max(np.abs(got - want) / scale) <= 1e-5
 
 
+@pytest.mark.parametrize("N,B", [(257, 1031), (513, 300), (1025, 261)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 2 | 4 | 8, 2.0), (2, 2.0)])
+@pytest.mark.parametrize("kind", ["peaky", "uniform"])
+def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
+    """n_fft 512 / 1024 / 2048 -> 257 / 513 / 1025 bins run a forward kernel with the row length at compile time (other
+    thread geometry than the generic kernel: same arithmetic per element, different association of the final sum): it
+    must agree with the generic kernel to a few ulp and with the oracle; rows start at arbitrary alignments."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    x, y = gen_inputs(kind, B, N, N, 55 + N)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.fft.rfftfreq(2 * (N - 1), 1 / 16000.0)
+    pos = (pos / pos.max()).float().to(device())
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
+    gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
+    torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
+    k = min(B, 40)
+    want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
+    np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
+
+
+def test_paper_row_lengths_unsorted_positions_and_strides():
+    nat = native()
+    from oracle.inputs import gen_inputs
+    for N, B in ((257, 9), (1025, 5)):
+        x, y = gen_inputs("uniform", B, N, N, 7 + N)
+        xs = torch.zeros(B, N + 3, device=device()); ys = torch.zeros(B, N + 3, device=device())
+        xs[:, :N] = x.to(device()); ys[:, :N] = y.to(device())
+        xv, yv = xs[:, :N], ys[:, :N]
+        g = torch.Generator().manual_seed(N)
+        pos = torch.linspace(0, 1, N)[torch.randperm(N, generator=g)].to(device())
+        pos2 = torch.linspace(0, 3, N)[torch.randperm(N, generator=g)].to(device())
+        for flags, p in [(8, 1.0), (1 | 2 | 4 | 8, 2.0)]:
+            spec = nat.forward_rows(xv, yv, pos, pos2, p, flags)
+            gen = nat.forward_rows(xv, yv, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE)
+            torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("N,B", [(2048, 1), (2048, 3), (512, 5), (8192, 2)])
 def test_full_row_kernels_strided_rows_and_tiny_batches(N, B):
     """Row strides larger than the row length, batches smaller than a workgroup's row count, broadcast upstream gradient."""
