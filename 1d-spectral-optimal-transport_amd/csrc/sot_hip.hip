@@ -1033,6 +1033,7 @@ hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs
 hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
 hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, hipStream_t s);
 bool forward_full_supports(int n, bool aligned16);
+bool backward_full_supports(int n, bool aligned16);
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                    hipStream_t s);
 int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
@@ -1062,6 +1063,7 @@ template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, cons
 hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 bool forward_full_supports(int, bool) { return false; }
+bool backward_full_supports(int, bool) { return false; }
 #endif
 #if !(SOT_PART & 32)
 int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const float*, const float*, const int64_t*, int64_t, int64_t, int,
@@ -1428,10 +1430,11 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
     if (grad_row == nullptr) return SOT_ERR_NULL_POINTER;
     BwdArgs b{};
     b.f = l.a; b.grad_row = grad_row; b.grad_row_stride = grad_row_stride; b.grad_scale = grad_scale; b.gx = gx; b.gy = gy;
-    // rows that fill their geometry exactly (512 or 2048 bins) take the fully specialised kernel (as in run_forward)
-    bool full = !l.rowpos && l.vec && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && (int64_t)l.cfg.G * l.cfg.CPT == pr->n &&
-                (pr->n == 512 || pr->n == 2048) && !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE)) &&
-                (gx == nullptr || (reinterpret_cast<uintptr_t>(gx) & 15) == 0) && (gy == nullptr || (reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+    // row lengths with a compile-time kernel take it (as in run_forward)
+    const bool aligned16 = l.vec && (gx == nullptr || (reinterpret_cast<uintptr_t>(gx) & 15) == 0) &&
+                           (gy == nullptr || (reinterpret_cast<uintptr_t>(gy) & 15) == 0);
+    bool full = !l.rowpos && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && backward_full_supports(pr->n, aligned16) &&
+                !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;
 #endif

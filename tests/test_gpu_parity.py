@@ -177,6 +177,33 @@ def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
 
 
+@pytest.mark.parametrize("N,B", [(257, 70), (513, 37), (1025, 29)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1 | 2 | 4, 2.0), (1 | 4 | 8, 2.0), (2, 1.0)])
+def test_paper_row_lengths_backward(N, B, flags, p):
+    """Backward kernel with the row length at compile time (257 / 513 / 1025 bins): gradients equal to the generic kernel's
+    (same closed form; the fp64 suffix sums are associated differently) and to the oracle's."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    x, y = gen_inputs("peaky", B, N, N, 311 + N)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.linspace(0, 1, N).to(device()); pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    g = torch.linspace(0.5, 1.5, B).to(device())
+    sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g, plan=plan, grad_scale=0.5)
+    gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g, plan=plan, grad_scale=0.5)
+    k = min(B, 8)
+    wx, wy = so.backward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(),
+                         (0.5 * g[:k]).cpu().numpy(), p=p, flags=flags & 15)
+    for got, ref, want in ((sx, gx, wx), (sy, gy, wy)):
+        scale = ref.abs().amax(dim=1, keepdim=True) + 1e-30
+        assert float(((got - ref).abs() / scale).max()) <= 2e-6
+        wscale = np.abs(want).max(axis=1, keepdims=True) + 1e-30
+        assert np.max(np.abs(got[:k].cpu().numpy() - want) / wscale) <= 1e-5
+    only_y = nat.backward_rows(x, y, pos, pos2, p, flags, g, need_gx=False, plan=plan, grad_scale=0.5)
+    assert only_y[0] is None and torch.equal(only_y[1], sy)
+
+
 def test_paper_row_lengths_unsorted_positions_and_strides():
     nat = native()
     from oracle.inputs import gen_inputs
@@ -192,6 +219,12 @@ def test_paper_row_lengths_unsorted_positions_and_strides():
             spec = nat.forward_rows(xv, yv, pos, pos2, p, flags)
             gen = nat.forward_rows(xv, yv, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE)
             torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
+            one = torch.ones(1, device=device())
+            sx, sy = nat.backward_rows(xv, yv, pos, pos2, p, flags, one, grad_scale=1.0 / B)
+            gx, gy = nat.backward_rows(xv, yv, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, one, grad_scale=1.0 / B)
+            for got, ref in ((sx, gx), (sy, gy)):
+                scale = ref.abs().amax(dim=1, keepdim=True) + 1e-30
+                assert float(((got - ref).abs() / scale).max()) <= 2e-6
 
 
 @pytest.mark.parametrize("N,B", [(2048, 1), (2048, 3), (512, 5), (8192, 2)])
