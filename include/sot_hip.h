@@ -47,9 +47,10 @@ typedef enum sot_status {
 #define SOT_FLAG_PRENORMALIZED 16u /* weights are used as given: the functional wasserstein_1d(u_values,
                                       v_values, u_weights, v_weights) of losses.py:223, which does not
                                       normalise (flags SQUARE / DONT_NORMALIZE are then ignored)       */
-#define SOT_FLAG_NO_SPECIALIZE 32u /* diagnostic: always run the generic forward kernel, never the variants
-                                      specialised for rows that fill their launch geometry exactly (results
-                                      are bit-identical either way; the tests compare the two)               */
+#define SOT_FLAG_NO_SPECIALIZE 32u /* diagnostic: always run the generic kernels, never the variants with the row
+                                      length at compile time (257/512/513/1025/2048/8192 bins).  Results are
+                                      bit-identical for 512/2048/8192 and agree to the last bits otherwise;
+                                      the tests compare the two                                              */
 
 /* One batch of spectrum pairs.  Mirrors the arguments of Wasserstein1D.forward
  * (losses.py:129) after its [batch,time,N] -> [B,N] reshape (losses.py:157-170). */

@@ -12,7 +12,7 @@ import sot_amd, torch
 sot_amd.build.LIB = {ROOT!r} + '/tools/ablate_libs/' + {name!r} + '.so'
 from sot_amd import _native as nat
 nat.load(build_if_missing=False)
-dev = torch.device('cuda:0'); B, N = 8192, 2048
+dev = torch.device('cuda:0'); B, N = {int(os.environ.get('AB_B', '8192'))}, {int(os.environ.get('AB_N', '2048'))}
 g = torch.Generator(device=dev).manual_seed(0)
 sets = [(torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)) for _ in range(6)]
 pos = torch.linspace(0, 1, N, device=dev); pos2 = pos.clone()
