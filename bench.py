@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--sets", type=int, default=6, help="distinct rotating input sets (>= 4 defeats the 256 MiB L3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-steps", action="store_true", help="replay each step from a HIP graph (opt-in)")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
+                    help="HIP streams the steps alternate over: 1 = one stream; 2 = the mean kernel / all-reduce of a step "
+                         "overlaps the next step's forward kernel; 0 (default) = 1 on one GPU (per-kernel times then agree "
+                         "with rocprofv3), 2 when there is a collective to hide (N > 1)")
     ap.add_argument("--cpu-rows", type=int, default=2048)
     return ap.parse_args()
 
@@ -86,9 +90,11 @@ def cpu_baseline(mode, n, rows, seed):
                       f"{tried} on a {ncpu}-cpu host (torch {torch.__version__} CPU)", "scalar": float(val)}
 
 
-# every 16th launch of the timed region is bracketed by HIP events and isolated from the other stream for that (a pipeline
-# bubble of ~12 us: per-step time 52.4 us at stride 4, 43.2 us at stride 16, 40.6 us with a single bracketed launch)
-EVENT_STRIDE = int(os.environ.get("SOT_BENCH_EVENT_STRIDE", "16"))
+# Launches of the timed region that are bracketed by HIP events: every 4th with one stream (an event pair costs ~2 us of
+# stream time), every 16th with two alternating streams (the bracketed launch is isolated from the other stream: a pipeline
+# bubble of ~12 us; per-step time 52.4 us at stride 4, 43.2 us at stride 16).
+def event_stride(n_lanes):
+    return int(os.environ.get("SOT_BENCH_EVENT_STRIDE", "4" if n_lanes == 1 else "16"))
 
 
 def main():
@@ -133,14 +139,20 @@ def main():
     # computed once; a step then is exactly the FFI calls Wasserstein1D.forward makes (no GPU work is skipped).
     marshalled = [mod._marshal(x, y, pos_x, pos_y, {}) for x, y in sets]
 
-    # Steps are independent, so they are issued on TWO alternating HIP streams: one step's batch-mean kernel (and, for N > 1,
-    # its RCCL all-reduce) then overlaps the next step's forward kernel instead of leaving the GPU idle between launches.
-    # Every 16th step of the timed region is bracketed by HIP events on the stream it runs on; that step is isolated from
-    # the other stream (it waits for it, and the other stream's next step waits for the closing event), so the event
-    # pair times the forward kernel alone.  Measured with one rank through RCCL: 61.7 us/step with everything on one
-    # stream, 44.4 us like this (51 us without any collective on one stream).  All work, collectives included, completes
-    # inside the timed region (device-wide synchronize at its end).
+    # Steps are independent.  With N > 1 (or --lanes 2) they are issued on TWO alternating HIP streams: one step's batch-mean
+    # kernel and its RCCL all-reduce then overlap the next step's forward kernel instead of leaving the GPU idle for the
+    # collective's latency.  Every 16th step of the timed region is then bracketed by HIP events on the stream it runs on and
+    # isolated from the other stream (it waits for it, and the other stream's next step waits for the closing event), so the
+    # event pair times the forward kernel alone.  Measured with one rank through RCCL: 61.7 us/step with everything on one
+    # stream, 44-47 us like this.  All work, collectives included, completes inside the timed region (device-wide
+    # synchronize at its end).  On one GPU the default is ONE stream: consecutive forward kernels then never share the GPU
+    # and rocprofv3's per-kernel durations agree with the event-bracketed ones (--lanes 2 on one GPU: 42.9 instead of
+    # 48.5 us per step, 191 instead of 169 M rows/s, but overlapped kernel durations in a profile).
     graph_mode = bool(args.graph_steps)   # --graph-steps: single stream, the whole step replayed from a HIP graph (opt-in)
+    n_lanes = args.lanes if args.lanes else (2 if dist_on else 1)
+    if graph_mode:
+        n_lanes = 1
+    EVENT_STRIDE = event_stride(n_lanes)
     default_stream = torch.cuda.current_stream()
     lanes = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     ring = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(4)]   # local / global fp64 sums (N > 1)
@@ -151,14 +163,14 @@ def main():
         with torch.no_grad():
             x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
             slot = i % len(ring)
-            if graph_mode:
+            if n_lanes == 1:
                 cur = torch.cuda.current_stream()
             else:
                 cur, other = lanes[i & 1], lanes[1 - (i & 1)]
                 torch.cuda.set_stream(cur)
             if profile is not None:
                 a, b = profile
-                if not graph_mode:
+                if n_lanes == 2:
                     cur.wait_stream(other)
                 a.record(cur)
             # same kernels as Wasserstein1D.forward (sot_w1d_loss), issued as two calls so that the HIP events bracket the
@@ -166,7 +178,7 @@ def main():
             rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
             if profile is not None:
                 b.record(cur)
-                if not graph_mode:
+                if n_lanes == 2:
                     other.wait_event(b)
             if not dist_on:
                 return nat.reduce_mean(rows)
@@ -310,6 +322,7 @@ def main():
                                    f"({json.dumps(MODES[args.mode])}), shared linspace positions, {len(sets)} rotating input sets "
                                    f"({len(sets) * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",
                        "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "prewarm_steps": args.prewarm, "global_rows": world * B,
+                       "streams": n_lanes,
                        "collective": "none" if not dist_on else "one RCCL all-reduce(SUM) of the fp64 partial sum per step" + (" (HIP-graph replay)" if args.graph_steps else ""),
                        "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

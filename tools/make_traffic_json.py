@@ -9,7 +9,7 @@ import os
 import sys
 
 prof_dir, workload, out = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "sot_forward_full_kernel<256, 8, 1, 1, false, false>"  # the bench workload's variant
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "sot_forward_full_kernel<256, 8, 1, 1, false, false, 0>"  # the bench workload's variant
 
 
 def mean_counter(sub, counter, kernel_substr):
