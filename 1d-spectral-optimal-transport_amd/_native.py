@@ -52,6 +52,11 @@ EXPORTS = {
     "sot_w1d_forward_csr": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_uint32, _vp, _vp]),
     "sot_segmented_sort": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
+    "sot_stft_frames": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
+    "sot_stft_mag_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
+                                            _vp, _vp]),
+    "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
+                                             _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -332,3 +337,37 @@ def segmented_sort(keys: torch.Tensor):
         check(lib.sot_segmented_sort(keys.data_ptr(), B, n, keys.stride(0) if B > 1 else n, vals.data_ptr(),
                                      idx.data_ptr(), stream_ptr(keys.device)))
     return vals, idx
+
+
+def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
+    """[batch, samples] fp32 on the GPU -> [batch, frames, n_fft/2+1] magnitudes (sot_stft_mag_forward)."""
+    require_hip(audio, window)
+    lib = load()
+    if audio.ndim != 2 or window.numel() != n_fft:
+        raise RuntimeError("stft_mag_forward expects audio [batch, samples] and a window of n_fft samples")
+    if audio.stride(1) != 1:
+        audio = audio.contiguous()
+    window = window.contiguous()
+    batch, samples = audio.shape
+    frames = int(lib.sot_stft_frames(samples, hop))
+    mag = torch.empty(batch, frames, n_fft // 2 + 1, dtype=torch.float32, device=audio.device)
+    with _on_device(audio.device):
+        check(lib.sot_stft_mag_forward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
+                                       int(n_fft), int(hop), mag.data_ptr(), stream_ptr(audio.device)))
+    return mag
+
+
+def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, grad_mag: torch.Tensor) -> torch.Tensor:
+    """dL/d(audio) [batch, samples] from dL/d(mag) [batch, frames, n_fft/2+1] (sot_stft_mag_backward)."""
+    require_hip(audio, window, grad_mag)
+    lib = load()
+    if audio.stride(1) != 1:
+        audio = audio.contiguous()
+    window = window.contiguous()
+    grad_mag = grad_mag.contiguous()
+    batch, samples = audio.shape
+    grad_audio = torch.empty(batch, samples, dtype=torch.float32, device=audio.device)
+    with _on_device(audio.device):
+        check(lib.sot_stft_mag_backward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
+                                        int(n_fft), int(hop), grad_mag.data_ptr(), grad_audio.data_ptr(), stream_ptr(audio.device)))
+    return grad_audio

@@ -11,7 +11,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "sot_hip.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
+STFT_SRC = os.path.join(PKG_DIR, "csrc", "sot_stft.hip")   # the STFT-magnitude producer: its own translation unit
+DEPS = [SRC, STFT_SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")]
 LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 
@@ -40,9 +41,13 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def _compile_part(part: int, extra_flags, verbose: bool) -> str:
-    obj = os.path.join(OBJ_DIR, f"sot_part{part}.o")
-    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-DSOT_PART={part}", "-c", "-o", obj, SRC]
+def _compile_part(part, extra_flags, verbose: bool) -> str:
+    if part == "stft":
+        obj = os.path.join(OBJ_DIR, "sot_stft.o")
+        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, STFT_SRC]
+    else:
+        obj = os.path.join(OBJ_DIR, f"sot_part{part}.o")
+        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-DSOT_PART={part}", "-c", "-o", obj, SRC]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -60,7 +65,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     os.makedirs(OBJ_DIR, exist_ok=True)
     workers = max(1, min(len(PARTS), (os.cpu_count() or 2)))
     with ThreadPoolExecutor(max_workers=workers) as pool:
-        objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose), PARTS))
+        objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose), (*PARTS, "stft")))
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd))

@@ -1,8 +1,11 @@
 """Producers of the hot path's inputs for BASELINE config 5 (the training-step slice): a harmonic batch
 generator and the magnitude STFT that `trainer.py:199-200` applies before the loss.
 
-This is host-side PLUMBING on torch ops (torch.stft -> rocFFT), not part of the hand-written HIP path: SURVEY
-§8(f) lists the STFT producer as the *next* row to fuse.  It mirrors, without copying, the behaviour of
+The magnitude STFT runs hand-written HIP kernels on the GPU (`csrc/sot_stft.hip` behind
+`sot_stft_mag_forward` / `sot_stft_mag_backward`: in-LDS FFT per frame, closed-form backward with an in-LDS
+overlap-add per clip); `stft_magnitude_torch` is the same transform on torch ops (torch.stft -> rocFFT / pocketfft),
+kept for CPU tensors, for transform sizes the kernels do not cover and as a cross-check.  The harmonic generator is
+torch plumbing.  Mirrors, without copying, the behaviour of
   * features.TorchSTFT / compute_mag / stft (features.py:85-113, 191-237): window from scipy.signal.get_window,
     `normalized=True`, `center=False`, end-padding so that every sample is covered (utils.pad_for_stft,
     utils.py:252-275), magnitude, output [batch, frames, bins];
@@ -29,8 +32,53 @@ def analysis_window(name, n_fft: int, device) -> torch.Tensor:
     return torch.as_tensor(get_window(name, n_fft), dtype=torch.float32, device=device)
 
 
+_WINDOWS = {}
+
+
+def _cached_window(name, n_fft: int, device) -> torch.Tensor:
+    key = (str(name), int(n_fft), str(device))
+    w = _WINDOWS.get(key)
+    if w is None:
+        w = _WINDOWS[key] = analysis_window(name, n_fft, device)
+    return w
+
+
+class _StftMagnitude(torch.autograd.Function):
+    """sot_stft_mag_forward / sot_stft_mag_backward (include/sot_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, audio, window, n_fft, hop):
+        from . import _native as nat
+        audio = audio.contiguous()
+        ctx.save_for_backward(audio, window)
+        ctx.n_fft, ctx.hop = n_fft, hop
+        return nat.stft_mag_forward(audio, window, n_fft, hop)
+
+    @staticmethod
+    def backward(ctx, grad_mag):
+        from . import _native as nat
+        audio, window = ctx.saved_tensors
+        grad_audio = nat.stft_mag_backward(audio, window, ctx.n_fft, ctx.hop, grad_mag.float()) if ctx.needs_input_grad[0] else None
+        return grad_audio, None, None, None
+
+
+def hip_stft_supported(n_fft: int, hop: int, samples: int) -> bool:
+    """Sizes the HIP kernels cover: n_fft a power of two in [64, 2048]; for the backward the end-padded clip must fit LDS."""
+    frames = -(-samples // hop)
+    return 64 <= n_fft <= 2048 and (n_fft & (n_fft - 1)) == 0 and n_fft + hop * (frames - 1) <= 8192
+
+
 def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop") -> torch.Tensor:
-    """[batch, samples] -> contiguous [batch, frames, n_fft/2+1] magnitudes, as the reference's TorchSTFT."""
+    """[batch, samples] -> contiguous [batch, frames, n_fft/2+1] magnitudes, as the reference's TorchSTFT
+    (features.py:85-113).  GPU tensors run the HIP kernels (differentiable w.r.t. the audio); CPU tensors and sizes
+    outside hip_stft_supported() run torch.stft."""
+    if audio.is_cuda and audio.ndim == 2 and hip_stft_supported(n_fft, hop, audio.shape[1]):
+        return _StftMagnitude.apply(audio.float(), _cached_window(window, n_fft, audio.device), int(n_fft), int(hop))
+    return stft_magnitude_torch(audio, n_fft, hop, window)
+
+
+def stft_magnitude_torch(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop") -> torch.Tensor:
+    """The same transform on torch ops (torch.stft)."""
     audio = end_padded(audio.float(), n_fft, hop)
     spec = torch.stft(audio, n_fft=n_fft, hop_length=hop, win_length=n_fft, window=analysis_window(window, n_fft, audio.device),
                       center=False, normalized=True, return_complex=True)

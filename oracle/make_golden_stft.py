@@ -1,0 +1,53 @@
+"""oracle/make_golden_stft.py -- fixtures for the STFT-magnitude producer, generated FROM THE REFERENCE.
+
+Runs only in the build container (imports /root/reference behind the shim of oracle/make_golden.py).  For seeded harmonic
+clips it stores what the reference's `features.TorchSTFT` (features.py:85-113 -> compute_mag -> stft, :191-237;
+utils.pad_for_stft, utils.py:252-275) returns, the scalar of the paper-cutoff SOT loss on those spectra, and the gradient
+of that scalar with respect to the ESTIMATE's audio (through torch.stft's autograd): tests/golden/stft_chain.npz.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_stft.py
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle.make_golden import import_reference, MODES, OUT  # noqa: E402
+from oracle.inputs import harmonic_audio_pair  # noqa: E402
+
+
+def main():
+    losses, features, _ = import_reference()
+    out = {}
+    # (n_fft, hop, samples): the paper's SOT-2048 and SOT-512 analysis settings, plus a clip whose length is not a
+    # multiple of the hop (end padding) and is shorter than two frames
+    for tag, n_fft, hop, n_samples, nb in (("a", 2048, 256, 4096, 2), ("b", 512, 128, 4096, 2), ("c", 1024, 256, 1000, 3)):
+        ax, ay = harmonic_audio_pair(nb=nb, seed=100 + n_fft, n_samples=n_samples)
+        tfm = features.get_transform({"type": "stft", "n_fft": n_fft, "hop_length": hop, "window": "flattop"}, 16000)
+        ay_g = ay.clone().requires_grad_(True)
+        sx, sy = tfm(ax), tfm(ay_g)
+        pos = tfm.get_frequencies()
+        pos = (pos / pos.max()).float()
+        mod = losses.Wasserstein1D(**MODES["cutoff"])
+        loss = mod(sx, sy, x_pos=pos, y_pos=pos.clone())
+        (g_audio,) = torch.autograd.grad(loss, [ay_g])
+        # plain sum of the magnitudes: a second, loss-independent pin of the STFT's own backward
+        ay_h = ay.clone().requires_grad_(True)
+        (g_sum,) = torch.autograd.grad(tfm(ay_h).sum(), [ay_h])
+        out.update({f"{tag}_n_fft": np.int64(n_fft), f"{tag}_hop": np.int64(hop), f"{tag}_audio_x": ax.numpy(),
+                    f"{tag}_audio_y": ay.numpy(), f"{tag}_spec_x": sx.detach().contiguous().numpy(),
+                    f"{tag}_spec_y": sy.detach().contiguous().numpy(), f"{tag}_pos": pos.numpy(),
+                    f"{tag}_loss": loss.detach().numpy(), f"{tag}_grad_audio_y": g_audio.numpy(),
+                    f"{tag}_grad_sum_mag": g_sum.numpy()})
+        print(tag, n_fft, hop, n_samples, tuple(sx.shape), float(loss))
+    np.savez_compressed(os.path.join(OUT, "stft_chain.npz"), **out)
+    print("wrote", os.path.join(OUT, "stft_chain.npz"), os.path.getsize(os.path.join(OUT, "stft_chain.npz")) / 1e6, "MB")
+
+
+if __name__ == "__main__":
+    main()

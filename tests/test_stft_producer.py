@@ -1,0 +1,134 @@
+"""The STFT-magnitude producer in front of the loss: oracle vs the reference's TorchSTFT fixtures on the
+CPU, HIP kernels vs fixtures / oracle / torch.stft on the GPU (forward, backward, and the chain into the SOT loss)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+TAGS = ["a", "b", "c"]   # (n_fft, hop, samples) = (2048, 256, 4096), (512, 128, 4096), (1024, 256, 1000): oracle/make_golden_stft.py
+
+
+def _fx():
+    return dict(np.load(os.path.join(GOLDEN, "stft_chain.npz")))
+
+
+def _window(n_fft):
+    from scipy.signal import get_window
+    return get_window("flattop", n_fft).astype(np.float32)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_numpy_oracle_matches_reference_torchstft(tag):
+    from oracle import sot_oracle as so
+    fx = _fx()
+    n_fft, hop = int(fx[f"{tag}_n_fft"]), int(fx[f"{tag}_hop"])
+    for which in ("x", "y"):
+        got = so.stft_magnitude_np(fx[f"{tag}_audio_{which}"], _window(n_fft), n_fft, hop)
+        want = fx[f"{tag}_spec_{which}"]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()   # the reference computes in fp32
+
+
+def test_cpu_tensors_use_the_torch_transform():
+    from sot_amd import spectra
+    fx = _fx()
+    got = spectra.stft_magnitude(torch.as_tensor(fx["c_audio_x"]), 1024, 256)
+    assert np.abs(got.numpy() - fx["c_spec_x"]).max() <= 2e-6 * np.abs(fx["c_spec_x"]).max()
+    assert spectra.hip_stft_supported(2048, 256, 4096) and not spectra.hip_stft_supported(4096, 256, 4096)
+    assert not spectra.hip_stft_supported(1000, 250, 4096) and not spectra.hip_stft_supported(2048, 256, 16000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_hip_stft_forward_matches_reference_and_oracle(tag):
+    from gpu_util import device, native
+    from oracle import sot_oracle as so
+    from sot_amd import spectra
+    nat = native()
+    fx = _fx()
+    n_fft, hop = int(fx[f"{tag}_n_fft"]), int(fx[f"{tag}_hop"])
+    win = torch.as_tensor(_window(n_fft)).to(device())
+    for which in ("x", "y"):
+        audio = torch.as_tensor(fx[f"{tag}_audio_{which}"]).to(device())
+        got = nat.stft_mag_forward(audio, win, n_fft, hop)
+        want = fx[f"{tag}_spec_{which}"]
+        assert tuple(got.shape) == want.shape and got.is_contiguous()
+        peak = np.abs(want).max()
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-5 * peak          # north_star tolerance, relative to the spectrum's peak
+        ref64 = so.stft_magnitude_np(fx[f"{tag}_audio_{which}"], _window(n_fft), n_fft, hop)
+        assert np.abs(got.cpu().numpy() - ref64).max() <= 2e-6 * peak         # observed ~3e-7
+        mod = spectra.stft_magnitude(audio, n_fft, hop)                       # module path = the same kernel
+        assert torch.equal(mod, got)
+        # strided rows
+        wide = torch.zeros(audio.shape[0], audio.shape[1] + 5, device=device())
+        wide[:, :audio.shape[1]] = audio
+        assert torch.equal(nat.stft_mag_forward(wide[:, :audio.shape[1]], win, n_fft, hop), got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_hip_stft_backward_matches_reference_autograd(tag):
+    """Gradient w.r.t. the audio.  d|X|/dX = X/|X| is ill-conditioned in bins at the FFT's noise floor (their phase is
+    rounding noise in ANY implementation), so sum(|STFT|) -- every bin with weight 1 -- is only reproducible to a few 1e-3 of the
+    gradient's peak between FFT implementations (the reference's fixture); with an upstream gradient proportional to the
+    magnitude the comparison with torch.stft's autograd is tight."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    nat = native()
+    fx = _fx()
+    n_fft, hop = int(fx[f"{tag}_n_fft"]), int(fx[f"{tag}_hop"])
+    win = torch.as_tensor(_window(n_fft)).to(device())
+    audio = torch.as_tensor(fx[f"{tag}_audio_y"]).to(device())
+    frames = -(-audio.shape[1] // hop)
+    ones = torch.ones(audio.shape[0], frames, n_fft // 2 + 1, device=device())
+    got = nat.stft_mag_backward(audio, win, n_fft, hop, ones).cpu().numpy()
+    want = fx[f"{tag}_grad_sum_mag"]
+    assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max()   # noise-floor bins, see the docstring (observed up to 4e-3)
+    g = torch.Generator(device=device()).manual_seed(5)
+    up = torch.randn(audio.shape[0], frames, n_fft // 2 + 1, device=device(), generator=g)
+    up = up * spectra.stft_magnitude_torch(audio, n_fft, hop)   # weights vanish where the phase is noise
+    a1 = audio.clone().requires_grad_(True)
+    (spectra.stft_magnitude(a1, n_fft, hop) * up).sum().backward()
+    a2 = audio.clone().requires_grad_(True)
+    (spectra.stft_magnitude_torch(a2, n_fft, hop) * up).sum().backward()
+    assert float((a1.grad - a2.grad).abs().max()) <= 2e-5 * float(a2.grad.abs().max())
+    again = nat.stft_mag_backward(audio, win, n_fft, hop, up)   # deterministic: no atomics
+    assert torch.equal(again, a1.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_chain_stft_into_sot_loss_matches_reference(tag):
+    """audio -> HIP STFT magnitude -> HIP SOT loss (paper cutoff) -> backward to the estimate's audio: scalar and audio
+    gradient of the REFERENCE's chain (TorchSTFT + Wasserstein1D + autograd) for the same clips."""
+    from gpu_util import device, module_for
+    from oracle.make_golden import MODES
+    from sot_amd import spectra
+    fx = _fx()
+    n_fft, hop = int(fx[f"{tag}_n_fft"]), int(fx[f"{tag}_hop"])
+    ax = torch.as_tensor(fx[f"{tag}_audio_x"]).to(device())
+    ay = torch.as_tensor(fx[f"{tag}_audio_y"]).to(device()).requires_grad_(True)
+    mod = module_for(MODES["cutoff"])
+    loss = spectra.training_step_slice(mod, ax, ay, n_fft=n_fft, hop=hop)
+    loss.backward()
+    want, gwant = float(fx[f"{tag}_loss"]), fx[f"{tag}_grad_audio_y"]
+    assert abs(float(loss) - want) <= 2e-5 * abs(want)   # the cutoff's knife-edge amplifies the spectra's last-bit differences
+    assert np.abs(ay.grad.cpu().numpy() - gwant).max() <= 2e-3 * np.abs(gwant).max()
+
+
+@pytest.mark.gpu
+def test_hip_stft_errors_and_fallback():
+    from gpu_util import device, native
+    from sot_amd import spectra
+    nat = native()
+    a = torch.rand(2, 4096, device=device())
+    with pytest.raises(nat.SotError):
+        nat.stft_mag_forward(a, torch.ones(1000, device=device()), 1000, 250)          # not a power of two
+    with pytest.raises(RuntimeError):
+        nat.stft_mag_forward(a.cpu(), torch.ones(2048), 2048, 256)                    # no CPU path in the native layer
+    out = spectra.stft_magnitude(a, 4096, 1024)                                        # unsupported size -> torch transform
+    assert tuple(out.shape) == (2, 4, 2049)
+    assert nat.stft_mag_forward(a[:0], torch.ones(2048, device=device()), 2048, 256).shape == (0, 16, 1025)
