@@ -16,9 +16,10 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert os.path.exists(lib_path)
     handle = ctypes.CDLL(lib_path)
     header = open(os.path.join(ROOT, "include", "sot_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?\s*(sot_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|size_t|const char \*)\s*\*?\s*(sot_\w+)\s*\(", header, flags=re.M))
     assert {"sot_w1d_forward", "sot_w1d_backward", "sot_w1d_reduce_mean", "sot_w1d_quantiles", "sot_segmented_sort",
-            "sot_prepare_positions", "sot_workspace_bytes", "sot_abi_version", "sot_status_string"} <= declared
+            "sot_prepare_positions", "sot_workspace_bytes", "sot_abi_version", "sot_status_string", "sot_stft_frames",
+            "sot_stft_mag_forward", "sot_stft_mag_backward"} <= declared
     for name in declared:
         assert hasattr(handle, name), name
     assert set(sot_amd._native.EXPORTS) == declared
