@@ -20,16 +20,18 @@
 
 namespace sot_stft {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;      // forward: one 256-thread workgroup per frame
+constexpr int kBwdThreads = 1024;  // backward: one 1024-thread workgroup per clip (its 2 x frames transforms run back to back)
 constexpr int kMaxFft = 2048;
 constexpr int kMaxClip = 8192;  // samples + end padding a backward workgroup can hold in LDS
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // twiddle table T[k] = exp(-2 pi i k / n), k < n/2 (accurate: sincospi)
+template <int T>
 __device__ __forceinline__ void build_twiddles(float2* tw, int n)
 {
-    for (int k = threadIdx.x; k < n / 2; k += kThreads) {
+    for (int k = threadIdx.x; k < n / 2; k += T) {
         float s, c;
         sincospif(2.0f * (float)k / (float)n, &s, &c);
         tw[k] = make_float2(c, -s);
@@ -38,13 +40,14 @@ __device__ __forceinline__ void build_twiddles(float2* tw, int n)
 
 // In-place radix-2 decimation-in-time FFT of n = 2^logn points held in LDS in BIT-REVERSED order on entry, natural
 // order on exit.  inverse: conjugate twiddles (no 1/n).  Ends with a barrier.
+template <int T>
 __device__ __forceinline__ void fft_inplace(float2* z, const float2* tw, int n, int logn, bool inverse)
 {
     for (int s = 1; s <= logn; ++s) {
         const int half = 1 << (s - 1);
         const int tstride = n >> s;  // twiddle index step: exp(-2 pi i pos / (2 half)) = T[pos * n / (2 half)]
         __syncthreads();
-        for (int j = threadIdx.x; j < n / 2; j += kThreads) {
+        for (int j = threadIdx.x; j < n / 2; j += T) {
             const int pos = j & (half - 1);
             const int i0 = ((j >> (s - 1)) << s) + pos;
             const int i1 = i0 + half;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
     float2* const tw = z + a.n_fft;
     const int n = a.n_fft, nb = n / 2 + 1;
     const float scale = 1.0f / sqrtf((float)n);  // normalized=True: frame_length^-0.5
-    build_twiddles(tw, n);
+    build_twiddles<kThreads>(tw, n);
     for (int64_t fr = blockIdx.x; fr < a.batch * a.frames; fr += gridDim.x) {
         const int64_t b = fr / a.frames, f = fr - b * a.frames;
         const float* src = a.audio + b * a.row_stride;
@@ -87,13 +90,13 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
             const float v = (t < a.samples) ? src[t] * a.window[i] : 0.0f;  // end padding: zeros (utils.py:252-275)
             z[bitrev(i, a.logn)] = make_float2(v, 0.0f);
         }
-        fft_inplace(z, tw, n, a.logn, false);
+        fft_inplace<kThreads>(z, tw, n, a.logn, false);
         float* dst = a.mag + fr * nb;
         for (int k = threadIdx.x; k < nb; k += kThreads) dst[k] = hypotf(z[k].x, z[k].y) * scale;
     }
 }
 
-__global__ __launch_bounds__(kThreads) void stft_mag_backward_kernel(const StftArgs a)
+__global__ __launch_bounds__(kBwdThreads) void stft_mag_backward_kernel(const StftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float2* const z = reinterpret_cast<float2*>(smem_f);
@@ -102,27 +105,27 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_kernel(const StftA
     const int n = a.n_fft, nb = n / 2 + 1;
     const float scale = 1.0f / sqrtf((float)n);
     const int64_t padded = a.n_fft + a.hop * (a.frames - 1);
-    build_twiddles(tw, n);
+    build_twiddles<kBwdThreads>(tw, n);
     for (int64_t b = blockIdx.x; b < a.batch; b += gridDim.x) {
         const float* src = a.audio + b * a.row_stride;
         __syncthreads();
-        for (int64_t t = threadIdx.x; t < padded; t += kThreads) acc[t] = 0.0f;
+        for (int64_t t = threadIdx.x; t < padded; t += kBwdThreads) acc[t] = 0.0f;
         for (int64_t f = 0; f < a.frames; ++f) {
             const int64_t t0 = f * a.hop;
             __syncthreads();
-            for (int i = threadIdx.x; i < n; i += kThreads) {
+            for (int i = threadIdx.x; i < n; i += kBwdThreads) {
                 const int64_t t = t0 + i;
                 const float v = (t < a.samples) ? src[t] * a.window[i] : 0.0f;
                 z[bitrev(i, a.logn)] = make_float2(v, 0.0f);
             }
-            fft_inplace(z, tw, n, a.logn, false);  // X (unscaled)
+            fft_inplace<kBwdThreads>(z, tw, n, a.logn, false);  // X (unscaled)
             // Z_k = g_k * X_k / |X_k| for the one-sided bins, 0 elsewhere; each thread rewrites the natural-order
             // spectrum into bit-reversed order for the inverse transform through registers (two passes, barrier between)
             const float* g = a.grad_mag + (b * a.frames + f) * nb;
-            float2 zk[kMaxFft / kThreads];
+            float2 zk[kMaxFft / kBwdThreads];
 #pragma unroll
-            for (int r = 0; r < kMaxFft / kThreads; ++r) {
-                const int k = threadIdx.x + r * kThreads;
+            for (int r = 0; r < kMaxFft / kBwdThreads; ++r) {
+                const int k = threadIdx.x + r * kBwdThreads;
                 float2 v = make_float2(0.0f, 0.0f);
                 if (k < nb) {
                     const float2 x = z[k];
@@ -133,16 +136,16 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_kernel(const StftA
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < kMaxFft / kThreads; ++r) {
-                const int k = threadIdx.x + r * kThreads;
+            for (int r = 0; r < kMaxFft / kBwdThreads; ++r) {
+                const int k = threadIdx.x + r * kBwdThreads;
                 if (k < n) z[bitrev(k, a.logn)] = zk[r];
             }
-            fft_inplace(z, tw, n, a.logn, true);  // c_i = sum_k Z_k e^{+2 pi i k i / n}
-            for (int i = threadIdx.x; i < n; i += kThreads) acc[t0 + i] += a.window[i] * z[i].x * scale;  // disjoint i per thread
+            fft_inplace<kBwdThreads>(z, tw, n, a.logn, true);  // c_i = sum_k Z_k e^{+2 pi i k i / n}
+            for (int i = threadIdx.x; i < n; i += kBwdThreads) acc[t0 + i] += a.window[i] * z[i].x * scale;  // disjoint i per thread
         }
         __syncthreads();
         float* dst = a.grad_audio + b * a.samples;
-        for (int64_t t = threadIdx.x; t < a.samples; t += kThreads) dst[t] = acc[t];
+        for (int64_t t = threadIdx.x; t < a.samples; t += kBwdThreads) dst[t] = acc[t];
     }
 }
 
@@ -212,7 +215,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     }
     const int grid = (int)(batch < 1024 ? batch : 1024);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(stft_mag_backward_kernel, dim3(grid), dim3(kThreads), lds, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(stft_mag_backward_kernel, dim3(grid), dim3(kBwdThreads), lds, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
