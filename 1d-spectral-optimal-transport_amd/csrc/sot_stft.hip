@@ -3,13 +3,13 @@
 // utils.pad_for_stft, utils.py:252-275): torch.stft(center=False, normalized=True, onesided) of the end-padded signal,
 // |.|, frames-major output [batch, frames, n_fft/2 + 1].  SURVEY §8f row 1.
 //
-// Forward: one workgroup per frame.  The windowed frame goes through an in-LDS radix-2 complex FFT of n_fft points
-// (bit-reversed load, log2(n_fft) butterfly stages, twiddles from an LDS table built with sincospi), the first
-// n_fft/2 + 1 bins are reduced to hypot(re, im) / sqrt(n_fft).
+// Forward: one workgroup per frame.  The windowed REAL frame is packed into n_fft/2 complex points and goes through an
+// in-LDS radix-2 complex FFT of half the frame length (bit-reversed load, log2(n_fft/2) butterfly stages, twiddles from
+// LDS tables built with sincospi); the n_fft/2 + 1 bins are unpacked pairwise and reduced to hypot(re, im) / sqrt(n_fft).
 // Backward (closed form of abs o stft's autograd): per clip, frame by frame, recompute the frame's spectrum X, form
-// Z_k = g_k X_k / |X_k| (0 where |X_k| = 0, torch's sgn(0)), inverse-transform the one-sided Z (other bins zero), take
-// window * Re(.) / sqrt(n_fft) and overlap-add it into the clip's gradient, which is kept in LDS and written once:
-// no atomics, deterministic.
+// Z_k = g_k X_k / |X_k| (0 where |X_k| = 0, torch's sgn(0)), inverse-transform it as a Hermitian spectrum (again a
+// half-length complex transform), multiply by window / sqrt(n_fft) and overlap-add it into the clip's gradient, which
+// is kept in LDS and written once: no atomics, deterministic.
 // HBM traffic: forward reads n_fft samples per frame (L2-resident overlap) and writes n_fft/2+1 magnitudes; backward
 // reads the audio and the magnitude gradients once and writes the audio gradient once.
 #include <hip/hip_runtime.h>
@@ -66,46 +66,93 @@ __device__ __forceinline__ int bitrev(int v, int logn) { return (int)(__brev((un
 
 struct StftArgs {
     const float* audio; int64_t batch, samples, row_stride;
-    const float* window; int n_fft, logn, hop; int64_t frames;
+    const float* window; int n_fft, logm, hop; int64_t frames;   // logm = log2(n_fft / 2)
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
     float* grad_audio;          // backward output [batch, samples] (contiguous)
 };
 
-__global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftArgs a)
+// The frames are REAL, so each one is transformed by a complex FFT of HALF its length m = n_fft/2 on the packed signal
+// z[i] = v[2i] + i v[2i+1]:   with Ze = (Z_k + conj(Z_{m-k})) / 2, Zo = -i/2 (Z_k - conj(Z_{m-k})), W = exp(-2 pi i k / n):
+//   X_k = Ze + W Zo,   X_{m-k} = conj(Ze - W Zo)      (k = 0 .. m/2; Z_m := Z_0)
+// LDS: z [m] | FFT twiddles exp(-2 pi i k / m) [m/2] | W_n^k [m/2 + 1].
+template <int T>
+__device__ __forceinline__ void build_tables(float2* tw, float2* wn, int m)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float2* const z = reinterpret_cast<float2*>(smem_f);
-    float2* const tw = z + a.n_fft;
-    const int n = a.n_fft, nb = n / 2 + 1;
-    const float scale = 1.0f / sqrtf((float)n);  // normalized=True: frame_length^-0.5
-    build_twiddles<kThreads>(tw, n);
-    for (int64_t fr = blockIdx.x; fr < a.batch * a.frames; fr += gridDim.x) {
-        const int64_t b = fr / a.frames, f = fr - b * a.frames;
-        const float* src = a.audio + b * a.row_stride;
-        const int64_t t0 = f * a.hop;
-        __syncthreads();  // previous frame's reads of z are done
-        for (int i = threadIdx.x; i < n; i += kThreads) {
-            const int64_t t = t0 + i;
-            const float v = (t < a.samples) ? src[t] * a.window[i] : 0.0f;  // end padding: zeros (utils.py:252-275)
-            z[bitrev(i, a.logn)] = make_float2(v, 0.0f);
-        }
-        fft_inplace<kThreads>(z, tw, n, a.logn, false);
-        float* dst = a.mag + fr * nb;
-        for (int k = threadIdx.x; k < nb; k += kThreads) dst[k] = hypotf(z[k].x, z[k].y) * scale;
+    build_twiddles<T>(tw, m);
+    for (int k = threadIdx.x; k <= m / 2; k += T) {
+        float s, c;
+        sincospif((float)k / (float)m, &s, &c);   // 2 pi k / n = pi k / m
+        wn[k] = make_float2(c, -s);
     }
 }
 
+// windowed, end-padded, packed frame -> LDS in bit-reversed order
+template <int T>
+__device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, int64_t t0, float2* z, int m)
+{
+    for (int i = threadIdx.x; i < m; i += T) {
+        const int64_t t = t0 + 2 * i;
+        const float v0 = (t < a.samples) ? src[t] * a.window[2 * i] : 0.0f;          // end padding: zeros (utils.py:252-275)
+        const float v1 = (t + 1 < a.samples) ? src[t + 1] * a.window[2 * i + 1] : 0.0f;
+        z[bitrev(i, a.logm)] = make_float2(v0, v1);
+    }
+}
+
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// spectrum bins k and m-k of the real frame from the packed transform (see above)
+__device__ __forceinline__ void unpack_pair(const float2* z, const float2* wn, int k, int m, float2& xk, float2& xm)
+{
+    const float2 zk = z[k], zm = z[(m - k) & (m - 1)];
+    const float2 ze = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);          // Z_k - conj(Z_{m-k})
+    const float2 zo = make_float2(0.5f * d.y, -0.5f * d.x);          // -i/2 * d
+    const float2 wz = cmul(wn[k], zo);
+    xk = make_float2(ze.x + wz.x, ze.y + wz.y);
+    xm = make_float2(ze.x - wz.x, -(ze.y - wz.y));
+}
+
+__global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int n = a.n_fft, m = n / 2, nb = m + 1;
+    float2* const z = reinterpret_cast<float2*>(smem_f);
+    float2* const tw = z + m;
+    float2* const wn = tw + m / 2;
+    const float scale = 1.0f / sqrtf((float)n);  // normalized=True: frame_length^-0.5
+    build_tables<kThreads>(tw, wn, m);
+    for (int64_t fr = blockIdx.x; fr < a.batch * a.frames; fr += gridDim.x) {
+        const int64_t b = fr / a.frames, f = fr - b * a.frames;
+        __syncthreads();  // previous frame's reads of z are done
+        load_frame<kThreads>(a, a.audio + b * a.row_stride, f * a.hop, z, m);
+        fft_inplace<kThreads>(z, tw, m, a.logm, false);
+        float* dst = a.mag + fr * nb;
+        for (int k = threadIdx.x; k <= m / 2; k += kThreads) {
+            float2 xk, xm;
+            unpack_pair(z, wn, k, m, xk, xm);
+            dst[k] = hypotf(xk.x, xk.y) * scale;
+            dst[m - k] = hypotf(xm.x, xm.y) * scale;
+        }
+    }
+}
+
+// Backward.  With Zin_k = g_k X_k / |X_k| (k = 0 .. m) the gradient of the windowed frame is
+//   y_i = Re(sum_{k=0}^{m} Zin_k e^{+2 pi i k i / n}) / sqrt(n),
+// i.e. the (unnormalised) inverse real transform of the Hermitian spectrum H_k = Zin_k / 2 (0 < k < m), H_0 = Re Zin_0,
+// H_m = Re Zin_m, again through a half-length complex transform:  G_k = (H_k + conj(H_{m-k})) + i conj(W) (H_k - conj(H_{m-k})),
+// g = IFFT_m(G) (no 1/m), y_{2i} = Re g_i, y_{2i+1} = Im g_i.
 __global__ __launch_bounds__(kBwdThreads) void stft_mag_backward_kernel(const StftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int n = a.n_fft, m = n / 2, nb = m + 1;
     float2* const z = reinterpret_cast<float2*>(smem_f);
-    float2* const tw = z + a.n_fft;
-    float* const acc = reinterpret_cast<float*>(tw + a.n_fft / 2);  // gradient of the (padded) clip
-    const int n = a.n_fft, nb = n / 2 + 1;
+    float2* const tw = z + m;
+    float2* const wn = tw + m / 2;
+    float* const acc = reinterpret_cast<float*>(wn + m / 2 + 2);  // gradient of the (padded) clip
     const float scale = 1.0f / sqrtf((float)n);
     const int64_t padded = a.n_fft + a.hop * (a.frames - 1);
-    build_twiddles<kBwdThreads>(tw, n);
+    build_tables<kBwdThreads>(tw, wn, m);
     for (int64_t b = blockIdx.x; b < a.batch; b += gridDim.x) {
         const float* src = a.audio + b * a.row_stride;
         __syncthreads();
@@ -113,35 +160,40 @@ __global__ __launch_bounds__(kBwdThreads) void stft_mag_backward_kernel(const St
         for (int64_t f = 0; f < a.frames; ++f) {
             const int64_t t0 = f * a.hop;
             __syncthreads();
-            for (int i = threadIdx.x; i < n; i += kBwdThreads) {
-                const int64_t t = t0 + i;
-                const float v = (t < a.samples) ? src[t] * a.window[i] : 0.0f;
-                z[bitrev(i, a.logn)] = make_float2(v, 0.0f);
-            }
-            fft_inplace<kBwdThreads>(z, tw, n, a.logn, false);  // X (unscaled)
-            // Z_k = g_k * X_k / |X_k| for the one-sided bins, 0 elsewhere; each thread rewrites the natural-order
-            // spectrum into bit-reversed order for the inverse transform through registers (two passes, barrier between)
+            load_frame<kBwdThreads>(a, src, t0, z, m);
+            fft_inplace<kBwdThreads>(z, tw, m, a.logm, false);
+            // pair (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
             const float* g = a.grad_mag + (b * a.frames + f) * nb;
-            float2 zk[kMaxFft / kBwdThreads];
-#pragma unroll
-            for (int r = 0; r < kMaxFft / kBwdThreads; ++r) {
-                const int k = threadIdx.x + r * kBwdThreads;
-                float2 v = make_float2(0.0f, 0.0f);
-                if (k < nb) {
-                    const float2 x = z[k];
-                    const float m = hypotf(x.x, x.y);
-                    if (m > 0.0f) { const float c = g[k] / m; v = make_float2(c * x.x, c * x.y); }
-                }
-                zk[r] = v;
+            const int k = threadIdx.x;   // m/2 + 1 <= 513 pairs <= kBwdThreads
+            float2 gk = make_float2(0.0f, 0.0f), gm = make_float2(0.0f, 0.0f);
+            if (k <= m / 2) {
+                float2 xk, xm;
+                unpack_pair(z, wn, k, m, xk, xm);
+                const float mk = hypotf(xk.x, xk.y), mm = hypotf(xm.x, xm.y);
+                const float ck = mk > 0.0f ? g[k] / mk : 0.0f;          // torch: sgn(0) = 0
+                const float cm = mm > 0.0f ? g[m - k] / mm : 0.0f;
+                float2 hk = make_float2(0.5f * ck * xk.x, 0.5f * ck * xk.y);
+                float2 hm = make_float2(0.5f * cm * xm.x, 0.5f * cm * xm.y);
+                if (k == 0) { hk = make_float2(ck * xk.x, 0.0f); hm = make_float2(cm * xm.x, 0.0f); }   // H_0, H_m are real
+                const float2 sk = make_float2(hk.x + hm.x, hk.y - hm.y);      // H_k + conj(H_{m-k})
+                const float2 dk = make_float2(hk.x - hm.x, hk.y + hm.y);      // H_k - conj(H_{m-k})
+                const float2 w = wn[k];
+                const float2 cw = cmul(cconj(w), dk);                          // conj(W) d
+                gk = make_float2(sk.x - cw.y, sk.y + cw.x);                    // s + i conj(W) d
+                // G_{m-k} = (H_{m-k} + conj(H_k)) + i (-W) (H_{m-k} - conj(H_k)) = conj(s) + i W conj(d)
+                const float2 wd = cmul(w, cconj(dk));
+                gm = make_float2(sk.x - wd.y, -sk.y + wd.x);
             }
             __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kMaxFft / kBwdThreads; ++r) {
-                const int k = threadIdx.x + r * kBwdThreads;
-                if (k < n) z[bitrev(k, a.logn)] = zk[r];
+            if (k <= m / 2) {
+                z[bitrev(k, a.logm)] = gk;
+                if (k > 0 && k < m - k) z[bitrev(m - k, a.logm)] = gm;
             }
-            fft_inplace<kBwdThreads>(z, tw, n, a.logn, true);  // c_i = sum_k Z_k e^{+2 pi i k i / n}
-            for (int i = threadIdx.x; i < n; i += kBwdThreads) acc[t0 + i] += a.window[i] * z[i].x * scale;  // disjoint i per thread
+            fft_inplace<kBwdThreads>(z, tw, m, a.logm, true);
+            for (int i = threadIdx.x; i < m; i += kBwdThreads) {
+                acc[t0 + 2 * i] += a.window[2 * i] * z[i].x * scale;
+                acc[t0 + 2 * i + 1] += a.window[2 * i + 1] * z[i].y * scale;
+            }
         }
         __syncthreads();
         float* dst = a.grad_audio + b * a.samples;
@@ -164,7 +216,7 @@ static int fill_args(const float* audio, int64_t batch, int64_t samples, int64_t
     if (logn < 6 || n_fft > kMaxFft) return SOT_ERR_UNSUPPORTED_SIZE;  // 64 ... 2048, powers of two
     if (batch > 0 && (audio == nullptr || window == nullptr)) return SOT_ERR_NULL_POINTER;
     a->audio = audio; a->batch = batch; a->samples = samples; a->row_stride = row_stride;
-    a->window = window; a->n_fft = n_fft; a->logn = logn; a->hop = hop;
+    a->window = window; a->n_fft = n_fft; a->logm = logn - 1; a->hop = hop;
     a->frames = (samples + hop - 1) / hop;  // utils.py:265: -(-signal_len // hop_length)
     return SOT_OK;
 }
@@ -185,7 +237,7 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     if (batch == 0) return SOT_OK;
     if (mag == nullptr) return SOT_ERR_NULL_POINTER;
     a.mag = mag;
-    const size_t lds = sizeof(float2) * ((size_t)n_fft + n_fft / 2);
+    const size_t lds = sizeof(float2) * ((size_t)n_fft / 2 + n_fft / 4 + n_fft / 4 + 2);
     const int64_t work = batch * a.frames;
     const int grid = (int)(work < 256 * 16 ? work : 256 * 16);
     (void)hipGetLastError();
@@ -205,7 +257,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     const int64_t padded = n_fft + (int64_t)hop * (a.frames - 1);
     if (padded > kMaxClip) return SOT_ERR_UNSUPPORTED_SIZE;
     a.grad_mag = grad_mag; a.grad_audio = grad_audio;
-    const size_t lds = sizeof(float2) * ((size_t)n_fft + n_fft / 2) + sizeof(float) * (size_t)padded;
+    const size_t lds = sizeof(float2) * ((size_t)n_fft / 2 + n_fft / 4 + n_fft / 4 + 2) + sizeof(float) * (size_t)padded;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
