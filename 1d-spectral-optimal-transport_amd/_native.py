@@ -55,8 +55,9 @@ EXPORTS = {
     "sot_stft_frames": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
     "sot_stft_mag_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                             _vp, _vp]),
+    "sot_stft_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
-                                             _vp, _vp, _vp]),
+                                             _vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None
@@ -367,7 +368,10 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
     grad_mag = grad_mag.contiguous()
     batch, samples = audio.shape
     grad_audio = torch.empty(batch, samples, dtype=torch.float32, device=audio.device)
+    ws = torch.empty(max(1, int(lib.sot_stft_backward_workspace_bytes(batch, samples, int(n_fft), int(hop)))), dtype=torch.uint8,
+                     device=audio.device)
     with _on_device(audio.device):
         check(lib.sot_stft_mag_backward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
-                                        int(n_fft), int(hop), grad_mag.data_ptr(), grad_audio.data_ptr(), stream_ptr(audio.device)))
+                                        int(n_fft), int(hop), grad_mag.data_ptr(), grad_audio.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        stream_ptr(audio.device)))
     return grad_audio

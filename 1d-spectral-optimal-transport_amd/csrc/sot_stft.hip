@@ -6,12 +6,15 @@
 // Forward: one workgroup per frame.  The windowed REAL frame is packed into n_fft/2 complex points and goes through an
 // in-LDS radix-2 complex FFT of half the frame length (bit-reversed load, log2(n_fft/2) butterfly stages, twiddles from
 // LDS tables built with sincospi); the n_fft/2 + 1 bins are unpacked pairwise and reduced to hypot(re, im) / sqrt(n_fft).
-// Backward (closed form of abs o stft's autograd): per clip, frame by frame, recompute the frame's spectrum X, form
+// Backward (closed form of abs o stft's autograd): per group of four consecutive frames, frame by frame, recompute the
+// frame's spectrum X, form
 // Z_k = g_k X_k / |X_k| (0 where |X_k| = 0, torch's sgn(0)), inverse-transform it as a Hermitian spectrum (again a
-// half-length complex transform), multiply by window / sqrt(n_fft) and overlap-add it into the clip's gradient, which
-// is kept in LDS and written once: no atomics, deterministic.
+// half-length complex transform), multiply by window / sqrt(n_fft) and overlap-add it into the group's gradient, which
+// is kept in LDS and written once to a scratch buffer; a second kernel adds, per sample, the groups that cover it in a
+// fixed order: no atomics, deterministic.
 // HBM traffic: forward reads n_fft samples per frame (L2-resident overlap) and writes n_fft/2+1 magnitudes; backward
-// reads the audio and the magnitude gradients once and writes the audio gradient once.
+// reads the audio and the magnitude gradients once, writes and re-reads the groups' partial gradients (1.4 x the audio
+// for 4 frames per group at 8 frames per sample) and writes the audio gradient once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -21,9 +24,8 @@
 namespace sot_stft {
 
 constexpr int kThreads = 256;      // forward: one 256-thread workgroup per frame
-constexpr int kBwdThreads = 1024;  // backward: one 1024-thread workgroup per clip (its 2 x frames transforms run back to back)
+constexpr int kFramesPerGroup = 4;  // backward: one workgroup per group of consecutive frames of a clip
 constexpr int kMaxFft = 2048;
-constexpr int kMaxClip = 8192;  // samples + end padding a backward workgroup can hold in LDS
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
@@ -70,6 +72,8 @@ struct StftArgs {
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
     float* grad_audio;          // backward output [batch, samples] (contiguous)
+    float* partial;             // backward scratch [batch, groups, span]: each frame group's overlap-added gradient
+    int64_t groups; int span;   // span = n_fft + hop * (kFramesPerGroup - 1)
 };
 
 // The frames are REAL, so each one is transformed by a complex FFT of HALF its length m = n_fft/2 on the packed signal
@@ -142,62 +146,93 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
 // i.e. the (unnormalised) inverse real transform of the Hermitian spectrum H_k = Zin_k / 2 (0 < k < m), H_0 = Re Zin_0,
 // H_m = Re Zin_m, again through a half-length complex transform:  G_k = (H_k + conj(H_{m-k})) + i conj(W) (H_k - conj(H_{m-k})),
 // g = IFFT_m(G) (no 1/m), y_{2i} = Re g_i, y_{2i+1} = Im g_i.
-__global__ __launch_bounds__(kBwdThreads) void stft_mag_backward_kernel(const StftArgs a)
+// Pass 1 (this kernel): one workgroup per group of kFramesPerGroup consecutive frames; their windowed gradients are
+// overlap-added in LDS and stored as the group's partial result.  Pass 2 (stft_overlap_add_kernel) adds, per sample, the
+// partial results of the groups that cover it in ascending group order: deterministic, no atomics.
+__global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(const StftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int n = a.n_fft, m = n / 2, nb = m + 1;
+    constexpr int kPairsPerThread = (kMaxFft / 4 + kThreads) / kThreads;  // m/2 + 1 <= 513 pairs (k, m-k)
     float2* const z = reinterpret_cast<float2*>(smem_f);
     float2* const tw = z + m;
     float2* const wn = tw + m / 2;
-    float* const acc = reinterpret_cast<float*>(wn + m / 2 + 2);  // gradient of the (padded) clip
+    float* const acc = reinterpret_cast<float*>(wn + m / 2 + 2);  // this group's overlap-added gradient [span]
     const float scale = 1.0f / sqrtf((float)n);
-    const int64_t padded = a.n_fft + a.hop * (a.frames - 1);
-    build_tables<kBwdThreads>(tw, wn, m);
-    for (int64_t b = blockIdx.x; b < a.batch; b += gridDim.x) {
+    build_tables<kThreads>(tw, wn, m);
+    for (int64_t w = blockIdx.x; w < a.batch * a.groups; w += gridDim.x) {
+        const int64_t b = w / a.groups, grp = w - b * a.groups;
         const float* src = a.audio + b * a.row_stride;
+        const int64_t f_begin = grp * kFramesPerGroup;
+        const int64_t f_end = min(f_begin + kFramesPerGroup, a.frames);
+        const int64_t base = f_begin * a.hop;   // first sample of the group's span
         __syncthreads();
-        for (int64_t t = threadIdx.x; t < padded; t += kBwdThreads) acc[t] = 0.0f;
-        for (int64_t f = 0; f < a.frames; ++f) {
+        for (int t = threadIdx.x; t < a.span; t += kThreads) acc[t] = 0.0f;
+        for (int64_t f = f_begin; f < f_end; ++f) {
             const int64_t t0 = f * a.hop;
             __syncthreads();
-            load_frame<kBwdThreads>(a, src, t0, z, m);
-            fft_inplace<kBwdThreads>(z, tw, m, a.logm, false);
-            // pair (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
+            load_frame<kThreads>(a, src, t0, z, m);
+            fft_inplace<kThreads>(z, tw, m, a.logm, false);
+            // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
             const float* g = a.grad_mag + (b * a.frames + f) * nb;
-            const int k = threadIdx.x;   // m/2 + 1 <= 513 pairs <= kBwdThreads
-            float2 gk = make_float2(0.0f, 0.0f), gm = make_float2(0.0f, 0.0f);
-            if (k <= m / 2) {
-                float2 xk, xm;
-                unpack_pair(z, wn, k, m, xk, xm);
-                const float mk = hypotf(xk.x, xk.y), mm = hypotf(xm.x, xm.y);
-                const float ck = mk > 0.0f ? g[k] / mk : 0.0f;          // torch: sgn(0) = 0
-                const float cm = mm > 0.0f ? g[m - k] / mm : 0.0f;
-                float2 hk = make_float2(0.5f * ck * xk.x, 0.5f * ck * xk.y);
-                float2 hm = make_float2(0.5f * cm * xm.x, 0.5f * cm * xm.y);
-                if (k == 0) { hk = make_float2(ck * xk.x, 0.0f); hm = make_float2(cm * xm.x, 0.0f); }   // H_0, H_m are real
-                const float2 sk = make_float2(hk.x + hm.x, hk.y - hm.y);      // H_k + conj(H_{m-k})
-                const float2 dk = make_float2(hk.x - hm.x, hk.y + hm.y);      // H_k - conj(H_{m-k})
-                const float2 w = wn[k];
-                const float2 cw = cmul(cconj(w), dk);                          // conj(W) d
-                gk = make_float2(sk.x - cw.y, sk.y + cw.x);                    // s + i conj(W) d
-                // G_{m-k} = (H_{m-k} + conj(H_k)) + i (-W) (H_{m-k} - conj(H_k)) = conj(s) + i W conj(d)
-                const float2 wd = cmul(w, cconj(dk));
-                gm = make_float2(sk.x - wd.y, -sk.y + wd.x);
+            float2 gk[kPairsPerThread], gm[kPairsPerThread];
+#pragma unroll
+            for (int r = 0; r < kPairsPerThread; ++r) {
+                const int k = threadIdx.x + r * kThreads;
+                gk[r] = make_float2(0.0f, 0.0f); gm[r] = make_float2(0.0f, 0.0f);
+                if (k <= m / 2) {
+                    float2 xk, xm;
+                    unpack_pair(z, wn, k, m, xk, xm);
+                    const float mk = hypotf(xk.x, xk.y), mm = hypotf(xm.x, xm.y);
+                    const float ck = mk > 0.0f ? g[k] / mk : 0.0f;          // torch: sgn(0) = 0
+                    const float cm = mm > 0.0f ? g[m - k] / mm : 0.0f;
+                    float2 hk = make_float2(0.5f * ck * xk.x, 0.5f * ck * xk.y);
+                    float2 hm = make_float2(0.5f * cm * xm.x, 0.5f * cm * xm.y);
+                    if (k == 0) { hk = make_float2(ck * xk.x, 0.0f); hm = make_float2(cm * xm.x, 0.0f); }   // H_0, H_m are real
+                    const float2 sk = make_float2(hk.x + hm.x, hk.y - hm.y);      // H_k + conj(H_{m-k})
+                    const float2 dk = make_float2(hk.x - hm.x, hk.y + hm.y);      // H_k - conj(H_{m-k})
+                    const float2 wk = wn[k];
+                    const float2 cw = cmul(cconj(wk), dk);                         // conj(W) d
+                    gk[r] = make_float2(sk.x - cw.y, sk.y + cw.x);                 // s + i conj(W) d
+                    // G_{m-k} = (H_{m-k} + conj(H_k)) + i (-W) (H_{m-k} - conj(H_k)) = conj(s) + i W conj(d)
+                    const float2 wd = cmul(wk, cconj(dk));
+                    gm[r] = make_float2(sk.x - wd.y, -sk.y + wd.x);
+                }
             }
             __syncthreads();
-            if (k <= m / 2) {
-                z[bitrev(k, a.logm)] = gk;
-                if (k > 0 && k < m - k) z[bitrev(m - k, a.logm)] = gm;
+#pragma unroll
+            for (int r = 0; r < kPairsPerThread; ++r) {
+                const int k = threadIdx.x + r * kThreads;
+                if (k <= m / 2) {
+                    z[bitrev(k, a.logm)] = gk[r];
+                    if (k > 0 && k < m - k) z[bitrev(m - k, a.logm)] = gm[r];
+                }
             }
-            fft_inplace<kBwdThreads>(z, tw, m, a.logm, true);
-            for (int i = threadIdx.x; i < m; i += kBwdThreads) {
-                acc[t0 + 2 * i] += a.window[2 * i] * z[i].x * scale;
-                acc[t0 + 2 * i + 1] += a.window[2 * i + 1] * z[i].y * scale;
+            fft_inplace<kThreads>(z, tw, m, a.logm, true);
+            const int off = (int)(t0 - base);
+            for (int i = threadIdx.x; i < m; i += kThreads) {
+                acc[off + 2 * i] += a.window[2 * i] * z[i].x * scale;
+                acc[off + 2 * i + 1] += a.window[2 * i + 1] * z[i].y * scale;
             }
         }
         __syncthreads();
-        float* dst = a.grad_audio + b * a.samples;
-        for (int64_t t = threadIdx.x; t < a.samples; t += kBwdThreads) dst[t] = acc[t];
+        float* dst = a.partial + w * a.span;
+        for (int t = threadIdx.x; t < a.span; t += kThreads) dst[t] = acc[t];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftArgs a)
+{
+    const int64_t total = a.batch * a.samples;
+    const int64_t gstep = (int64_t)kFramesPerGroup * a.hop;   // samples between the starts of consecutive groups
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = idx / a.samples, t = idx - b * a.samples;
+        int64_t g_lo = (t - a.span + gstep) / gstep;           // first group whose span [g * gstep, g * gstep + span) holds t
+        if (t - a.span + 1 <= 0) g_lo = 0;
+        const int64_t g_hi = min(t / gstep, a.groups - 1);
+        float sum = 0.0f;
+        for (int64_t g = g_lo; g <= g_hi; ++g) sum += a.partial[(b * a.groups + g) * a.span + (t - g * gstep)];
+        a.grad_audio[idx] = sum;
     }
 }
 
@@ -245,29 +280,49 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
+size_t sot_stft_backward_workspace_bytes(int64_t batch, int64_t samples, int n_fft, int hop)
+{
+    if (batch < 1 || samples < 1 || hop < 1 || n_fft < 1) return 0;
+    const int64_t frames = (samples + hop - 1) / hop;
+    const int64_t groups = (frames + sot_stft::kFramesPerGroup - 1) / sot_stft::kFramesPerGroup;
+    const int64_t span = n_fft + (int64_t)hop * (sot_stft::kFramesPerGroup - 1);
+    return sizeof(float) * (size_t)(batch * groups * span);
+}
+
 int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, int64_t audio_row_stride, const float* window,
-                          int n_fft, int hop, const float* grad_mag, float* grad_audio, void* stream)
+                          int n_fft, int hop, const float* grad_mag, float* grad_audio, void* workspace, size_t workspace_bytes,
+                          void* stream)
 {
     using namespace sot_stft;
     StftArgs a{};
     const int rc = fill_args(audio, batch, samples, audio_row_stride, window, n_fft, hop, &a);
     if (rc != SOT_OK) return rc;
     if (batch == 0) return SOT_OK;
-    if (grad_mag == nullptr || grad_audio == nullptr) return SOT_ERR_NULL_POINTER;
-    const int64_t padded = n_fft + (int64_t)hop * (a.frames - 1);
-    if (padded > kMaxClip) return SOT_ERR_UNSUPPORTED_SIZE;
+    if (grad_mag == nullptr || grad_audio == nullptr || workspace == nullptr) return SOT_ERR_NULL_POINTER;
+    if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
+    const int64_t span = n_fft + (int64_t)hop * (kFramesPerGroup - 1);
+    if (span > 16384) return SOT_ERR_UNSUPPORTED_SIZE;   // the group's gradient lives in LDS
     a.grad_mag = grad_mag; a.grad_audio = grad_audio;
-    const size_t lds = sizeof(float2) * ((size_t)n_fft / 2 + n_fft / 4 + n_fft / 4 + 2) + sizeof(float) * (size_t)padded;
+    a.partial = reinterpret_cast<float*>(workspace);
+    a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
+    a.span = (int)span;
+    const size_t lds = sizeof(float2) * ((size_t)n_fft / 2 + n_fft / 4 + n_fft / 4 + 2) + sizeof(float) * (size_t)span;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                64 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_partial_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
-    const int grid = (int)(batch < 1024 ? batch : 1024);
+    const int64_t work = batch * a.groups;
+    const int grid = (int)(work < 256 * 16 ? work : 256 * 16);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(stft_mag_backward_kernel, dim3(grid), dim3(kBwdThreads), lds, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(stft_mag_backward_partial_kernel, dim3(grid), dim3(kThreads), lds, st, a);
+    if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
+    const int64_t total = batch * samples;
+    const int grid2 = (int)((total + kThreads - 1) / kThreads < 256 * 32 ? (total + kThreads - 1) / kThreads : 256 * 32);
+    hipLaunchKernelGGL(stft_overlap_add_kernel, dim3(grid2), dim3(kThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

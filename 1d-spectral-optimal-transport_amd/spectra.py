@@ -63,9 +63,8 @@ class _StftMagnitude(torch.autograd.Function):
 
 
 def hip_stft_supported(n_fft: int, hop: int, samples: int) -> bool:
-    """Sizes the HIP kernels cover: n_fft a power of two in [64, 2048]; for the backward the end-padded clip must fit LDS."""
-    frames = -(-samples // hop)
-    return 64 <= n_fft <= 2048 and (n_fft & (n_fft - 1)) == 0 and n_fft + hop * (frames - 1) <= 8192
+    """Sizes the HIP kernels cover: n_fft a power of two in [64, 2048] (a group of 4 frames must fit LDS in the backward)."""
+    return 64 <= n_fft <= 2048 and (n_fft & (n_fft - 1)) == 0 and samples >= 1 and 1 <= hop and n_fft + 3 * hop <= 16384
 
 
 def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop") -> torch.Tensor:
@@ -104,11 +103,61 @@ def harmonic_batch(batch: int, n_samples: int = 4096, sample_rate: float = 16000
     return 0.9 * sig / sig.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
 
 
+class _AudioToLoss(torch.autograd.Function):
+    """The whole slice behind ONE autograd node: STFT magnitudes of target and estimate, SOT loss with the batch mean
+    (forward: 4 kernels), and on the way back the SOT backward kernel w.r.t. the estimate's spectrum followed by the STFT
+    backward kernel into the estimate's audio.  Same kernels as the separate nodes, two autograd round trips fewer."""
+
+    @staticmethod
+    def forward(ctx, audio_target, audio_estimate, window, pos_x, pos_y, n_fft, hop, p, flags, plan):
+        from . import _native as nat
+        audio_estimate = audio_estimate.contiguous()
+        spec_x = nat.stft_mag_forward(audio_target.contiguous(), window, n_fft, hop)
+        spec_y = nat.stft_mag_forward(audio_estimate, window, n_fft, hop)
+        rows_x = spec_x.view(-1, spec_x.shape[-1])
+        rows_y = spec_y.view(-1, spec_y.shape[-1])
+        mean, _, _ = nat.loss_fused(rows_x, rows_y, pos_x, pos_y, p, flags, plan)
+        ctx.save_for_backward(audio_estimate, window, rows_x, rows_y, pos_x, pos_y)
+        ctx.cfg = (n_fft, hop, p, flags, plan, tuple(spec_y.shape))
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _native as nat
+        audio_estimate, window, rows_x, rows_y, pos_x, pos_y = ctx.saved_tensors
+        n_fft, hop, p, flags, plan, shape = ctx.cfg
+        if not ctx.needs_input_grad[1]:
+            return (None,) * 10
+        _, gy = nat.backward_rows(rows_x, rows_y, pos_x, pos_y, p, flags, g.float(), need_gx=False, need_gy=True, plan=plan,
+                                  grad_scale=1.0 / rows_x.shape[0])
+        grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, gy.view(shape))
+        return None, grad_audio, None, None, None, None, None, None, None, None
+
+
+_POSITIONS = {}
+
+
 def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate: torch.Tensor, n_fft: int = 2048, hop: int = 256,
                         sample_rate: float = 16000.0, window="flattop"):
     """One step of the slice trainer.py:192-221 runs around the loss: spectra of target and estimate, unit-scaled
-    frequency positions, SOT loss (forward).  The caller backpropagates into `audio_estimate`."""
+    frequency positions, SOT loss (forward).  The caller backpropagates into `audio_estimate`.
+    On the GPU, for the module's plain mean (no hinge) the slice is one autograd node (_AudioToLoss); otherwise it is the
+    composition of stft_magnitude and the module."""
+    dev = audio_target.device
+    key = (int(n_fft), float(sample_rate), str(dev))
+    pos = _POSITIONS.get(key)
+    if pos is None:
+        p0 = unit_frequencies(n_fft, sample_rate, dev)
+        pos = _POSITIONS[key] = (p0, p0.clone())
+    fused = (audio_target.is_cuda and audio_target.ndim == 2 and audio_estimate.shape == audio_target.shape and
+             hip_stft_supported(n_fft, hop, audio_target.shape[1]) and not getattr(loss_module, "hinge", False))
+    if fused:
+        from .losses import _flags
+        flags = _flags(loss_module.square_dist, bool(loss_module.dont_normalize), bool(loss_module.limit_quantile_range),
+                       loss_module.require_sort)
+        plan = loss_module._plans.get(pos[0], pos[1]) if loss_module.require_sort else None
+        return _AudioToLoss.apply(audio_target.float(), audio_estimate.float(), _cached_window(window, n_fft, dev), pos[0], pos[1],
+                                  int(n_fft), int(hop), float(loss_module.p), flags, plan)
     spec_x = stft_magnitude(audio_target, n_fft, hop, window)
     spec_y = stft_magnitude(audio_estimate, n_fft, hop, window)
-    pos = unit_frequencies(n_fft, sample_rate, spec_x.device)
-    return loss_module(spec_x, spec_y, x_pos=pos, y_pos=pos.clone())
+    return loss_module(spec_x, spec_y, x_pos=pos[0], y_pos=pos[1])

@@ -38,7 +38,7 @@ def test_cpu_tensors_use_the_torch_transform():
     got = spectra.stft_magnitude(torch.as_tensor(fx["c_audio_x"]), 1024, 256)
     assert np.abs(got.numpy() - fx["c_spec_x"]).max() <= 2e-6 * np.abs(fx["c_spec_x"]).max()
     assert spectra.hip_stft_supported(2048, 256, 4096) and not spectra.hip_stft_supported(4096, 256, 4096)
-    assert not spectra.hip_stft_supported(1000, 250, 4096) and not spectra.hip_stft_supported(2048, 256, 16000)
+    assert not spectra.hip_stft_supported(1000, 250, 4096) and spectra.hip_stft_supported(2048, 256, 16000)
 
 
 @pytest.mark.gpu
@@ -117,6 +117,25 @@ def test_chain_stft_into_sot_loss_matches_reference(tag):
     want, gwant = float(fx[f"{tag}_loss"]), fx[f"{tag}_grad_audio_y"]
     assert abs(float(loss) - want) <= 2e-5 * abs(want)   # the cutoff's knife-edge amplifies the spectra's last-bit differences
     assert np.abs(ay.grad.cpu().numpy() - gwant).max() <= 2e-3 * np.abs(gwant).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,samples,batch", [(2048, 256, 16000, 3), (256, 64, 777, 5), (1024, 512, 5000, 2), (64, 16, 100, 4)])
+def test_hip_stft_other_sizes_against_torch(n_fft, hop, samples, batch):
+    """Long clips (many frame groups), odd lengths, hop = n_fft/2: forward and (magnitude-weighted) backward vs torch.stft."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    native()
+    g = torch.Generator(device=device()).manual_seed(n_fft + samples)
+    audio = torch.randn(batch, samples, device=device(), generator=g)
+    ref = spectra.stft_magnitude_torch(audio, n_fft, hop, "hann")
+    got = spectra.stft_magnitude(audio, n_fft, hop, "hann")
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    up = torch.randn(ref.shape, device=device(), generator=g) * ref
+    a1 = audio.clone().requires_grad_(True); (spectra.stft_magnitude(a1, n_fft, hop, "hann") * up).sum().backward()
+    a2 = audio.clone().requires_grad_(True); (spectra.stft_magnitude_torch(a2, n_fft, hop, "hann") * up).sum().backward()
+    assert float((a1.grad - a2.grad).abs().max()) <= 2e-5 * float(a2.grad.abs().max())
 
 
 @pytest.mark.gpu
