@@ -40,25 +40,44 @@ __device__ __forceinline__ void build_twiddles(float2* tw, int n)
     }
 }
 
-// In-place radix-2 decimation-in-time FFT of n = 2^logn points held in LDS in BIT-REVERSED order on entry, natural
-// order on exit.  inverse: conjugate twiddles (no 1/n).  Ends with a barrier.
+// In-place decimation-in-time FFT of n = 2^logn points held in LDS in BIT-REVERSED order on entry, natural order on exit.
+// Two radix-2 stages are executed per pass (a radix-4 butterfly on the elements i0, i0+h, i0+2h, i0+3h: the same
+// operations, in the same order per element, as two separate stages -- half the LDS round trips and barriers); an odd
+// logn starts with one plain radix-2 stage.  inverse: conjugate twiddles (no 1/n).  Ends with a barrier.
 template <int T>
 __device__ __forceinline__ void fft_inplace(float2* z, const float2* tw, int n, int logn, bool inverse)
 {
-    for (int s = 1; s <= logn; ++s) {
-        const int half = 1 << (s - 1);
-        const int tstride = n >> s;  // twiddle index step: exp(-2 pi i pos / (2 half)) = T[pos * n / (2 half)]
+    int s = 1;
+    if (logn & 1) {  // stage 1: half = 1, twiddle 1
         __syncthreads();
         for (int j = threadIdx.x; j < n / 2; j += T) {
-            const int pos = j & (half - 1);
-            const int i0 = ((j >> (s - 1)) << s) + pos;
-            const int i1 = i0 + half;
-            float2 w = tw[pos * tstride];
-            if (inverse) w.y = -w.y;
-            const float2 a = z[i0];
-            const float2 b = cmul(z[i1], w);
-            z[i0] = make_float2(a.x + b.x, a.y + b.y);
-            z[i1] = make_float2(a.x - b.x, a.y - b.y);
+            const float2 a = z[2 * j], b = z[2 * j + 1];
+            z[2 * j] = make_float2(a.x + b.x, a.y + b.y);
+            z[2 * j + 1] = make_float2(a.x - b.x, a.y - b.y);
+        }
+        s = 2;
+    }
+    for (; s <= logn; s += 2) {
+        const int h = 1 << (s - 1);       // half size of stage s; stage s+1 has half size 2h
+        const int t1 = n >> s;            // stage s:     exp(-2 pi i pos / (2h)) = T[pos * n / (2h)]
+        const int t2 = n >> (s + 1);      // stage s + 1: exp(-2 pi i pos / (4h)) = T[pos * n / (4h)]
+        __syncthreads();
+        for (int j = threadIdx.x; j < n / 4; j += T) {
+            const int pos = j & (h - 1);
+            const int i0 = ((j >> (s - 1)) << (s + 1)) + pos;
+            float2 w1 = tw[pos * t1], w2 = tw[pos * t2];
+            if (inverse) { w1.y = -w1.y; w2.y = -w2.y; }
+            const float2 a = z[i0], b = cmul(z[i0 + h], w1), c = z[i0 + 2 * h], d = cmul(z[i0 + 3 * h], w1);
+            const float2 a1 = make_float2(a.x + b.x, a.y + b.y), b1 = make_float2(a.x - b.x, a.y - b.y);
+            const float2 c1 = make_float2(c.x + d.x, c.y + d.y), d1 = make_float2(c.x - d.x, c.y - d.y);
+            const float2 c2 = cmul(c1, w2);
+            // exp(-2 pi i (pos + h) / (4h)) = w2 * (-i)  (forward),  w2 * (+i)  (inverse)
+            const float2 w3 = inverse ? make_float2(-w2.y, w2.x) : make_float2(w2.y, -w2.x);
+            const float2 d2 = cmul(d1, w3);
+            z[i0] = make_float2(a1.x + c2.x, a1.y + c2.y);
+            z[i0 + 2 * h] = make_float2(a1.x - c2.x, a1.y - c2.y);
+            z[i0 + h] = make_float2(b1.x + d2.x, b1.y + d2.y);
+            z[i0 + 3 * h] = make_float2(b1.x - d2.x, b1.y - d2.y);
         }
     }
     __syncthreads();
