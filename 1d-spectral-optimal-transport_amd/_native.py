@@ -55,6 +55,11 @@ EXPORTS = {
     "sot_stft_frames": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
     "sot_stft_mag_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                             _vp, _vp]),
+    "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
+    "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                                 _vp, _vp, ctypes.c_size_t, _vp]),
+    "sot_spec_distance_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                  ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp]),
     "sot_stft_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                              _vp, _vp, _vp, ctypes.c_size_t, _vp]),
@@ -375,3 +380,34 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
                                         int(n_fft), int(hop), grad_mag.data_ptr(), grad_audio.data_ptr(), ws.data_ptr(), ws.numel(),
                                         stream_ptr(audio.device)))
     return grad_audio
+
+
+def spec_distance_forward(target: torch.Tensor, value: torch.Tensor, mag_weight: float, logmag_weight: float, eps: float = 1e-5,
+                          l2: bool = False) -> torch.Tensor:
+    """0-d fp32: mag_weight * mean D(t - v) + logmag_weight * mean D(slog t - slog v) (sot_spec_distance_forward)."""
+    require_hip(target, value)
+    lib = load()
+    target, value = target.contiguous(), value.contiguous()
+    if target.shape != value.shape or target.numel() == 0:
+        raise RuntimeError("spec_distance_forward expects two non-empty tensors of the same shape")
+    out = torch.empty((), dtype=torch.float32, device=target.device)
+    ws = torch.empty(int(lib.sot_spec_distance_workspace_bytes()), dtype=torch.uint8, device=target.device)
+    with _on_device(target.device):
+        check(lib.sot_spec_distance_forward(target.data_ptr(), value.data_ptr(), target.numel(), float(mag_weight), float(logmag_weight),
+                                            float(eps), int(bool(l2)), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            stream_ptr(target.device)))
+    return out
+
+
+def spec_distance_backward(target, value, mag_weight, logmag_weight, upstream, grad_scale=1.0, eps=1e-5, l2=False, need_target=False,
+                           need_value=True):
+    require_hip(target, value, upstream)
+    lib = load()
+    target, value = target.contiguous(), value.contiguous()
+    gt = torch.empty_like(target) if need_target else None
+    gv = torch.empty_like(value) if need_value else None
+    with _on_device(target.device):
+        check(lib.sot_spec_distance_backward(target.data_ptr(), value.data_ptr(), target.numel(), float(mag_weight), float(logmag_weight),
+                                             float(eps), int(bool(l2)), upstream.contiguous().data_ptr(), float(grad_scale), _ptr(gt), _ptr(gv),
+                                             stream_ptr(target.device)))
+    return gt, gv

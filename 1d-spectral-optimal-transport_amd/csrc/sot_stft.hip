@@ -255,6 +255,77 @@ __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spectral distance of the reference's MSSLoss (losses.py:365-425; mean_difference, losses.py:7-36; safe_log,
+// utils.py:145-151): over `count` magnitudes,
+//   d = mag_weight * mean(D(t - v)) + logmag_weight * mean(D(slog(t) - slog(v))),  D = |.| (L1) or (.)^2 (L2),
+//   slog(x) = log(x <= eps ? eps : x).
+// Forward: per-workgroup fp64 partial sums (fixed assignment of elements to workgroups), a second one-workgroup kernel
+// adds the partials in index order: deterministic.  Backward: elementwise.
+// ---------------------------------------------------------------------------------------------
+struct DistArgs {
+    const float* target; const float* value; int64_t count;
+    float mag_weight, logmag_weight, eps; int l2;
+    double* partial; int n_partial; float* out;           // forward
+    const float* upstream; float grad_scale;               // backward: d(loss)/d(d) as a device scalar, times grad_scale
+    float* grad_target; float* grad_value;                 // either may be null
+};
+
+__device__ __forceinline__ float safe_logf(float x, float eps) { return logf(x <= eps ? eps : x); }
+
+__global__ __launch_bounds__(kThreads) void spec_distance_partial_kernel(const DistArgs a)
+{
+    __shared__ double red[kThreads / 64];
+    double acc_m = 0.0, acc_l = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * kThreads) {
+        const float t = a.target[i], v = a.value[i];
+        if (a.mag_weight > 0.0f) { const float d = t - v; acc_m += a.l2 ? (double)(d * d) : (double)fabsf(d); }
+        if (a.logmag_weight > 0.0f) { const float d = safe_logf(t, a.eps) - safe_logf(v, a.eps); acc_l += a.l2 ? (double)(d * d) : (double)fabsf(d); }
+    }
+    double acc = (double)a.mag_weight * acc_m + (double)a.logmag_weight * acc_l;
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) tot += red[w];
+        a.partial[blockIdx.x] = tot;
+    }
+}
+
+__global__ void spec_distance_finish_kernel(const DistArgs a)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < a.n_partial; ++i) tot += a.partial[i];
+        a.out[0] = (float)(tot / (double)a.count);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void spec_distance_backward_kernel(const DistArgs a)
+{
+    const float gs = a.upstream[0] * a.grad_scale / (float)a.count;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * kThreads) {
+        const float t = a.target[i], v = a.value[i];
+        float gt = 0.0f, gv = 0.0f;   // d(distance * count)/dt, /dv
+        if (a.mag_weight > 0.0f) {
+            const float d = t - v;
+            const float g = a.l2 ? 2.0f * d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));   // torch: sgn(0) = 0
+            gt += a.mag_weight * g; gv -= a.mag_weight * g;
+        }
+        if (a.logmag_weight > 0.0f) {
+            const float d = safe_logf(t, a.eps) - safe_logf(v, a.eps);
+            const float g = a.l2 ? 2.0f * d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+            gt += (t <= a.eps) ? 0.0f : a.logmag_weight * g / t;    // where(x <= eps, eps, x): no gradient below eps
+            gv -= (v <= a.eps) ? 0.0f : a.logmag_weight * g / v;
+        }
+        if (a.grad_target) a.grad_target[i] = gs * gt;
+        if (a.grad_value) a.grad_value[i] = gs * gv;
+    }
+}
+
+constexpr int kDistBlocks = 1024;
+
 static int ilog2_exact(int v)
 {
     int l = 0;
@@ -342,6 +413,45 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     const int64_t total = batch * samples;
     const int grid2 = (int)((total + kThreads - 1) / kThreads < 256 * 32 ? (total + kThreads - 1) / kThreads : 256 * 32);
     hipLaunchKernelGGL(stft_overlap_add_kernel, dim3(grid2), dim3(kThreads), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+size_t sot_spec_distance_workspace_bytes(void) { return sizeof(double) * (size_t)sot_stft::kDistBlocks; }
+
+int sot_spec_distance_forward(const float* target, const float* value, int64_t count, float mag_weight, float logmag_weight,
+                              float eps, int l2, float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    using namespace sot_stft;
+    if (count < 1) return SOT_ERR_BAD_SHAPE;
+    if (target == nullptr || value == nullptr || out == nullptr || workspace == nullptr) return SOT_ERR_NULL_POINTER;
+    if (workspace_bytes < sot_spec_distance_workspace_bytes()) return SOT_ERR_WORKSPACE;
+    DistArgs a{};
+    a.target = target; a.value = value; a.count = count; a.mag_weight = mag_weight; a.logmag_weight = logmag_weight; a.eps = eps;
+    a.l2 = l2; a.partial = reinterpret_cast<double*>(workspace); a.out = out;
+    const int64_t need = (count + kThreads - 1) / kThreads;
+    a.n_partial = (int)(need < kDistBlocks ? need : kDistBlocks);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(spec_distance_partial_kernel, dim3(a.n_partial), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(spec_distance_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+int sot_spec_distance_backward(const float* target, const float* value, int64_t count, float mag_weight, float logmag_weight,
+                               float eps, int l2, const float* upstream, float grad_scale, float* grad_target, float* grad_value,
+                               void* stream)
+{
+    using namespace sot_stft;
+    if (count < 1) return SOT_ERR_BAD_SHAPE;
+    if (target == nullptr || value == nullptr || upstream == nullptr) return SOT_ERR_NULL_POINTER;
+    if (grad_target == nullptr && grad_value == nullptr) return SOT_OK;
+    DistArgs a{};
+    a.target = target; a.value = value; a.count = count; a.mag_weight = mag_weight; a.logmag_weight = logmag_weight; a.eps = eps;
+    a.l2 = l2; a.upstream = upstream; a.grad_scale = grad_scale; a.grad_target = grad_target; a.grad_value = grad_value;
+    const int64_t need = (count + kThreads - 1) / kThreads;
+    const int grid = (int)(need < 256 * 32 ? need : 256 * 32);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(spec_distance_backward_kernel, dim3(grid), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

@@ -15,7 +15,7 @@ import torch
 
 from . import _native as nat
 
-__all__ = ["Wasserstein1D", "wasserstein_1d", "wasserstein_1d_csr", "quantile_function", "MixOfLosses", "safe_divide"]
+__all__ = ["Wasserstein1D", "wasserstein_1d", "wasserstein_1d_csr", "quantile_function", "MixOfLosses", "MSSLoss", "safe_divide"]
 
 FLAG_PRENORMALIZED = 16  # weights are used as given (the functional form wasserstein_1d)
 
@@ -261,6 +261,95 @@ class Wasserstein1D(torch.nn.Module):
             return _RowMean.apply(loss)  # torch.mean over every row -> 0-d tensor (losses.py:211)
         loss = loss.reshape(original_shape)
         return torch.mean(loss, dim=dims)
+
+
+class _MultiScaleSpectral(torch.autograd.Function):
+    """MSSLoss behind ONE autograd node: per FFT size two STFT-magnitude kernels and the spectral-distance kernels
+    (include/sot_hip.h: sot_stft_mag_*, sot_spec_distance_*); the backward walks the scales again (distance backward ->
+    STFT backward) and accumulates the audio gradients."""
+
+    @staticmethod
+    def forward(ctx, target_audio, audio, fft_sizes, mag_weight, logmag_weight, l2):
+        from . import spectra
+        target_audio, audio = target_audio.contiguous(), audio.contiguous()
+        total = None
+        saved = []
+        for size in fft_sizes:
+            hop = int(size * (1.0 - 0.75))                      # compute_mag's default overlap (features.py:214-216)
+            win = spectra._cached_window(None, size, audio.device)   # window=None -> hann (features.py:203-204)
+            t = nat.stft_mag_forward(target_audio, win, size, hop)
+            v = nat.stft_mag_forward(audio, win, size, hop)
+            d = nat.spec_distance_forward(t, v, mag_weight, logmag_weight, 1e-5, l2)
+            total = d if total is None else total + d
+            saved += [t, v]
+        ctx.save_for_backward(target_audio, audio, *saved)
+        ctx.cfg = (tuple(fft_sizes), mag_weight, logmag_weight, l2)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import spectra
+        target_audio, audio, *saved = ctx.saved_tensors
+        fft_sizes, mag_weight, logmag_weight, l2 = ctx.cfg
+        need_t, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = g.float().reshape(1)
+        grad_t = torch.zeros_like(target_audio) if need_t else None
+        grad_v = torch.zeros_like(audio) if need_v else None
+        for i, size in enumerate(fft_sizes):
+            hop = int(size * (1.0 - 0.75))
+            win = spectra._cached_window(None, size, audio.device)
+            t, v = saved[2 * i], saved[2 * i + 1]
+            gt, gv = nat.spec_distance_backward(t, v, mag_weight, logmag_weight, g, 1.0, 1e-5, l2, need_target=need_t, need_value=need_v)
+            if need_v:
+                grad_v += nat.stft_mag_backward(audio, win, size, hop, gv)
+            if need_t:
+                grad_t += nat.stft_mag_backward(target_audio, win, size, hop, gt)
+        return grad_t, grad_v, None, None, None, None
+
+
+class MSSLoss(torch.nn.Module):
+    """Multi-scale spectrogram loss, the reference's `losses.MSSLoss` (losses.py:365-425): for each FFT
+    size the magnitude STFT (hann window, 75 % overlap, end-padded, normalized: features.compute_mag) of target and estimate,
+    `mag_weight * mean D(t - v) + logmag_weight * mean D(safe_log t - safe_log v)` with D = |.| ('L1') or (.)^2 ('L2'),
+    summed over the sizes.  On the GPU everything runs in HIP kernels behind one autograd node; `dims` other than None, FFT
+    sizes the kernels do not cover and CPU tensors take the same composition on torch ops."""
+
+    def __init__(self, fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type="L1", mag_weight=0.0, logmag_weight=0.0):
+        super().__init__()
+        self.fft_sizes = tuple(fft_sizes)
+        self.loss_type = loss_type
+        self.mag_weight = mag_weight
+        self.logmag_weight = logmag_weight
+
+    def forward(self, target_audio, audio, **kwargs):
+        from . import spectra
+        kind = self.loss_type.upper()
+        if kind not in ("L1", "L2"):
+            raise ValueError("Loss type ({}), must be " '"L1", "L2" '.format(kind))   # losses.py:36
+        dims = kwargs.get("dims", None)
+        native_ok = (audio.is_cuda and target_audio.is_cuda and dims is None and audio.ndim == 2 and audio.shape == target_audio.shape and
+                     (self.mag_weight > 0 or self.logmag_weight > 0) and
+                     all(spectra.hip_stft_supported(s, int(s * 0.25), audio.shape[1]) for s in self.fft_sizes))
+        if native_ok:
+            return _MultiScaleSpectral.apply(target_audio.float(), audio.float(), self.fft_sizes, float(self.mag_weight),
+                                             float(self.logmag_weight), kind == "L2")
+        loss = 0.0
+        for size in self.fft_sizes:
+            hop = int(size * (1.0 - 0.75))
+            t = spectra.stft_magnitude(target_audio, size, hop, None).permute(0, 2, 1)   # [batch, freq, frames] as compute_mag
+            v = spectra.stft_magnitude(audio, size, hop, None).permute(0, 2, 1)
+            for weight, a, b in ((self.mag_weight, t, v), (self.logmag_weight, _safe_log(t), _safe_log(v))):
+                if weight > 0:
+                    diff = a - b
+                    red = list(range(diff.ndim)) if dims is None else dims
+                    loss = loss + weight * (torch.mean(torch.abs(diff), dim=red) if kind == "L1" else torch.mean(diff ** 2, dim=red))
+        return loss
+
+
+def _safe_log(x, eps=1e-5):
+    """utils.py:145-151."""
+    e = torch.tensor(eps, device=x.device)
+    return torch.log(torch.where(x <= e, e, x))
 
 
 class MixOfLosses(torch.nn.Module):

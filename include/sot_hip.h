@@ -184,6 +184,20 @@ int sot_stft_mag_backward(const float *audio, int64_t batch, int64_t samples, in
                           const float *window, int n_fft, int hop, const float *grad_mag, float *grad_audio,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Spectral distance of the reference's MSSLoss (losses.py:365-425 with mean_difference
+ * losses.py:7-36 and safe_log utils.py:145-151) over `count` magnitudes target[i], value[i]:
+ *   out[0] = mag_weight * mean(D(t - v)) + logmag_weight * mean(D(slog t - slog v)),  D = |.| (l2 == 0) or (.)^2,
+ *   slog(x) = log(x <= eps ? eps : x).  Deterministic (fixed-order fp64 partial sums in the caller-owned workspace). */
+size_t sot_spec_distance_workspace_bytes(void);
+int sot_spec_distance_forward(const float *target, const float *value, int64_t count, float mag_weight,
+                              float logmag_weight, float eps, int l2, float *out, void *workspace,
+                              size_t workspace_bytes, void *stream);
+/* gradients w.r.t. target and/or value (either may be NULL) given d(loss)/d(out) as a one-element device tensor times
+ * grad_scale; |.|' (0) = 0 and no gradient through slog below eps, as torch */
+int sot_spec_distance_backward(const float *target, const float *value, int64_t count, float mag_weight,
+                               float logmag_weight, float eps, int l2, const float *upstream, float grad_scale,
+                               float *grad_target, float *grad_value, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

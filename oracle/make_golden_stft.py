@@ -45,6 +45,17 @@ def main():
                     f"{tag}_loss": loss.detach().numpy(), f"{tag}_grad_audio_y": g_audio.numpy(),
                     f"{tag}_grad_sum_mag": g_sum.numpy()})
         print(tag, n_fft, hop, n_samples, tuple(sx.shape), float(loss))
+    # MSSLoss (losses.py:365-425): scalar and gradient w.r.t. the estimate's audio, paper setting (mag only)
+    # and with the log-magnitude term / L2
+    ax, ay = harmonic_audio_pair(nb=2, seed=77, n_samples=4096)
+    out["mss_audio_x"], out["mss_audio_y"] = ax.numpy(), ay.numpy()
+    for tag, kw in (("paper", dict(mag_weight=1.0, logmag_weight=0.0)), ("both", dict(mag_weight=1.0, logmag_weight=0.5)),
+                    ("l2", dict(mag_weight=0.7, logmag_weight=0.3, loss_type="L2"))):
+        ay_g = ay.clone().requires_grad_(True)
+        val = losses.MSSLoss(**kw)(ax, ay_g)
+        (gr,) = torch.autograd.grad(val, [ay_g])
+        out[f"mss_{tag}_loss"], out[f"mss_{tag}_grad_y"] = val.detach().numpy(), gr.numpy()
+        print("MSSLoss", tag, float(val))
     np.savez_compressed(os.path.join(OUT, "stft_chain.npz"), **out)
     print("wrote", os.path.join(OUT, "stft_chain.npz"), os.path.getsize(os.path.join(OUT, "stft_chain.npz")) / 1e6, "MB")
 

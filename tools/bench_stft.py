@@ -30,3 +30,21 @@ for n_fft, hop in ((2048, 256), (512, 128)):
     out_mb = 256 * frames * bins * 4 / 1e6
     print(f"n_fft {n_fft} hop {hop}: {256 * frames} frames, {out_mb:.1f} MB of magnitudes: forward HIP {th:7.1f} us  torch {tt:7.1f} us | "
           f"forward+backward (incl. autograd) HIP {bh:7.1f} us  torch {bt:7.1f} us")
+
+# MSSLoss (6 FFT sizes, magnitude L1: the paper's setting), forward + backward w.r.t. the estimate: HIP module vs the same
+# composition on torch.stft
+from sot_amd.losses import MSSLoss
+est = spectra.harmonic_batch(256, generator=g, device=dev)
+mss = MSSLoss(mag_weight=1.0)
+def mss_hip():
+    e = est.detach().requires_grad_(True)
+    mss(audio, e).backward()
+def mss_torch():
+    e = est.detach().requires_grad_(True)
+    loss = 0.0
+    for size in mss.fft_sizes:
+        t = spectra.stft_magnitude_torch(audio, size, size // 4, None)
+        v = spectra.stft_magnitude_torch(e, size, size // 4, None)
+        loss = loss + (t - v).abs().mean()
+    loss.backward()
+print(f"MSSLoss fwd+bwd, 256 clips x 4096 samples, 6 scales: HIP {ev(mss_hip, 20, 10):7.1f} us   torch.stft composition {ev(mss_torch, 20, 10):7.1f} us")
