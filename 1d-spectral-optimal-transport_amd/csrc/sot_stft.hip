@@ -40,17 +40,18 @@ __device__ __forceinline__ void build_twiddles(float2* tw, int n)
     }
 }
 
-// In-place decimation-in-time FFT of n = 2^logn points held in LDS in BIT-REVERSED order on entry, natural order on exit.
+// In-place decimation-in-time FFT of n = 2^logn points held in LDS in BIT-REVERSED order on entry, natural order on exit,
+// executed by the `nthr` threads lid = 0 .. nthr-1 of one frame slot (a workgroup holds kThreads / nthr slots, each with
+// its own z; the barriers are workgroup-wide, every slot runs the same passes).
 // Two radix-2 stages are executed per pass (a radix-4 butterfly on the elements i0, i0+h, i0+2h, i0+3h: the same
 // operations, in the same order per element, as two separate stages -- half the LDS round trips and barriers); an odd
 // logn starts with one plain radix-2 stage.  inverse: conjugate twiddles (no 1/n).  Ends with a barrier.
-template <int T>
-__device__ __forceinline__ void fft_inplace(float2* z, const float2* tw, int n, int logn, bool inverse)
+__device__ __forceinline__ void fft_inplace(float2* z, const float2* tw, int n, int logn, bool inverse, int lid, int nthr)
 {
     int s = 1;
     if (logn & 1) {  // stage 1: half = 1, twiddle 1
         __syncthreads();
-        for (int j = threadIdx.x; j < n / 2; j += T) {
+        for (int j = lid; j < n / 2; j += nthr) {
             const float2 a = z[2 * j], b = z[2 * j + 1];
             z[2 * j] = make_float2(a.x + b.x, a.y + b.y);
             z[2 * j + 1] = make_float2(a.x - b.x, a.y - b.y);
@@ -62,7 +63,7 @@ __device__ __forceinline__ void fft_inplace(float2* z, const float2* tw, int n, 
         const int t1 = n >> s;            // stage s:     exp(-2 pi i pos / (2h)) = T[pos * n / (2h)]
         const int t2 = n >> (s + 1);      // stage s + 1: exp(-2 pi i pos / (4h)) = T[pos * n / (4h)]
         __syncthreads();
-        for (int j = threadIdx.x; j < n / 4; j += T) {
+        for (int j = lid; j < n / 4; j += nthr) {
             const int pos = j & (h - 1);
             const int i0 = ((j >> (s - 1)) << (s + 1)) + pos;
             float2 w1 = tw[pos * t1], w2 = tw[pos * t2];
@@ -88,6 +89,7 @@ __device__ __forceinline__ int bitrev(int v, int logn) { return (int)(__brev((un
 struct StftArgs {
     const float* audio; int64_t batch, samples, row_stride;
     const float* window; int n_fft, logm, hop; int64_t frames;   // logm = log2(n_fft / 2)
+    int tpf;                    // threads per frame slot: max(16, n_fft / 8); a workgroup holds kThreads / tpf slots
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
     float* grad_audio;          // backward output [batch, samples] (contiguous)
@@ -98,7 +100,8 @@ struct StftArgs {
 // The frames are REAL, so each one is transformed by a complex FFT of HALF its length m = n_fft/2 on the packed signal
 // z[i] = v[2i] + i v[2i+1]:   with Ze = (Z_k + conj(Z_{m-k})) / 2, Zo = -i/2 (Z_k - conj(Z_{m-k})), W = exp(-2 pi i k / n):
 //   X_k = Ze + W Zo,   X_{m-k} = conj(Ze - W Zo)      (k = 0 .. m/2; Z_m := Z_0)
-// LDS: z [m] | FFT twiddles exp(-2 pi i k / m) [m/2] | W_n^k [m/2 + 1].
+// LDS: z [slots][m] | FFT twiddles exp(-2 pi i k / m) [m/2] | W_n^k [m/2 + 1].  Small transforms share a workgroup:
+// n_fft = 64 / 128 -> 16 frames per workgroup, 256 -> 8, 512 -> 4, 1024 -> 2, 2048 -> 1.
 template <int T>
 __device__ __forceinline__ void build_tables(float2* tw, float2* wn, int m)
 {
@@ -110,14 +113,13 @@ __device__ __forceinline__ void build_tables(float2* tw, float2* wn, int m)
     }
 }
 
-// windowed, end-padded, packed frame -> LDS in bit-reversed order
-template <int T>
-__device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, int64_t t0, float2* z, int m)
+// windowed, end-padded, packed frame -> LDS in bit-reversed order (zeros for an idle slot)
+__device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, int64_t t0, float2* z, int m, bool active, int lid, int nthr)
 {
-    for (int i = threadIdx.x; i < m; i += T) {
+    for (int i = lid; i < m; i += nthr) {
         const int64_t t = t0 + 2 * i;
-        const float v0 = (t < a.samples) ? src[t] * a.window[2 * i] : 0.0f;          // end padding: zeros (utils.py:252-275)
-        const float v1 = (t + 1 < a.samples) ? src[t + 1] * a.window[2 * i + 1] : 0.0f;
+        const float v0 = (active && t < a.samples) ? src[t] * a.window[2 * i] : 0.0f;          // end padding: zeros (utils.py:252-275)
+        const float v1 = (active && t + 1 < a.samples) ? src[t + 1] * a.window[2 * i + 1] : 0.0f;
         z[bitrev(i, a.logm)] = make_float2(v0, v1);
     }
 }
@@ -140,22 +142,30 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int n = a.n_fft, m = n / 2, nb = m + 1;
-    float2* const z = reinterpret_cast<float2*>(smem_f);
-    float2* const tw = z + m;
+    const int nthr = a.tpf, slots = kThreads / nthr;
+    const int slot = threadIdx.x / nthr, lid = threadIdx.x - slot * nthr;
+    float2* const zall = reinterpret_cast<float2*>(smem_f);
+    float2* const z = zall + slot * m;
+    float2* const tw = zall + slots * m;
     float2* const wn = tw + m / 2;
     const float scale = 1.0f / sqrtf((float)n);  // normalized=True: frame_length^-0.5
+    const int64_t total = a.batch * a.frames;
     build_tables<kThreads>(tw, wn, m);
-    for (int64_t fr = blockIdx.x; fr < a.batch * a.frames; fr += gridDim.x) {
-        const int64_t b = fr / a.frames, f = fr - b * a.frames;
-        __syncthreads();  // previous frame's reads of z are done
-        load_frame<kThreads>(a, a.audio + b * a.row_stride, f * a.hop, z, m);
-        fft_inplace<kThreads>(z, tw, m, a.logm, false);
-        float* dst = a.mag + fr * nb;
-        for (int k = threadIdx.x; k <= m / 2; k += kThreads) {
-            float2 xk, xm;
-            unpack_pair(z, wn, k, m, xk, xm);
-            dst[k] = hypotf(xk.x, xk.y) * scale;
-            dst[m - k] = hypotf(xm.x, xm.y) * scale;
+    for (int64_t base = (int64_t)blockIdx.x * slots; base < total; base += (int64_t)gridDim.x * slots) {
+        const int64_t fr = base + slot;
+        const bool active = fr < total;
+        const int64_t b = active ? fr / a.frames : 0, f = active ? fr - b * a.frames : 0;
+        __syncthreads();  // previous frames' reads of z are done
+        load_frame(a, a.audio + b * a.row_stride, f * a.hop, z, m, active, lid, nthr);
+        fft_inplace(z, tw, m, a.logm, false, lid, nthr);
+        if (active) {
+            float* dst = a.mag + fr * nb;
+            for (int k = lid; k <= m / 2; k += nthr) {
+                float2 xk, xm;
+                unpack_pair(z, wn, k, m, xk, xm);
+                dst[k] = hypotf(xk.x, xk.y) * scale;
+                dst[m - k] = hypotf(xm.x, xm.y) * scale;
+            }
         }
     }
 }
@@ -165,41 +175,47 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
 // i.e. the (unnormalised) inverse real transform of the Hermitian spectrum H_k = Zin_k / 2 (0 < k < m), H_0 = Re Zin_0,
 // H_m = Re Zin_m, again through a half-length complex transform:  G_k = (H_k + conj(H_{m-k})) + i conj(W) (H_k - conj(H_{m-k})),
 // g = IFFT_m(G) (no 1/m), y_{2i} = Re g_i, y_{2i+1} = Im g_i.
-// Pass 1 (this kernel): one workgroup per group of kFramesPerGroup consecutive frames; their windowed gradients are
+// Pass 1 (this kernel): one frame slot per group of kFramesPerGroup consecutive frames; their windowed gradients are
 // overlap-added in LDS and stored as the group's partial result.  Pass 2 (stft_overlap_add_kernel) adds, per sample, the
 // partial results of the groups that cover it in ascending group order: deterministic, no atomics.
 __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(const StftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int n = a.n_fft, m = n / 2, nb = m + 1;
-    constexpr int kPairsPerThread = (kMaxFft / 4 + kThreads) / kThreads;  // m/2 + 1 <= 513 pairs (k, m-k)
-    float2* const z = reinterpret_cast<float2*>(smem_f);
-    float2* const tw = z + m;
+    const int nthr = a.tpf, slots = kThreads / nthr;
+    const int slot = threadIdx.x / nthr, lid = threadIdx.x - slot * nthr;
+    constexpr int kPairIters = 3;   // m/2 + 1 pairs (k, m-k) over nthr >= m/4 threads
+    float2* const zall = reinterpret_cast<float2*>(smem_f);
+    float2* const z = zall + slot * m;
+    float2* const tw = zall + slots * m;
     float2* const wn = tw + m / 2;
-    float* const acc = reinterpret_cast<float*>(wn + m / 2 + 2);  // this group's overlap-added gradient [span]
+    float* const acc = reinterpret_cast<float*>(wn + m / 2 + 2) + slot * a.span;  // this group's overlap-added gradient [span]
     const float scale = 1.0f / sqrtf((float)n);
+    const int64_t total = a.batch * a.groups;
     build_tables<kThreads>(tw, wn, m);
-    for (int64_t w = blockIdx.x; w < a.batch * a.groups; w += gridDim.x) {
-        const int64_t b = w / a.groups, grp = w - b * a.groups;
+    for (int64_t base0 = (int64_t)blockIdx.x * slots; base0 < total; base0 += (int64_t)gridDim.x * slots) {
+        const int64_t w = base0 + slot;
+        const bool active = w < total;
+        const int64_t b = active ? w / a.groups : 0, grp = active ? w - b * a.groups : 0;
         const float* src = a.audio + b * a.row_stride;
         const int64_t f_begin = grp * kFramesPerGroup;
-        const int64_t f_end = min(f_begin + kFramesPerGroup, a.frames);
-        const int64_t base = f_begin * a.hop;   // first sample of the group's span
         __syncthreads();
-        for (int t = threadIdx.x; t < a.span; t += kThreads) acc[t] = 0.0f;
-        for (int64_t f = f_begin; f < f_end; ++f) {
+        for (int t = lid; t < a.span; t += nthr) acc[t] = 0.0f;
+        for (int fi = 0; fi < kFramesPerGroup; ++fi) {
+            const int64_t f = f_begin + fi;
+            const bool has = active && f < a.frames;   // idle slots / missing frames run the same passes on zeros
             const int64_t t0 = f * a.hop;
             __syncthreads();
-            load_frame<kThreads>(a, src, t0, z, m);
-            fft_inplace<kThreads>(z, tw, m, a.logm, false);
+            load_frame(a, src, t0, z, m, has, lid, nthr);
+            fft_inplace(z, tw, m, a.logm, false, lid, nthr);
             // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
-            const float* g = a.grad_mag + (b * a.frames + f) * nb;
-            float2 gk[kPairsPerThread], gm[kPairsPerThread];
+            const float* g = a.grad_mag + (b * a.frames + (has ? f : 0)) * nb;
+            float2 gk[kPairIters], gm[kPairIters];
 #pragma unroll
-            for (int r = 0; r < kPairsPerThread; ++r) {
-                const int k = threadIdx.x + r * kThreads;
+            for (int r = 0; r < kPairIters; ++r) {
+                const int k = lid + r * nthr;
                 gk[r] = make_float2(0.0f, 0.0f); gm[r] = make_float2(0.0f, 0.0f);
-                if (k <= m / 2) {
+                if (has && k <= m / 2) {
                     float2 xk, xm;
                     unpack_pair(z, wn, k, m, xk, xm);
                     const float mk = hypotf(xk.x, xk.y), mm = hypotf(xm.x, xm.y);
@@ -220,23 +236,27 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < kPairsPerThread; ++r) {
-                const int k = threadIdx.x + r * kThreads;
+            for (int r = 0; r < kPairIters; ++r) {
+                const int k = lid + r * nthr;
                 if (k <= m / 2) {
                     z[bitrev(k, a.logm)] = gk[r];
                     if (k > 0 && k < m - k) z[bitrev(m - k, a.logm)] = gm[r];
                 }
             }
-            fft_inplace<kThreads>(z, tw, m, a.logm, true);
-            const int off = (int)(t0 - base);
-            for (int i = threadIdx.x; i < m; i += kThreads) {
-                acc[off + 2 * i] += a.window[2 * i] * z[i].x * scale;
-                acc[off + 2 * i + 1] += a.window[2 * i + 1] * z[i].y * scale;
+            fft_inplace(z, tw, m, a.logm, true, lid, nthr);
+            if (has) {
+                const int off = fi * a.hop;
+                for (int i = lid; i < m; i += nthr) {
+                    acc[off + 2 * i] += a.window[2 * i] * z[i].x * scale;
+                    acc[off + 2 * i + 1] += a.window[2 * i + 1] * z[i].y * scale;
+                }
             }
         }
         __syncthreads();
-        float* dst = a.partial + w * a.span;
-        for (int t = threadIdx.x; t < a.span; t += kThreads) dst[t] = acc[t];
+        if (active) {
+            float* dst = a.partial + w * a.span;
+            for (int t = lid; t < a.span; t += nthr) dst[t] = acc[t];
+        }
     }
 }
 
@@ -342,6 +362,7 @@ static int fill_args(const float* audio, int64_t batch, int64_t samples, int64_t
     if (batch > 0 && (audio == nullptr || window == nullptr)) return SOT_ERR_NULL_POINTER;
     a->audio = audio; a->batch = batch; a->samples = samples; a->row_stride = row_stride;
     a->window = window; a->n_fft = n_fft; a->logm = logn - 1; a->hop = hop;
+    a->tpf = (n_fft / 8 > 16) ? n_fft / 8 : 16;   // threads per frame slot (n_fft / 8 radix-4 butterflies per pass)
     a->frames = (samples + hop - 1) / hop;  // utils.py:265: -(-signal_len // hop_length)
     return SOT_OK;
 }
@@ -362,8 +383,9 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     if (batch == 0) return SOT_OK;
     if (mag == nullptr) return SOT_ERR_NULL_POINTER;
     a.mag = mag;
-    const size_t lds = sizeof(float2) * ((size_t)n_fft / 2 + n_fft / 4 + n_fft / 4 + 2);
-    const int64_t work = batch * a.frames;
+    const int slots = kThreads / a.tpf, m = n_fft / 2;
+    const size_t lds = sizeof(float2) * ((size_t)slots * m + m + 2);
+    const int64_t work = (batch * a.frames + slots - 1) / slots;
     const int grid = (int)(work < 256 * 16 ? work : 256 * 16);
     (void)hipGetLastError();
     hipLaunchKernelGGL(stft_mag_forward_kernel, dim3(grid), dim3(kThreads), lds, reinterpret_cast<hipStream_t>(stream), a);
@@ -391,12 +413,13 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     if (grad_mag == nullptr || grad_audio == nullptr || workspace == nullptr) return SOT_ERR_NULL_POINTER;
     if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
     const int64_t span = n_fft + (int64_t)hop * (kFramesPerGroup - 1);
-    if (span > 16384) return SOT_ERR_UNSUPPORTED_SIZE;   // the group's gradient lives in LDS
+    if (span > 8192) return SOT_ERR_UNSUPPORTED_SIZE;   // the groups' gradients live in LDS
     a.grad_mag = grad_mag; a.grad_audio = grad_audio;
     a.partial = reinterpret_cast<float*>(workspace);
     a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
     a.span = (int)span;
-    const size_t lds = sizeof(float2) * ((size_t)n_fft / 2 + n_fft / 4 + n_fft / 4 + 2) + sizeof(float) * (size_t)span;
+    const int slots = kThreads / a.tpf, m = n_fft / 2;
+    const size_t lds = sizeof(float2) * ((size_t)slots * m + m + 2) + sizeof(float) * (size_t)slots * (size_t)span;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_partial_kernel),
@@ -404,7 +427,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
             (void)hipGetLastError();
         attr_set = true;
     }
-    const int64_t work = batch * a.groups;
+    const int64_t work = (batch * a.groups + slots - 1) / slots;
     const int grid = (int)(work < 256 * 16 ? work : 256 * 16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();

@@ -64,7 +64,7 @@ class _StftMagnitude(torch.autograd.Function):
 
 def hip_stft_supported(n_fft: int, hop: int, samples: int) -> bool:
     """Sizes the HIP kernels cover: n_fft a power of two in [64, 2048] (a group of 4 frames must fit LDS in the backward)."""
-    return 64 <= n_fft <= 2048 and (n_fft & (n_fft - 1)) == 0 and samples >= 1 and 1 <= hop and n_fft + 3 * hop <= 16384
+    return 64 <= n_fft <= 2048 and (n_fft & (n_fft - 1)) == 0 and samples >= 1 and 1 <= hop and n_fft + 3 * hop <= 8192
 
 
 def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop") -> torch.Tensor:
