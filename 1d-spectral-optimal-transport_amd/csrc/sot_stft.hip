@@ -313,13 +313,19 @@ __global__ __launch_bounds__(kThreads) void spec_distance_partial_kernel(const D
     }
 }
 
-__global__ void spec_distance_finish_kernel(const DistArgs a)
+// one workgroup: thread t adds partials t, t + 256, ... in index order, then a fixed tree over the 256 threads
+__global__ __launch_bounds__(kThreads) void spec_distance_finish_kernel(const DistArgs a)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double tot = 0.0;
-        for (int i = 0; i < a.n_partial; ++i) tot += a.partial[i];
-        a.out[0] = (float)(tot / (double)a.count);
+    __shared__ double red[kThreads];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < a.n_partial; i += kThreads) acc += a.partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) a.out[0] = (float)(red[0] / (double)a.count);
 }
 
 __global__ __launch_bounds__(kThreads) void spec_distance_backward_kernel(const DistArgs a)
@@ -456,7 +462,7 @@ int sot_spec_distance_forward(const float* target, const float* value, int64_t c
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
     hipLaunchKernelGGL(spec_distance_partial_kernel, dim3(a.n_partial), dim3(kThreads), 0, st, a);
-    hipLaunchKernelGGL(spec_distance_finish_kernel, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(spec_distance_finish_kernel, dim3(1), dim3(kThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
