@@ -55,6 +55,9 @@ EXPORTS = {
     "sot_stft_frames": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
     "sot_stft_mag_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                             _vp, _vp]),
+    "sot_oscillator_bank_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp]),
+    "sot_oscillator_bank_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp,
+                                                    _vp, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, _vp, ctypes.c_size_t, _vp]),
@@ -411,3 +414,31 @@ def spec_distance_backward(target, value, mag_weight, logmag_weight, upstream, g
                                              float(eps), int(bool(l2)), upstream.contiguous().data_ptr(), float(grad_scale), _ptr(gt), _ptr(gv),
                                              stream_ptr(target.device)))
     return gt, gv
+
+
+def oscillator_bank_forward(freq: torch.Tensor, amp: torch.Tensor, sample_rate: float) -> torch.Tensor:
+    """[batch, samples, sinusoids] envelopes -> [batch, samples] audio (sot_oscillator_bank_forward)."""
+    require_hip(freq, amp)
+    lib = load()
+    if freq.ndim != 3 or freq.shape != amp.shape:
+        raise RuntimeError("oscillator_bank_forward expects two [batch, samples, sinusoids] tensors")
+    freq, amp = freq.contiguous(), amp.contiguous()
+    batch, samples, k = freq.shape
+    audio = torch.empty(batch, samples, dtype=torch.float32, device=freq.device)
+    with _on_device(freq.device):
+        check(lib.sot_oscillator_bank_forward(freq.data_ptr(), amp.data_ptr(), batch, samples, k, float(sample_rate), audio.data_ptr(),
+                                              stream_ptr(freq.device)))
+    return audio
+
+
+def oscillator_bank_backward(freq, amp, sample_rate, grad_audio, need_freq=True, need_amp=True):
+    require_hip(freq, amp, grad_audio)
+    lib = load()
+    freq, amp, grad_audio = freq.contiguous(), amp.contiguous(), grad_audio.contiguous()
+    batch, samples, k = freq.shape
+    gf = torch.empty_like(freq) if need_freq else None
+    ga = torch.empty_like(amp) if need_amp else None
+    with _on_device(freq.device):
+        check(lib.sot_oscillator_bank_backward(freq.data_ptr(), amp.data_ptr(), batch, samples, k, float(sample_rate), grad_audio.data_ptr(),
+                                               _ptr(gf), _ptr(ga), stream_ptr(freq.device)))
+    return gf, ga

@@ -12,7 +12,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "sot_hip.hip")
 STFT_SRC = os.path.join(PKG_DIR, "csrc", "sot_stft.hip")   # the STFT-magnitude producer: its own translation unit
-DEPS = [SRC, STFT_SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
+OSC_SRC = os.path.join(PKG_DIR, "csrc", "sot_osc.hip")     # the oscillator bank
+DEPS = [SRC, STFT_SRC, OSC_SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")]
 LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 
@@ -42,9 +43,9 @@ def is_stale() -> bool:
 
 
 def _compile_part(part, extra_flags, verbose: bool) -> str:
-    if part == "stft":
-        obj = os.path.join(OBJ_DIR, "sot_stft.o")
-        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, STFT_SRC]
+    if part in ("stft", "osc"):
+        obj = os.path.join(OBJ_DIR, f"sot_{part}.o")
+        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, STFT_SRC if part == "stft" else OSC_SRC]
     else:
         obj = os.path.join(OBJ_DIR, f"sot_part{part}.o")
         cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-DSOT_PART={part}", "-c", "-o", obj, SRC]
@@ -65,7 +66,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     os.makedirs(OBJ_DIR, exist_ok=True)
     workers = max(1, min(len(PARTS), (os.cpu_count() or 2)))
     with ThreadPoolExecutor(max_workers=workers) as pool:
-        objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose), (*PARTS, "stft")))
+        objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose), (*PARTS, "stft", "osc")))
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd))

@@ -90,6 +90,38 @@ def unit_frequencies(n_fft: int, sample_rate: float, device) -> torch.Tensor:
     return (f / f.max()).float().to(device)
 
 
+class _OscillatorBank(torch.autograd.Function):
+    """sot_oscillator_bank_forward / _backward (include/sot_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, freq, amp, sample_rate):
+        from . import _native as nat
+        freq, amp = freq.contiguous(), amp.contiguous()
+        ctx.save_for_backward(freq, amp)
+        ctx.sample_rate = sample_rate
+        return nat.oscillator_bank_forward(freq, amp, sample_rate)
+
+    @staticmethod
+    def backward(ctx, grad_audio):
+        from . import _native as nat
+        freq, amp = ctx.saved_tensors
+        gf, ga = nat.oscillator_bank_backward(freq, amp, ctx.sample_rate, grad_audio.float(), need_freq=ctx.needs_input_grad[0],
+                                              need_amp=ctx.needs_input_grad[1])
+        return gf, ga, None
+
+
+def oscillator_bank(frequency_envelopes: torch.Tensor, amplitude_envelopes: torch.Tensor, sample_rate: int = 16000) -> torch.Tensor:
+    """The reference's ddsp.oscillator_bank (ddsp.py:208-263; sum_sinusoids=True, use_angular_cumsum=False): sample-wise
+    frequencies (Hz) and amplitudes [batch, samples, sinusoids] -> audio [batch, samples]; sinusoids at or above Nyquist are
+    muted.  GPU tensors run the HIP kernels (differentiable w.r.t. both envelopes), CPU tensors torch ops."""
+    f, a = frequency_envelopes.float(), amplitude_envelopes.float()
+    if f.is_cuda and f.ndim == 3 and f.shape == a.shape and f.shape[1] <= 131072 and f.shape[2] <= 1024:
+        return _OscillatorBank.apply(f, a, float(sample_rate))
+    a = torch.where(f >= sample_rate / 2.0, torch.zeros_like(a), a)
+    phases = torch.cumsum(f * (2.0 * torch.pi) / float(sample_rate), dim=1)
+    return torch.sum(a * torch.sin(phases), dim=-1)
+
+
 def harmonic_batch(batch: int, n_samples: int = 4096, sample_rate: float = 16000.0, generator=None, device="cuda"):
     """Random harmonic clips on `device`: f0 ~ U[40,1950] Hz, n_active ~ U{1..8} partials, amplitudes ~ U[0.4,1]."""
     dev = torch.device(device)

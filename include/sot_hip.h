@@ -184,6 +184,19 @@ int sot_stft_mag_backward(const float *audio, int64_t batch, int64_t samples, in
                           const float *window, int n_fft, int hop, const float *grad_mag, float *grad_audio,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Additive oscillator bank in front of the STFT in the training step: ddsp.oscillator_bank
+ * (ddsp.py:208-263 with use_angular_cumsum=False, sum_sinusoids=True) incl. remove_above_nyquist (ddsp.py:25-49):
+ *   audio[b,t] = sum_k a'[b,t,k] sin(phase[b,t,k]),  a' = (f >= sample_rate/2) ? 0 : a,
+ *   phase = cumsum_t((f * 2pi) / sample_rate)  (fp64 accumulation rounded to fp32 per sample, as ATen's CPU cumsum).
+ * freq / amp / grad_freq / grad_amp: [batch, samples, sinusoids] contiguous; audio / grad_audio: [batch, samples].
+ * samples <= 131072, sinusoids <= 1024.  Deterministic. */
+int sot_oscillator_bank_forward(const float *freq, const float *amp, int64_t batch, int64_t samples, int sinusoids,
+                                float sample_rate, float *audio, void *stream);
+/* gradients w.r.t. the envelopes (either may be NULL) given dL/d(audio) */
+int sot_oscillator_bank_backward(const float *freq, const float *amp, int64_t batch, int64_t samples, int sinusoids,
+                                 float sample_rate, const float *grad_audio, float *grad_freq, float *grad_amp,
+                                 void *stream);
+
 /* ---- Spectral distance of the reference's MSSLoss (losses.py:365-425 with mean_difference
  * losses.py:7-36 and safe_log utils.py:145-151) over `count` magnitudes target[i], value[i]:
  *   out[0] = mag_weight * mean(D(t - v)) + logmag_weight * mean(D(slog t - slog v)),  D = |.| (l2 == 0) or (.)^2,

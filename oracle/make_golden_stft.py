@@ -56,6 +56,23 @@ def main():
         (gr,) = torch.autograd.grad(val, [ay_g])
         out[f"mss_{tag}_loss"], out[f"mss_{tag}_grad_y"] = val.detach().numpy(), gr.numpy()
         print("MSSLoss", tag, float(val))
+    # oscillator bank (ddsp.py:208-263): audio and gradients w.r.t. both envelopes for seeded envelopes, one
+    # sinusoid crossing Nyquist; T = 5000 is not a multiple of the kernel's time tile
+    import ddsp  # type: ignore
+    gen = torch.Generator().manual_seed(9)
+    for tag, (nb, T, K) in (("o1", (2, 5000, 8)), ("o2", (3, 700, 3))):
+        f0 = 60 + 900 * torch.rand(nb, 1, 1, generator=gen)
+        glide = 1 + 0.2 * torch.linspace(0, 1, T).view(1, T, 1) * torch.rand(nb, 1, 1, generator=gen)
+        freq = (f0 * glide * torch.arange(1, K + 1).view(1, 1, K)).float()
+        freq[0, :, K - 1] = torch.linspace(7000, 9000, T)          # crosses sample_rate / 2
+        amp = (torch.rand(nb, T, K, generator=gen) * torch.linspace(1, 0.2, K).view(1, 1, K)).float()
+        fr, am = freq.clone().requires_grad_(True), amp.clone().requires_grad_(True)
+        audio = ddsp.oscillator_bank(fr, am, sample_rate=16000)
+        up = torch.randn(nb, T, generator=gen)
+        gf, ga = torch.autograd.grad((audio * up).sum(), [fr, am])
+        out.update({f"{tag}_freq": freq.numpy(), f"{tag}_amp": amp.numpy(), f"{tag}_audio": audio.detach().numpy(), f"{tag}_up": up.numpy(),
+                    f"{tag}_grad_freq": gf.numpy(), f"{tag}_grad_amp": ga.numpy()})
+        print("oscillator_bank", tag, tuple(audio.shape), float(audio.abs().max()))
     np.savez_compressed(os.path.join(OUT, "stft_chain.npz"), **out)
     print("wrote", os.path.join(OUT, "stft_chain.npz"), os.path.getsize(os.path.join(OUT, "stft_chain.npz")) / 1e6, "MB")
 

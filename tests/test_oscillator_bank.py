@@ -1,0 +1,88 @@
+"""Oscillator bank in front of the STFT: the HIP kernels and the CPU composition against outputs and
+autograd gradients of the reference's ddsp.oscillator_bank (fixtures from oracle/make_golden_stft.py, keys o1_*, o2_*)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from sot_amd import spectra
+
+TAGS = ("o1", "o2")
+
+
+def _fx():
+    return dict(np.load(os.path.join(GOLDEN, "stft_chain.npz")))
+
+
+def _rel(got, want):
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_cpu_composition_matches_reference(tag):
+    fx = _fx()
+    f = torch.from_numpy(fx[f"{tag}_freq"]).requires_grad_(True)
+    a = torch.from_numpy(fx[f"{tag}_amp"]).requires_grad_(True)
+    audio = spectra.oscillator_bank(f, a, 16000)
+    assert _rel(audio.detach().numpy(), fx[f"{tag}_audio"]) <= 1e-6
+    (audio * torch.from_numpy(fx[f"{tag}_up"])).sum().backward()
+    assert _rel(f.grad.numpy(), fx[f"{tag}_grad_freq"]) <= 1e-5
+    assert _rel(a.grad.numpy(), fx[f"{tag}_grad_amp"]) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_hip_oscillator_bank_matches_reference(tag):
+    fx = _fx()
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(fx[f"{tag}_freq"]).to(dev).requires_grad_(True)
+    a = torch.from_numpy(fx[f"{tag}_amp"]).to(dev).requires_grad_(True)
+    audio = spectra.oscillator_bank(f, a, 16000)
+    # phases reach a few thousand radians, where one fp32 ulp is ~2.4e-4: sin() of the SAME fp32 phase is what is compared,
+    # so the only differences are sinf's last ulp and the summation order over the sinusoids
+    assert _rel(audio.detach().cpu().numpy(), fx[f"{tag}_audio"]) <= 2e-6
+    (audio * torch.from_numpy(fx[f"{tag}_up"]).to(dev)).sum().backward()
+    assert _rel(a.grad.cpu().numpy(), fx[f"{tag}_grad_amp"]) <= 2e-6
+    assert _rel(f.grad.cpu().numpy(), fx[f"{tag}_grad_freq"]) <= 2e-5
+    # sinusoids above Nyquist are muted: no gradient reaches their amplitude
+    muted = fx[f"{tag}_freq"] >= 8000.0
+    assert muted.any() and np.all(a.grad.cpu().numpy()[muted] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,samples,k", [(1, 1, 1), (3, 2048, 4), (2, 2049, 7), (5, 4096, 60), (2, 20000, 17)])
+def test_hip_oscillator_bank_against_torch_autograd(batch, samples, k):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(samples + k)
+    f = (30 + 9000 * torch.rand(batch, samples, k, generator=g)).to(dev)
+    a = torch.rand(batch, samples, k, generator=g).to(dev)
+    up = torch.randn(batch, samples, generator=g).to(dev)
+    f1, a1 = f.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    got = spectra.oscillator_bank(f1, a1, 16000)
+    (got * up).sum().backward()
+    # the same composition in float64 on the fp32-rounded phases is not expressible; compare with the CPU composition
+    f2, a2 = f.cpu().clone().requires_grad_(True), a.cpu().clone().requires_grad_(True)
+    want = spectra.oscillator_bank(f2, a2, 16000)
+    (want * up.cpu()).sum().backward()
+    assert _rel(got.detach().cpu().numpy(), want.detach().numpy()) <= 3e-6
+    assert _rel(a1.grad.cpu().numpy(), a2.grad.numpy()) <= 3e-6
+    assert _rel(f1.grad.cpu().numpy(), f2.grad.numpy()) <= 3e-5
+    # deterministic: a second evaluation is bit-identical
+    again = spectra.oscillator_bank(f, a, 16000)
+    assert torch.equal(again, got.detach())
+
+
+@pytest.mark.gpu
+def test_hip_oscillator_bank_only_amplitude_gradient_and_errors():
+    from sot_amd import _native as nat
+    dev = torch.device("cuda:0")
+    f = torch.full((2, 300, 3), 440.0, device=dev)
+    a = torch.rand(2, 300, 3, device=dev).requires_grad_(True)
+    spectra.oscillator_bank(f, a, 16000).sum().backward()
+    assert a.grad is not None and torch.isfinite(a.grad).all()
+    with pytest.raises(RuntimeError):
+        nat.oscillator_bank_forward(f, a.detach()[:, :, :2], 16000.0)
+    with pytest.raises(RuntimeError):
+        nat.oscillator_bank_forward(f.cpu(), a.detach().cpu(), 16000.0)
