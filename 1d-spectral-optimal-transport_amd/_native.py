@@ -55,9 +55,11 @@ EXPORTS = {
     "sot_stft_frames": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
     "sot_stft_mag_forward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                             _vp, _vp]),
-    "sot_oscillator_bank_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp]),
+    "sot_oscillator_bank_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]),
+    "sot_oscillator_bank_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp,
+                                                   ctypes.c_size_t, _vp]),
     "sot_oscillator_bank_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp,
-                                                    _vp, _vp]),
+                                                    _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, _vp, ctypes.c_size_t, _vp]),
@@ -425,10 +427,18 @@ def oscillator_bank_forward(freq: torch.Tensor, amp: torch.Tensor, sample_rate: 
     freq, amp = freq.contiguous(), amp.contiguous()
     batch, samples, k = freq.shape
     audio = torch.empty(batch, samples, dtype=torch.float32, device=freq.device)
+    ws = _oscillator_workspace(lib, batch, samples, k, freq.device)
     with _on_device(freq.device):
         check(lib.sot_oscillator_bank_forward(freq.data_ptr(), amp.data_ptr(), batch, samples, k, float(sample_rate), audio.data_ptr(),
-                                              stream_ptr(freq.device)))
+                                              ws.data_ptr(), ws.numel(), stream_ptr(freq.device)))
     return audio
+
+
+def _oscillator_workspace(lib, batch, samples, k, device):
+    need = int(lib.sot_oscillator_bank_workspace_bytes(batch, samples, k))
+    if need == 0 and batch > 0:
+        raise RuntimeError(f"oscillator bank: {samples} samples x {k} sinusoids is outside what the HIP kernels take")
+    return torch.empty(max(need, 8), dtype=torch.uint8, device=device)
 
 
 def oscillator_bank_backward(freq, amp, sample_rate, grad_audio, need_freq=True, need_amp=True):
@@ -438,7 +448,8 @@ def oscillator_bank_backward(freq, amp, sample_rate, grad_audio, need_freq=True,
     batch, samples, k = freq.shape
     gf = torch.empty_like(freq) if need_freq else None
     ga = torch.empty_like(amp) if need_amp else None
+    ws = _oscillator_workspace(lib, batch, samples, k, freq.device)
     with _on_device(freq.device):
         check(lib.sot_oscillator_bank_backward(freq.data_ptr(), amp.data_ptr(), batch, samples, k, float(sample_rate), grad_audio.data_ptr(),
-                                               _ptr(gf), _ptr(ga), stream_ptr(freq.device)))
+                                               _ptr(gf), _ptr(ga), ws.data_ptr(), ws.numel(), stream_ptr(freq.device)))
     return gf, ga

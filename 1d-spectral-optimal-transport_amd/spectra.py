@@ -115,7 +115,7 @@ def oscillator_bank(frequency_envelopes: torch.Tensor, amplitude_envelopes: torc
     frequencies (Hz) and amplitudes [batch, samples, sinusoids] -> audio [batch, samples]; sinusoids at or above Nyquist are
     muted.  GPU tensors run the HIP kernels (differentiable w.r.t. both envelopes), CPU tensors torch ops."""
     f, a = frequency_envelopes.float(), amplitude_envelopes.float()
-    if f.is_cuda and f.ndim == 3 and f.shape == a.shape and f.shape[1] <= 131072 and f.shape[2] <= 1024:
+    if f.is_cuda and f.ndim == 3 and f.shape == a.shape and 1 <= f.shape[1] <= (1 << 20) and 1 <= f.shape[2] <= 512:
         return _OscillatorBank.apply(f, a, float(sample_rate))
     a = torch.where(f >= sample_rate / 2.0, torch.zeros_like(a), a)
     phases = torch.cumsum(f * (2.0 * torch.pi) / float(sample_rate), dim=1)

@@ -189,13 +189,16 @@ int sot_stft_mag_backward(const float *audio, int64_t batch, int64_t samples, in
  *   audio[b,t] = sum_k a'[b,t,k] sin(phase[b,t,k]),  a' = (f >= sample_rate/2) ? 0 : a,
  *   phase = cumsum_t((f * 2pi) / sample_rate)  (fp64 accumulation rounded to fp32 per sample, as ATen's CPU cumsum).
  * freq / amp / grad_freq / grad_amp: [batch, samples, sinusoids] contiguous; audio / grad_audio: [batch, samples].
- * samples <= 131072, sinusoids <= 1024.  Deterministic. */
+ * samples <= 2^20, sinusoids <= 512 (else SOT_ERR_UNSUPPORTED_SIZE).  Deterministic.
+ * `workspace`: device scratch of at least sot_oscillator_bank_workspace_bytes() bytes (per-segment phase carries, fp64;
+ * the forward uses the first half only); 0 is returned for sizes the kernels do not take. */
+size_t sot_oscillator_bank_workspace_bytes(int64_t batch, int64_t samples, int sinusoids);
 int sot_oscillator_bank_forward(const float *freq, const float *amp, int64_t batch, int64_t samples, int sinusoids,
-                                float sample_rate, float *audio, void *stream);
+                                float sample_rate, float *audio, void *workspace, size_t workspace_bytes, void *stream);
 /* gradients w.r.t. the envelopes (either may be NULL) given dL/d(audio) */
 int sot_oscillator_bank_backward(const float *freq, const float *amp, int64_t batch, int64_t samples, int sinusoids,
                                  float sample_rate, const float *grad_audio, float *grad_freq, float *grad_amp,
-                                 void *stream);
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Spectral distance of the reference's MSSLoss (losses.py:365-425 with mean_difference
  * losses.py:7-36 and safe_log utils.py:145-151) over `count` magnitudes target[i], value[i]:

@@ -52,7 +52,7 @@ def test_hip_oscillator_bank_matches_reference(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch,samples,k", [(1, 1, 1), (3, 2048, 4), (2, 2049, 7), (5, 4096, 60), (2, 20000, 17)])
+@pytest.mark.parametrize("batch,samples,k", [(1, 1, 1), (3, 2048, 4), (2, 2049, 7), (5, 4096, 60), (2, 20000, 17), (64, 4096, 8), (2, 700, 300), (1, 50, 512)])
 def test_hip_oscillator_bank_against_torch_autograd(batch, samples, k):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(samples + k)
