@@ -350,6 +350,11 @@ def segmented_sort(keys: torch.Tensor):
     return vals, idx
 
 
+def _aligned8(t: torch.Tensor) -> torch.Tensor:
+    """the STFT kernels read the window two taps at a time: an odd-offset view is copied to a fresh allocation"""
+    return t if t.data_ptr() % 8 == 0 else t.clone()
+
+
 def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
     """[batch, samples] fp32 on the GPU -> [batch, frames, n_fft/2+1] magnitudes (sot_stft_mag_forward)."""
     require_hip(audio, window)
@@ -358,7 +363,7 @@ def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
         raise RuntimeError("stft_mag_forward expects audio [batch, samples] and a window of n_fft samples")
     if audio.stride(1) != 1:
         audio = audio.contiguous()
-    window = window.contiguous()
+    window = _aligned8(window.contiguous())
     batch, samples = audio.shape
     frames = int(lib.sot_stft_frames(samples, hop))
     mag = torch.empty(batch, frames, n_fft // 2 + 1, dtype=torch.float32, device=audio.device)
@@ -374,7 +379,7 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
     lib = load()
     if audio.stride(1) != 1:
         audio = audio.contiguous()
-    window = window.contiguous()
+    window = _aligned8(window.contiguous())
     grad_mag = grad_mag.contiguous()
     batch, samples = audio.shape
     grad_audio = torch.empty(batch, samples, dtype=torch.float32, device=audio.device)

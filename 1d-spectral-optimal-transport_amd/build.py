@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "sot_hip.hip")
 STFT_SRC = os.path.join(PKG_DIR, "csrc", "sot_stft.hip")   # the STFT-magnitude producer: its own translation unit
 OSC_SRC = os.path.join(PKG_DIR, "csrc", "sot_osc.hip")     # the oscillator bank
-DEPS = [SRC, STFT_SRC, OSC_SRC, os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
+DEPS = [SRC, STFT_SRC, OSC_SRC, os.path.join(PKG_DIR, "csrc", "sot_stft_tables.inc"), os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")]
 LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 

@@ -23,62 +23,88 @@
 
 namespace sot_stft {
 
-constexpr int kThreads = 256;      // forward: one 256-thread workgroup per frame
-constexpr int kFramesPerGroup = 4;  // backward: one workgroup per group of consecutive frames of a clip
+constexpr int kThreads = 256;
+constexpr int kFramesPerGroup = 4;  // backward: one frame slot per group of consecutive frames of a clip
 constexpr int kMaxFft = 2048;
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+#include "sot_stft_tables.inc"      // kPassTw, kWn (csrc/gen/make_stft_tables.py)
 
-// twiddle table T[k] = exp(-2 pi i k / n), k < n/2 (accurate: sincospi)
-template <int T>
-__device__ __forceinline__ void build_twiddles(float2* tw, int n)
+typedef float v2f __attribute__((ext_vector_type(2)));   // one complex point; arithmetic maps to v_pk_*_f32
+
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) { return a.xx * b + a.yy * (v2f){-b.y, b.x}; }
+__device__ __forceinline__ v2f cconj(v2f a) { return (v2f){a.x, -a.y}; }
+__device__ __forceinline__ v2f mul_i(v2f a) { return (v2f){-a.y, a.x}; }    // a * (+i)
+__device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }   // a * (-i)
+
+// LDS index of element i of a transform buffer: one point of padding after every 32.  The bit-reversed load (lane
+// stride m/2, m/4, ...) and the stride-4 accesses of the first pass would otherwise pile 32 lanes onto two banks
+// (SQ_LDS_BANK_CONFLICT 72 % -> 37 % of the LDS cycles of the forward kernel).
+__host__ __device__ constexpr int zi(int i) { return i + (i >> 5); }
+
+// Frame geometry for n_fft = 2^(LOGM+1).  The frames are REAL, so each one is transformed by a complex FFT of HALF its
+// length m = n_fft/2 on the packed signal z[i] = v[2i] + i v[2i+1]:   with Ze = (Z_k + conj(Z_{m-k})) / 2,
+// Zo = -i/2 (Z_k - conj(Z_{m-k})), W = exp(-2 pi i k / n):   X_k = Ze + W Zo,   X_{m-k} = conj(Ze - W Zo)   (k <= m/2).
+// One frame SLOT is m/4 threads (one radix-4 butterfly each per pass; at least 16); small transforms share a workgroup:
+// n_fft = 64 / 128 -> 16 frames per workgroup, 256 -> 8, 512 -> 4, 1024 -> 2, 2048 -> 1.
+// LDS: z [slots][zi(m)] | per-pass FFT twiddles [m] | W_n^k [m/2 + 2]  (| backward: overlap-add buffers [slots][span]).
+template <int LOGM>
+struct Geo {
+    static constexpr int logm = LOGM, m = 1 << LOGM, n = 2 * m, nb = m + 1;
+    static constexpr int tpf = (m / 4 > 16) ? m / 4 : 16;
+    static constexpr int slots = kThreads / tpf;
+    static constexpr int zpoints = zi(m);
+    static constexpr int table_points = m + m / 2 + 2;
+    static constexpr size_t lds_points = (size_t)slots * zpoints + table_points;
+};
+
+// twiddles from the constant tables (L2-resident) into LDS: tw[2 (h - 1) + pos] = exp(-2 pi i pos / 2h),
+// tw[2 (h - 1) + h + pos] = exp(-2 pi i pos / 4h) for every pass half size h <= m/4;  wn[k] = exp(-2 pi i k / n)
+template <int LOGM>
+__device__ __forceinline__ void load_tables(v2f* tw, v2f* wn)
 {
-    for (int k = threadIdx.x; k < n / 2; k += T) {
-        float s, c;
-        sincospif(2.0f * (float)k / (float)n, &s, &c);
-        tw[k] = make_float2(c, -s);
-    }
+    using G = Geo<LOGM>;
+    for (int i = threadIdx.x; i < G::m - 2; i += kThreads) { const float2 t = kPassTw[i]; tw[i] = (v2f){t.x, t.y}; }
+    for (int k = threadIdx.x; k <= G::m / 2; k += kThreads) { const float2 t = kWn[k << (10 - LOGM)]; wn[k] = (v2f){t.x, t.y}; }
 }
 
-// In-place decimation-in-time FFT of n = 2^logn points held in LDS in BIT-REVERSED order on entry, natural order on exit,
-// executed by the `nthr` threads lid = 0 .. nthr-1 of one frame slot (a workgroup holds kThreads / nthr slots, each with
-// its own z; the barriers are workgroup-wide, every slot runs the same passes).
-// Two radix-2 stages are executed per pass (a radix-4 butterfly on the elements i0, i0+h, i0+2h, i0+3h: the same
-// operations, in the same order per element, as two separate stages -- half the LDS round trips and barriers); an odd
-// logn starts with one plain radix-2 stage.  inverse: conjugate twiddles (no 1/n).  Ends with a barrier.
-__device__ __forceinline__ void fft_inplace(float2* z, const float2* tw, int n, int logn, bool inverse, int lid, int nthr)
+// In-place decimation-in-time FFT of m = 2^LOGM points held in LDS (element i at z[zi(i)]) in BIT-REVERSED order on
+// entry, natural order on exit, executed by the tpf threads lid = 0 .. tpf-1 of one frame slot (the barriers are
+// workgroup-wide, every slot runs the same passes).  Two radix-2 stages are executed per pass (a radix-4 butterfly on the
+// elements i0, i0+h, i0+2h, i0+3h: the same operations, in the same order per element, as two separate stages -- half
+// the LDS round trips and barriers); an odd LOGM starts with one plain radix-2 stage.  INVERSE: conjugate twiddles
+// (no 1/m).  Ends with a barrier.
+template <int LOGM, bool INVERSE>
+__device__ __forceinline__ void fft_inplace(v2f* z, const v2f* tw, int lid)
 {
-    int s = 1;
-    if (logn & 1) {  // stage 1: half = 1, twiddle 1
+    using G = Geo<LOGM>;
+    if (LOGM & 1) {  // stage 1: half = 1, twiddle 1
         __syncthreads();
-        for (int j = lid; j < n / 2; j += nthr) {
-            const float2 a = z[2 * j], b = z[2 * j + 1];
-            z[2 * j] = make_float2(a.x + b.x, a.y + b.y);
-            z[2 * j + 1] = make_float2(a.x - b.x, a.y - b.y);
+        for (int j = lid; j < G::m / 2; j += G::tpf) {
+            const int p0 = zi(2 * j), p1 = zi(2 * j + 1);
+            const v2f a = z[p0], b = z[p1];
+            z[p0] = a + b;
+            z[p1] = a - b;
         }
-        s = 2;
     }
-    for (; s <= logn; s += 2) {
+#pragma unroll
+    for (int s = (LOGM & 1) ? 2 : 1; s <= LOGM; s += 2) {
         const int h = 1 << (s - 1);       // half size of stage s; stage s+1 has half size 2h
-        const int t1 = n >> s;            // stage s:     exp(-2 pi i pos / (2h)) = T[pos * n / (2h)]
-        const int t2 = n >> (s + 1);      // stage s + 1: exp(-2 pi i pos / (4h)) = T[pos * n / (4h)]
         __syncthreads();
-        for (int j = lid; j < n / 4; j += nthr) {
+        for (int j = lid; j < G::m / 4; j += G::tpf) {
             const int pos = j & (h - 1);
             const int i0 = ((j >> (s - 1)) << (s + 1)) + pos;
-            float2 w1 = tw[pos * t1], w2 = tw[pos * t2];
-            if (inverse) { w1.y = -w1.y; w2.y = -w2.y; }
-            const float2 a = z[i0], b = cmul(z[i0 + h], w1), c = z[i0 + 2 * h], d = cmul(z[i0 + 3 * h], w1);
-            const float2 a1 = make_float2(a.x + b.x, a.y + b.y), b1 = make_float2(a.x - b.x, a.y - b.y);
-            const float2 c1 = make_float2(c.x + d.x, c.y + d.y), d1 = make_float2(c.x - d.x, c.y - d.y);
-            const float2 c2 = cmul(c1, w2);
+            const int p0 = zi(i0), p1 = zi(i0 + h), p2 = zi(i0 + 2 * h), p3 = zi(i0 + 3 * h);
+            v2f w1 = tw[2 * (h - 1) + pos], w2 = tw[2 * (h - 1) + h + pos];
+            if (INVERSE) { w1 = cconj(w1); w2 = cconj(w2); }
+            const v2f a = z[p0], b = cmul(z[p1], w1), c = z[p2], d = cmul(z[p3], w1);
+            const v2f a1 = a + b, b1 = a - b, c1 = c + d, d1 = c - d;
+            const v2f c2 = cmul(c1, w2);
             // exp(-2 pi i (pos + h) / (4h)) = w2 * (-i)  (forward),  w2 * (+i)  (inverse)
-            const float2 w3 = inverse ? make_float2(-w2.y, w2.x) : make_float2(w2.y, -w2.x);
-            const float2 d2 = cmul(d1, w3);
-            z[i0] = make_float2(a1.x + c2.x, a1.y + c2.y);
-            z[i0 + 2 * h] = make_float2(a1.x - c2.x, a1.y - c2.y);
-            z[i0 + h] = make_float2(b1.x + d2.x, b1.y + d2.y);
-            z[i0 + 3 * h] = make_float2(b1.x - d2.x, b1.y - d2.y);
+            const v2f d2 = cmul(d1, INVERSE ? mul_i(w2) : mul_mi(w2));
+            z[p0] = a1 + c2;
+            z[p2] = a1 - c2;
+            z[p1] = b1 + d2;
+            z[p3] = b1 - d2;
         }
     }
     __syncthreads();
@@ -89,7 +115,6 @@ __device__ __forceinline__ int bitrev(int v, int logn) { return (int)(__brev((un
 struct StftArgs {
     const float* audio; int64_t batch, samples, row_stride;
     const float* window; int n_fft, logm, hop; int64_t frames;   // logm = log2(n_fft / 2)
-    int tpf;                    // threads per frame slot: max(16, n_fft / 8); a workgroup holds kThreads / tpf slots
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
     float* grad_audio;          // backward output [batch, samples] (contiguous)
@@ -97,75 +122,77 @@ struct StftArgs {
     int64_t groups; int span;   // span = n_fft + hop * (kFramesPerGroup - 1)
 };
 
-// The frames are REAL, so each one is transformed by a complex FFT of HALF its length m = n_fft/2 on the packed signal
-// z[i] = v[2i] + i v[2i+1]:   with Ze = (Z_k + conj(Z_{m-k})) / 2, Zo = -i/2 (Z_k - conj(Z_{m-k})), W = exp(-2 pi i k / n):
-//   X_k = Ze + W Zo,   X_{m-k} = conj(Ze - W Zo)      (k = 0 .. m/2; Z_m := Z_0)
-// LDS: z [slots][m] | FFT twiddles exp(-2 pi i k / m) [m/2] | W_n^k [m/2 + 1].  Small transforms share a workgroup:
-// n_fft = 64 / 128 -> 16 frames per workgroup, 256 -> 8, 512 -> 4, 1024 -> 2, 2048 -> 1.
-template <int T>
-__device__ __forceinline__ void build_tables(float2* tw, float2* wn, int m)
-{
-    build_twiddles<T>(tw, m);
-    for (int k = threadIdx.x; k <= m / 2; k += T) {
-        float s, c;
-        sincospif((float)k / (float)m, &s, &c);   // 2 pi k / n = pi k / m
-        wn[k] = make_float2(c, -s);
-    }
-}
-
 // windowed, end-padded, packed frame -> LDS in bit-reversed order (zeros for an idle slot)
-__device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, int64_t t0, float2* z, int m, bool active, int lid, int nthr)
+template <int LOGM>
+__device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, int64_t t0, v2f* z, bool active, int lid)
 {
-    for (int i = lid; i < m; i += nthr) {
+    using G = Geo<LOGM>;
+    const float2* win = reinterpret_cast<const float2*>(a.window);   // 8-byte aligned (checked by the host)
+    const bool inside = active && t0 + G::n <= a.samples;            // the whole frame lies inside the clip
+#pragma unroll
+    for (int i = lid; i < G::m; i += G::tpf) {
         const int64_t t = t0 + 2 * i;
-        const float v0 = (active && t < a.samples) ? src[t] * a.window[2 * i] : 0.0f;          // end padding: zeros (utils.py:252-275)
-        const float v1 = (active && t + 1 < a.samples) ? src[t + 1] * a.window[2 * i + 1] : 0.0f;
-        z[bitrev(i, a.logm)] = make_float2(v0, v1);
+        const float2 w = win[i];
+        float v0, v1;
+        if (inside) {
+            v0 = src[t] * w.x; v1 = src[t + 1] * w.y;
+        } else {                                                      // end padding: zeros (utils.py:252-275)
+            v0 = (active && t < a.samples) ? src[t] * w.x : 0.0f;
+            v1 = (active && t + 1 < a.samples) ? src[t + 1] * w.y : 0.0f;
+        }
+        z[zi(bitrev(i, LOGM))] = (v2f){v0, v1};
     }
 }
 
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-
-// spectrum bins k and m-k of the real frame from the packed transform (see above)
-__device__ __forceinline__ void unpack_pair(const float2* z, const float2* wn, int k, int m, float2& xk, float2& xm)
+// |x| as torch's abs(complex) gives it (hypot): sqrt(re^2 + im^2) wherever the squares stay normal (a correctly rounded
+// sqrt of a sum that is good to 1 ulp); the scaled hypotf when any lane of the wave holds a tiny or huge value
+__device__ __forceinline__ float magnitude(v2f x)
 {
-    const float2 zk = z[k], zm = z[(m - k) & (m - 1)];
-    const float2 ze = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-    const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);          // Z_k - conj(Z_{m-k})
-    const float2 zo = make_float2(0.5f * d.y, -0.5f * d.x);          // -i/2 * d
-    const float2 wz = cmul(wn[k], zo);
-    xk = make_float2(ze.x + wz.x, ze.y + wz.y);
-    xm = make_float2(ze.x - wz.x, -(ze.y - wz.y));
+    const float s = fmaf(x.x, x.x, x.y * x.y);
+    const bool plain = (s > 1e-30f && s < 1e30f) || (x.x == 0.0f && x.y == 0.0f);
+    if (__builtin_expect(__ballot(!plain) != 0ull, 0)) return hypotf(x.x, x.y);
+    return sqrtf(s);
 }
 
+// spectrum bins k and m-k of the real frame from the packed transform (see Geo)
+template <int LOGM>
+__device__ __forceinline__ void unpack_pair(const v2f* z, const v2f* wn, int k, v2f& xk, v2f& xm)
+{
+    constexpr int m = 1 << LOGM;
+    const v2f zk = z[zi(k)], zm = z[zi((m - k) & (m - 1))];
+    const v2f ze = 0.5f * (zk + cconj(zm));
+    const v2f zo = 0.5f * mul_mi(zk - cconj(zm));          // -i/2 (Z_k - conj(Z_{m-k}))
+    const v2f wz = cmul(wn[k], zo);
+    xk = ze + wz;
+    xm = cconj(ze - wz);
+}
+
+template <int LOGM>
 __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftArgs a)
 {
+    using G = Geo<LOGM>;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int n = a.n_fft, m = n / 2, nb = m + 1;
-    const int nthr = a.tpf, slots = kThreads / nthr;
-    const int slot = threadIdx.x / nthr, lid = threadIdx.x - slot * nthr;
-    float2* const zall = reinterpret_cast<float2*>(smem_f);
-    float2* const z = zall + slot * m;
-    float2* const tw = zall + slots * m;
-    float2* const wn = tw + m / 2;
-    const float scale = 1.0f / sqrtf((float)n);  // normalized=True: frame_length^-0.5
-    const int64_t total = a.batch * a.frames;
-    build_tables<kThreads>(tw, wn, m);
-    for (int64_t base = (int64_t)blockIdx.x * slots; base < total; base += (int64_t)gridDim.x * slots) {
-        const int64_t fr = base + slot;
-        const bool active = fr < total;
-        const int64_t b = active ? fr / a.frames : 0, f = active ? fr - b * a.frames : 0;
-        __syncthreads();  // previous frames' reads of z are done
-        load_frame(a, a.audio + b * a.row_stride, f * a.hop, z, m, active, lid, nthr);
-        fft_inplace(z, tw, m, a.logm, false, lid, nthr);
-        if (active) {
-            float* dst = a.mag + fr * nb;
-            for (int k = lid; k <= m / 2; k += nthr) {
-                float2 xk, xm;
-                unpack_pair(z, wn, k, m, xk, xm);
-                dst[k] = hypotf(xk.x, xk.y) * scale;
-                dst[m - k] = hypotf(xm.x, xm.y) * scale;
-            }
+    const int slot = threadIdx.x / G::tpf, lid = threadIdx.x - slot * G::tpf;
+    v2f* const zall = reinterpret_cast<v2f*>(smem_f);
+    v2f* const z = zall + slot * G::zpoints;
+    v2f* const tw = zall + G::slots * G::zpoints;
+    v2f* const wn = tw + G::m;
+    const float scale = 1.0f / sqrtf((float)G::n);  // normalized=True: frame_length^-0.5
+    const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;   // < 2^31 (host)
+    load_tables<LOGM>(tw, wn);
+    const unsigned fr = blockIdx.x * G::slots + slot;
+    const bool active = fr < total;
+    const unsigned b = active ? fr / frames : 0u, f = active ? fr - b * frames : 0u;
+    load_frame<LOGM>(a, a.audio + (int64_t)b * a.row_stride, (int64_t)f * a.hop, z, active, lid);
+    fft_inplace<LOGM, false>(z, tw, lid);
+    if (active) {
+        float* dst = a.mag + (int64_t)fr * G::nb;
+#pragma unroll
+        for (int k = lid; k <= G::m / 2; k += G::tpf) {
+            v2f xk, xm;
+            unpack_pair<LOGM>(z, wn, k, xk, xm);
+            dst[k] = magnitude(xk) * scale;
+            dst[G::m - k] = magnitude(xm) * scale;
         }
     }
 }
@@ -178,85 +205,84 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
 // Pass 1 (this kernel): one frame slot per group of kFramesPerGroup consecutive frames; their windowed gradients are
 // overlap-added in LDS and stored as the group's partial result.  Pass 2 (stft_overlap_add_kernel) adds, per sample, the
 // partial results of the groups that cover it in ascending group order: deterministic, no atomics.
+template <int LOGM>
 __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(const StftArgs a)
 {
+    using G = Geo<LOGM>;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int n = a.n_fft, m = n / 2, nb = m + 1;
-    const int nthr = a.tpf, slots = kThreads / nthr;
-    const int slot = threadIdx.x / nthr, lid = threadIdx.x - slot * nthr;
-    constexpr int kPairIters = 3;   // m/2 + 1 pairs (k, m-k) over nthr >= m/4 threads
-    float2* const zall = reinterpret_cast<float2*>(smem_f);
-    float2* const z = zall + slot * m;
-    float2* const tw = zall + slots * m;
-    float2* const wn = tw + m / 2;
-    float* const acc = reinterpret_cast<float*>(wn + m / 2 + 2) + slot * a.span;  // this group's overlap-added gradient [span]
-    const float scale = 1.0f / sqrtf((float)n);
-    const int64_t total = a.batch * a.groups;
-    build_tables<kThreads>(tw, wn, m);
-    for (int64_t base0 = (int64_t)blockIdx.x * slots; base0 < total; base0 += (int64_t)gridDim.x * slots) {
-        const int64_t w = base0 + slot;
-        const bool active = w < total;
-        const int64_t b = active ? w / a.groups : 0, grp = active ? w - b * a.groups : 0;
-        const float* src = a.audio + b * a.row_stride;
-        const int64_t f_begin = grp * kFramesPerGroup;
+    constexpr int m = G::m;
+    const int slot = threadIdx.x / G::tpf, lid = threadIdx.x - slot * G::tpf;
+    constexpr int kPairIters = 3;   // m/2 + 1 pairs (k, m-k) over tpf >= m/4 threads
+    v2f* const zall = reinterpret_cast<v2f*>(smem_f);
+    v2f* const z = zall + slot * G::zpoints;
+    v2f* const tw = zall + G::slots * G::zpoints;
+    v2f* const wn = tw + m;
+    float* const acc = reinterpret_cast<float*>(zall + G::lds_points) + slot * a.span;  // this group's overlap-added gradient [span]
+    const float2* win = reinterpret_cast<const float2*>(a.window);
+    const float scale = 1.0f / sqrtf((float)G::n);
+    const unsigned total = (unsigned)(a.batch * a.groups), groups = (unsigned)a.groups;
+    load_tables<LOGM>(tw, wn);
+    const unsigned w = blockIdx.x * G::slots + slot;
+    const bool active = w < total;
+    const unsigned b = active ? w / groups : 0u, grp = active ? w - b * groups : 0u;
+    const float* src = a.audio + (int64_t)b * a.row_stride;
+    const int64_t f_begin = (int64_t)grp * kFramesPerGroup;
+    for (int t = lid; t < a.span; t += G::tpf) acc[t] = 0.0f;
+    for (int fi = 0; fi < kFramesPerGroup; ++fi) {
+        const int64_t f = f_begin + fi;
+        const bool has = active && f < a.frames;   // idle slots / missing frames run the same passes on zeros
+        const int64_t t0 = f * a.hop;
         __syncthreads();
-        for (int t = lid; t < a.span; t += nthr) acc[t] = 0.0f;
-        for (int fi = 0; fi < kFramesPerGroup; ++fi) {
-            const int64_t f = f_begin + fi;
-            const bool has = active && f < a.frames;   // idle slots / missing frames run the same passes on zeros
-            const int64_t t0 = f * a.hop;
-            __syncthreads();
-            load_frame(a, src, t0, z, m, has, lid, nthr);
-            fft_inplace(z, tw, m, a.logm, false, lid, nthr);
-            // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
-            const float* g = a.grad_mag + (b * a.frames + (has ? f : 0)) * nb;
-            float2 gk[kPairIters], gm[kPairIters];
+        load_frame<LOGM>(a, src, t0, z, has, lid);
+        fft_inplace<LOGM, false>(z, tw, lid);
+        // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
+        const float* g = a.grad_mag + ((int64_t)b * a.frames + (has ? f : 0)) * G::nb;
+        v2f gk[kPairIters], gm[kPairIters];
 #pragma unroll
-            for (int r = 0; r < kPairIters; ++r) {
-                const int k = lid + r * nthr;
-                gk[r] = make_float2(0.0f, 0.0f); gm[r] = make_float2(0.0f, 0.0f);
-                if (has && k <= m / 2) {
-                    float2 xk, xm;
-                    unpack_pair(z, wn, k, m, xk, xm);
-                    const float mk = hypotf(xk.x, xk.y), mm = hypotf(xm.x, xm.y);
-                    const float ck = mk > 0.0f ? g[k] / mk : 0.0f;          // torch: sgn(0) = 0
-                    const float cm = mm > 0.0f ? g[m - k] / mm : 0.0f;
-                    float2 hk = make_float2(0.5f * ck * xk.x, 0.5f * ck * xk.y);
-                    float2 hm = make_float2(0.5f * cm * xm.x, 0.5f * cm * xm.y);
-                    if (k == 0) { hk = make_float2(ck * xk.x, 0.0f); hm = make_float2(cm * xm.x, 0.0f); }   // H_0, H_m are real
-                    const float2 sk = make_float2(hk.x + hm.x, hk.y - hm.y);      // H_k + conj(H_{m-k})
-                    const float2 dk = make_float2(hk.x - hm.x, hk.y + hm.y);      // H_k - conj(H_{m-k})
-                    const float2 wk = wn[k];
-                    const float2 cw = cmul(cconj(wk), dk);                         // conj(W) d
-                    gk[r] = make_float2(sk.x - cw.y, sk.y + cw.x);                 // s + i conj(W) d
-                    // G_{m-k} = (H_{m-k} + conj(H_k)) + i (-W) (H_{m-k} - conj(H_k)) = conj(s) + i W conj(d)
-                    const float2 wd = cmul(wk, cconj(dk));
-                    gm[r] = make_float2(sk.x - wd.y, -sk.y + wd.x);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kPairIters; ++r) {
-                const int k = lid + r * nthr;
-                if (k <= m / 2) {
-                    z[bitrev(k, a.logm)] = gk[r];
-                    if (k > 0 && k < m - k) z[bitrev(m - k, a.logm)] = gm[r];
-                }
-            }
-            fft_inplace(z, tw, m, a.logm, true, lid, nthr);
-            if (has) {
-                const int off = fi * a.hop;
-                for (int i = lid; i < m; i += nthr) {
-                    acc[off + 2 * i] += a.window[2 * i] * z[i].x * scale;
-                    acc[off + 2 * i + 1] += a.window[2 * i + 1] * z[i].y * scale;
-                }
+        for (int r = 0; r < kPairIters; ++r) {
+            const int k = lid + r * G::tpf;
+            gk[r] = (v2f){0.0f, 0.0f}; gm[r] = (v2f){0.0f, 0.0f};
+            if (has && k <= m / 2) {
+                v2f xk, xm;
+                unpack_pair<LOGM>(z, wn, k, xk, xm);
+                const float mk = magnitude(xk), mm = magnitude(xm);
+                const float ck = mk > 0.0f ? g[k] / mk : 0.0f;          // torch: sgn(0) = 0
+                const float cm = mm > 0.0f ? g[m - k] / mm : 0.0f;
+                v2f hk = (0.5f * ck) * xk, hm = (0.5f * cm) * xm;
+                if (k == 0) { hk = (v2f){ck * xk.x, 0.0f}; hm = (v2f){cm * xm.x, 0.0f}; }   // H_0, H_m are real
+                const v2f sk = hk + cconj(hm);      // H_k + conj(H_{m-k})
+                const v2f dk = hk - cconj(hm);      // H_k - conj(H_{m-k})
+                const v2f wk = wn[k];
+                gk[r] = sk + mul_i(cmul(cconj(wk), dk));                 // s + i conj(W) d
+                // G_{m-k} = (H_{m-k} + conj(H_k)) + i (-W) (H_{m-k} - conj(H_k)) = conj(s) + i W conj(d)
+                gm[r] = cconj(sk) + mul_i(cmul(wk, cconj(dk)));
             }
         }
         __syncthreads();
-        if (active) {
-            float* dst = a.partial + w * a.span;
-            for (int t = lid; t < a.span; t += nthr) dst[t] = acc[t];
+#pragma unroll
+        for (int r = 0; r < kPairIters; ++r) {
+            const int k = lid + r * G::tpf;
+            if (k <= m / 2) {
+                z[zi(bitrev(k, LOGM))] = gk[r];
+                if (k > 0 && k < m - k) z[zi(bitrev(m - k, LOGM))] = gm[r];
+            }
         }
+        fft_inplace<LOGM, true>(z, tw, lid);
+        if (has) {
+            const int off = fi * a.hop;
+#pragma unroll
+            for (int i = lid; i < m; i += G::tpf) {
+                const v2f v = z[zi(i)];
+                const float2 wv = win[i];
+                acc[off + 2 * i] += wv.x * v.x * scale;
+                acc[off + 2 * i + 1] += wv.y * v.y * scale;
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        float* dst = a.partial + (int64_t)w * a.span;
+        for (int t = lid; t < a.span; t += G::tpf) dst[t] = acc[t];
     }
 }
 
@@ -366,11 +392,38 @@ static int fill_args(const float* audio, int64_t batch, int64_t samples, int64_t
     const int logn = ilog2_exact(n_fft);
     if (logn < 6 || n_fft > kMaxFft) return SOT_ERR_UNSUPPORTED_SIZE;  // 64 ... 2048, powers of two
     if (batch > 0 && (audio == nullptr || window == nullptr)) return SOT_ERR_NULL_POINTER;
+    if (reinterpret_cast<uintptr_t>(window) % 8 != 0) return SOT_ERR_BAD_SHAPE;   // the kernels read the window two taps at a time
     a->audio = audio; a->batch = batch; a->samples = samples; a->row_stride = row_stride;
     a->window = window; a->n_fft = n_fft; a->logm = logn - 1; a->hop = hop;
-    a->tpf = (n_fft / 8 > 16) ? n_fft / 8 : 16;   // threads per frame slot (n_fft / 8 radix-4 butterflies per pass)
     a->frames = (samples + hop - 1) / hop;  // utils.py:265: -(-signal_len // hop_length)
+    if (batch * a->frames > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
     return SOT_OK;
+}
+
+// launches KERNEL<log2(n_fft / 2)> with one frame slot per unit of `work`
+#define SOT_STFT_LAUNCH(KERNEL, work, extra_lds_per_slot, st, a)                                                              \
+    do {                                                                                                                      \
+        switch ((a).logm) {                                                                                                   \
+            case 5: launch_slots<5>(KERNEL<5>, work, extra_lds_per_slot, st, a); break;                                       \
+            case 6: launch_slots<6>(KERNEL<6>, work, extra_lds_per_slot, st, a); break;                                       \
+            case 7: launch_slots<7>(KERNEL<7>, work, extra_lds_per_slot, st, a); break;                                       \
+            case 8: launch_slots<8>(KERNEL<8>, work, extra_lds_per_slot, st, a); break;                                       \
+            case 9: launch_slots<9>(KERNEL<9>, work, extra_lds_per_slot, st, a); break;                                       \
+            default: launch_slots<10>(KERNEL<10>, work, extra_lds_per_slot, st, a); break;                                    \
+        }                                                                                                                     \
+    } while (0)
+
+template <int LOGM>
+static void launch_slots(void (*kernel)(const StftArgs), int64_t work, size_t extra_lds_per_slot, hipStream_t st, const StftArgs& a)
+{
+    using G = Geo<LOGM>;
+    const size_t lds = G::lds_points * sizeof(float2) + (size_t)G::slots * extra_lds_per_slot;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+    }
+    const unsigned grid = (unsigned)((work + G::slots - 1) / G::slots);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, a);
 }
 
 }  // namespace sot_stft
@@ -389,12 +442,8 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     if (batch == 0) return SOT_OK;
     if (mag == nullptr) return SOT_ERR_NULL_POINTER;
     a.mag = mag;
-    const int slots = kThreads / a.tpf, m = n_fft / 2;
-    const size_t lds = sizeof(float2) * ((size_t)slots * m + m + 2);
-    const int64_t work = (batch * a.frames + slots - 1) / slots;
-    const int grid = (int)(work < 256 * 16 ? work : 256 * 16);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(stft_mag_forward_kernel, dim3(grid), dim3(kThreads), lds, reinterpret_cast<hipStream_t>(stream), a);
+    SOT_STFT_LAUNCH(stft_mag_forward_kernel, batch * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -424,20 +473,9 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     a.partial = reinterpret_cast<float*>(workspace);
     a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
     a.span = (int)span;
-    const int slots = kThreads / a.tpf, m = n_fft / 2;
-    const size_t lds = sizeof(float2) * ((size_t)slots * m + m + 2) + sizeof(float) * (size_t)slots * (size_t)span;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_partial_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-            (void)hipGetLastError();
-        attr_set = true;
-    }
-    const int64_t work = (batch * a.groups + slots - 1) / slots;
-    const int grid = (int)(work < 256 * 16 ? work : 256 * 16);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(stft_mag_backward_partial_kernel, dim3(grid), dim3(kThreads), lds, st, a);
+    SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
     const int64_t total = batch * samples;
     const int grid2 = (int)((total + kThreads - 1) / kThreads < 256 * 32 ? (total + kThreads - 1) / kThreads : 256 * 32);
