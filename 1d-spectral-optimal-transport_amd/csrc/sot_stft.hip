@@ -3,18 +3,21 @@
 // utils.pad_for_stft, utils.py:252-275): torch.stft(center=False, normalized=True, onesided) of the end-padded signal,
 // |.|, frames-major output [batch, frames, n_fft/2 + 1].  SURVEY §8f row 1.
 //
-// Forward: one workgroup per frame.  The windowed REAL frame is packed into n_fft/2 complex points and goes through an
-// in-LDS radix-2 complex FFT of half the frame length (bit-reversed load, log2(n_fft/2) butterfly stages, twiddles from
-// LDS tables built with sincospi); the n_fft/2 + 1 bins are unpacked pairwise and reduced to hypot(re, im) / sqrt(n_fft).
-// Backward (closed form of abs o stft's autograd): per group of four consecutive frames, frame by frame, recompute the
+// Forward: one frame slot (n_fft/8 threads) per frame, kernels instantiated per transform size.  The windowed REAL frame
+// is packed into n_fft/2 complex points and goes through an in-LDS complex FFT of half the frame length (bit-reversed
+// load, two radix-2 stages per barrier-separated pass, twiddles copied into LDS from constant tables); the n_fft/2 + 1
+// bins are unpacked pairwise and reduced to |.| / sqrt(n_fft).
+// Backward (closed form of abs o stft's autograd): per group of two consecutive frames, frame by frame, recompute the
 // frame's spectrum X, form
 // Z_k = g_k X_k / |X_k| (0 where |X_k| = 0, torch's sgn(0)), inverse-transform it as a Hermitian spectrum (again a
 // half-length complex transform), multiply by window / sqrt(n_fft) and overlap-add it into the group's gradient, which
 // is kept in LDS and written once to a scratch buffer; a second kernel adds, per sample, the groups that cover it in a
 // fixed order: no atomics, deterministic.
 // HBM traffic: forward reads n_fft samples per frame (L2-resident overlap) and writes n_fft/2+1 magnitudes; backward
-// reads the audio and the magnitude gradients once, writes and re-reads the groups' partial gradients (1.4 x the audio
-// for 4 frames per group at 8 frames per sample) and writes the audio gradient once.
+// reads the audio and the magnitude gradients once, writes and re-reads the groups' partial gradients (4.5 x the audio
+// for 2 frames per group at 8 frames per sample: 19 MB for 4096 frames of 2048, L2/MALL-resident) and writes the audio
+// gradient once.  (4 frames per group: 2.75 x, but half the workgroups; the same time at n_fft 2048, 20 % slower over
+// the six scales of MSSLoss.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -24,7 +27,7 @@
 namespace sot_stft {
 
 constexpr int kThreads = 256;
-constexpr int kFramesPerGroup = 4;  // backward: one frame slot per group of consecutive frames of a clip
+constexpr int kFramesPerGroup = 2;  // backward: one frame slot per group of consecutive frames of a clip
 constexpr int kMaxFft = 2048;
 
 #include "sot_stft_tables.inc"      // kPassTw, kWn (csrc/gen/make_stft_tables.py)
