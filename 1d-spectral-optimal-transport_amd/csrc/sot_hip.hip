@@ -1408,7 +1408,7 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
     if (pr->B == 0) return SOT_OK;
     l.a.row_loss = row_loss;
     l.a.oUq = uq; l.a.oVq = vq; l.a.oQ = Q; l.a.oU = U; l.a.oV = V;
-    // row lengths with a compile-time kernel (512 / 2048 / 8192 bins, and the paper's 257 / 513 / 1025) take it
+    // row lengths with a compile-time kernel (forward_full_supports: powers of two 512 ... 8192 and n_fft/2 + 1) take it
     bool full = !l.rowpos && !quant && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && forward_full_supports(pr->n, l.vec) &&
                 !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)

@@ -105,11 +105,13 @@ def test_config2_full_size_scalars(kind, mode, manifest):
     assert abs(got - want) <= RTOL * abs(want), (got, want)
 
 
-@pytest.mark.parametrize("N,B", [(512, 1030), (2048, 520), (8192, 70)])
+@pytest.mark.parametrize("N,B", [(512, 1030), (1024, 777), (2048, 520), (4096, 130), (8192, 70)])
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0)])
 def test_full_row_kernel_matches_generic(N, B, flags, p):
     """Rows that fill their launch geometry (n == m == G*CPT) run the fully specialised forward kernel: it must agree
-    bit for bit with the generic kernel (SOT_FLAG_NO_SPECIALIZE) and, on a sample of rows, with the oracle."""
+    bit for bit with the generic kernel (SOT_FLAG_NO_SPECIALIZE) and, on a sample of rows, with the oracle.  (4096 bins:
+    the generic kernel runs 256 threads x 16 elements, the specialised one 512 x 8: the same terms, another association of
+    the row's final sum, hence a few ulp.)"""
     from oracle.inputs import gen_inputs
     from oracle import sot_oracle as so
     nat = native()
@@ -120,13 +122,16 @@ def test_full_row_kernel_matches_generic(N, B, flags, p):
     plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
     spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
     gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
-    assert torch.equal(spec, gen), float((spec - gen).abs().max())
+    if N == 4096:
+        torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
+    else:
+        assert torch.equal(spec, gen), float((spec - gen).abs().max())
     k = min(B, 24)
     want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
 
 
-@pytest.mark.parametrize("N,B", [(512, 530), (2048, 200)])
+@pytest.mark.parametrize("N,B", [(512, 530), (1024, 301), (2048, 200), (4096, 67)])
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0)])
 def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
     """The specialised backward kernel (rows with n == m == 512 / 2048) gives bit for bit the gradients of the generic
@@ -153,7 +158,7 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
         assert np.max(np.abs(got - want) / scale) <= 1e-5
 
 
-@pytest.mark.parametrize("N,B", [(257, 1031), (513, 300), (1025, 261)])
+@pytest.mark.parametrize("N,B", [(129, 1500), (257, 1031), (513, 300), (1025, 261), (2049, 133)])
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 2 | 4 | 8, 2.0), (2, 2.0)])
 @pytest.mark.parametrize("kind", ["peaky", "uniform"])
 def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
@@ -177,7 +182,7 @@ def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
 
 
-@pytest.mark.parametrize("N,B", [(257, 70), (513, 37), (1025, 29)])
+@pytest.mark.parametrize("N,B", [(129, 90), (257, 70), (513, 37), (1025, 29), (2049, 21)])
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1 | 2 | 4, 2.0), (1 | 4 | 8, 2.0), (2, 1.0)])
 def test_paper_row_lengths_backward(N, B, flags, p):
     """Backward kernel with the row length at compile time (257 / 513 / 1025 bins): gradients equal to the generic kernel's
