@@ -2,7 +2,8 @@
 
 Same names, argument meaning and error behaviour as the reference's ``losses`` module
 (/root/reference/losses.py): ``Wasserstein1D`` (:89-211), ``quantile_function`` (:214-220),
-``wasserstein_1d`` (:223-313), ``MixOfLosses`` (:346-362) and ``utils.safe_divide``
+``wasserstein_1d`` (:223-313), ``Wasserstein1DWithTransform`` (:316-343), ``MixOfLosses`` (:346-362), ``MSSLoss``
+(:365-425) and ``utils.safe_divide``
 (utils.py:135-142), so ``trainer.py:220/228``, ``metrics.py:148`` and the YAML
 ``class_path: losses.Wasserstein1D`` keep working unchanged.
 
@@ -15,7 +16,8 @@ import torch
 
 from . import _native as nat
 
-__all__ = ["Wasserstein1D", "wasserstein_1d", "wasserstein_1d_csr", "quantile_function", "MixOfLosses", "MSSLoss", "safe_divide"]
+__all__ = ["Wasserstein1D", "Wasserstein1DWithTransform", "wasserstein_1d", "wasserstein_1d_csr", "quantile_function", "MixOfLosses",
+           "MSSLoss", "safe_divide"]
 
 FLAG_PRENORMALIZED = 16  # weights are used as given (the functional form wasserstein_1d)
 
@@ -350,6 +352,47 @@ def _safe_log(x, eps=1e-5):
     """utils.py:145-151."""
     e = torch.tensor(eps, device=x.device)
     return torch.log(torch.where(x <= e, e, x))
+
+
+class Wasserstein1DWithTransform(torch.nn.Module):
+    """The reference's audio-in form (losses.py:316-343): both signals go through the transform that
+    ``features.get_transform(transform_kwargs, sample_rate)`` names, the transform's bin frequencies scaled to [0, 1]
+    become the positions of both sides, and ``Wasserstein1D`` (attribute ``wasserstein``) compares the spectra.
+    Built here for the STFT transform (``{"type": "stft", "n_fft", "hop_length", "window", "log", "sr"}``, the reference's
+    ``features.TorchSTFT``, features.py:85-113: hann window unless a scipy window name is given; defaults n_fft 1024, hop
+    256, sr 16000).  ``"cqt"`` (nnAudio) and ``"identity"`` (no bin frequencies in the reference either) raise.
+    On the GPU the STFT, the loss and their backward are the HIP kernels of spectra.training_step_slice."""
+
+    def __init__(self, p=1, fixed_x=None, require_sort=True, log_scaled_x=False, transform_kwargs=None, **kwargs):
+        super().__init__()
+        self.wasserstein = Wasserstein1D(p=p, fixed_x=fixed_x, require_sort=require_sort, log_scaled_x=log_scaled_x, **kwargs)
+        if not isinstance(transform_kwargs, dict):
+            raise AttributeError("transform_kwargs must be a dict (the reference pops 'sr' from it)")
+        tk = dict(transform_kwargs)
+        self.sr = tk.pop("sr", 16000)
+        name = tk.pop("type")
+        if name != "stft":
+            raise ValueError(f"Unknown transform {name}" if name not in ("cqt", "identity") else
+                             f"transform {name!r} is not built here (only 'stft')")
+        self.n_fft = int(tk.pop("n_fft", 1024))
+        hop_length = tk.pop("hop_length", 256)
+        self.log = bool(tk.pop("log", False))
+        self.window = tk.pop("window", None)
+        overlap = 1 - hop_length / self.n_fft                 # features.py:99, then features.py:194
+        self.hop = int(self.n_fft * (1.0 - overlap))
+        assert self.n_fft * overlap % 2.0 == 0.0              # features.py:199
+
+    def forward(self, x, y, **kwargs):
+        from . import spectra
+        if not self.log and not kwargs:
+            return spectra.training_step_slice(self.wasserstein, x, y, n_fft=self.n_fft, hop=self.hop, sample_rate=float(self.sr),
+                                               window=self.window)
+        spec_x = spectra.stft_magnitude(x, self.n_fft, self.hop, self.window)
+        spec_y = spectra.stft_magnitude(y, self.n_fft, self.hop, self.window)
+        if self.log:
+            spec_x, spec_y = _safe_log(spec_x), _safe_log(spec_y)
+        pos = spectra.unit_frequencies(self.n_fft, float(self.sr), x.device)
+        return self.wasserstein(spec_x, spec_y, x_pos=pos, y_pos=pos.clone(), **kwargs)
 
 
 class MixOfLosses(torch.nn.Module):

@@ -56,6 +56,18 @@ def main():
         (gr,) = torch.autograd.grad(val, [ay_g])
         out[f"mss_{tag}_loss"], out[f"mss_{tag}_grad_y"] = val.detach().numpy(), gr.numpy()
         print("MSSLoss", tag, float(val))
+    # Wasserstein1DWithTransform (losses.py:316-343): audio in, TorchSTFT of both signals inside the module; a plain p = 1
+    # configuration (hann window by default) and the paper's keyword set with a named window
+    ax, ay = harmonic_audio_pair(nb=3, seed=31, n_samples=3000)
+    out["wt_audio_x"], out["wt_audio_y"] = ax.numpy(), ay.numpy()
+    for tag, p, tk, kw in (("p1", 1, {"type": "stft", "n_fft": 1024, "hop_length": 256, "sr": 16000}, {}),
+                           ("paper", 2, {"type": "stft", "n_fft": 512, "hop_length": 128, "window": "flattop", "sr": 22050},
+                            dict(square_dist=True, dont_normalize=True, limit_quantile_range=True))):
+        ay_g = ay.clone().requires_grad_(True)
+        val = losses.Wasserstein1DWithTransform(p=p, transform_kwargs=dict(tk), **kw)(ax, ay_g)
+        (gr,) = torch.autograd.grad(val, [ay_g])
+        out[f"wt_{tag}_loss"], out[f"wt_{tag}_grad_y"] = val.detach().numpy(), gr.numpy()
+        print("Wasserstein1DWithTransform", tag, float(val))
     # oscillator bank (ddsp.py:208-263): audio and gradients w.r.t. both envelopes for seeded envelopes, one
     # sinusoid crossing Nyquist; T = 5000 is not a multiple of the kernel's time tile
     import ddsp  # type: ignore

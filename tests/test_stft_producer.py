@@ -120,6 +120,43 @@ def test_chain_stft_into_sot_loss_matches_reference(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,p,tk,kw", [
+    ("p1", 1, {"type": "stft", "n_fft": 1024, "hop_length": 256, "sr": 16000}, {}),
+    ("paper", 2, {"type": "stft", "n_fft": 512, "hop_length": 128, "window": "flattop", "sr": 22050},
+     dict(square_dist=True, dont_normalize=True, limit_quantile_range=True))])
+def test_wasserstein_with_transform_matches_reference(tag, p, tk, kw):
+    """losses.Wasserstein1DWithTransform: audio in, STFT inside the module; scalar and audio gradient of the reference."""
+    from gpu_util import device
+    from sot_amd.losses import Wasserstein1DWithTransform
+    fx = _fx()
+    ax = torch.as_tensor(fx["wt_audio_x"]).to(device())
+    ay = torch.as_tensor(fx["wt_audio_y"]).to(device()).requires_grad_(True)
+    mod = Wasserstein1DWithTransform(p=p, transform_kwargs=dict(tk), **kw).to(device())
+    loss = mod(ax, ay)
+    loss.backward()
+    want, gwant = float(fx[f"wt_{tag}_loss"]), fx[f"wt_{tag}_grad_y"]
+    assert abs(float(loss.detach()) - want) <= 2e-5 * abs(want)
+    # p = 1: the gradient w.r.t. a CDF level is a difference of two |.| costs that jumps where levels swap order, so
+    # last-bit differences of the spectra move single entries by ~1e-3 of the largest one (observed 2.1e-3)
+    assert np.abs(ay.grad.cpu().numpy() - gwant).max() <= 5e-3 * np.abs(gwant).max()
+    # per-call keywords take the composed path (stft_magnitude + module): the same value
+    again = mod(ax, ay.detach(), hinge=0.0) if tag == "p1" else mod(ax, ay.detach(), dont_normalize=True)
+    assert abs(float(again) - want) <= 2e-5 * abs(want)
+
+
+def test_wasserstein_with_transform_rejects_other_transforms():
+    from sot_amd.losses import Wasserstein1DWithTransform
+    with pytest.raises(ValueError):
+        Wasserstein1DWithTransform(transform_kwargs={"type": "cqt"})
+    with pytest.raises(ValueError):
+        Wasserstein1DWithTransform(transform_kwargs={"type": "wavelet"})
+    with pytest.raises(AttributeError):
+        Wasserstein1DWithTransform(transform_kwargs="stft")
+    mod = Wasserstein1DWithTransform(p=2, transform_kwargs={"type": "stft", "n_fft": 2048, "hop_length": 256}, square_dist=True)
+    assert (mod.n_fft, mod.hop, mod.sr, mod.wasserstein.p, mod.wasserstein.square_dist) == (2048, 256, 16000, 2, True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_fft,hop,samples,batch", [(2048, 256, 16000, 3), (256, 64, 777, 5), (1024, 512, 5000, 2), (64, 16, 100, 4)])
 def test_hip_stft_other_sizes_against_torch(n_fft, hop, samples, batch):
     """Long clips (many frame groups), odd lengths, hop = n_fft/2: forward and (magnitude-weighted) backward vs torch.stft."""
