@@ -39,6 +39,9 @@ EXPORTS = {
     "sot_abi_version": (ctypes.c_int, []),
     "sot_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "sot_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(SotProblem)]),
+    "sot_w1d_loss_and_grad": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, _vp, _vp, ctypes.c_float, _vp, _vp,
+                                             ctypes.c_size_t, _vp]),
+    "sot_scale_inplace": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp]),
     "sot_prepare_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sot_w1d_forward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_reduce_mean": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_float,
@@ -253,6 +256,35 @@ def loss_fused(x, y, xpos, ypos, p, flags, plan=None, denom=None, hinge=None, wa
                               _ptr(total), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return mean, row_loss, total
+
+
+def loss_and_grad(x, y, xpos, ypos, p, flags, plan=None):
+    """Training form (sot_w1d_loss_and_grad): (mean 0-d fp32, row_loss [B], d mean / d y [B, m]) -- one pass over the rows
+    where a compile-time backward kernel exists."""
+    lib = load()
+    dev = x.device
+    B, m = x.shape[0], y.shape[1]
+    row_loss = torch.empty(B, dtype=torch.float32, device=dev)
+    mean = torch.empty((), dtype=torch.float32, device=dev)
+    gy = torch.empty(B, m, dtype=torch.float32, device=dev)
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    ws = workspace(pr, dev) if need_ws else None
+    with _on_device(dev):
+        rc = lib.sot_w1d_loss_and_grad(ctypes.byref(pr), row_loss.data_ptr(), float(B), mean.data_ptr(), None, 1.0 / B, gy.data_ptr(),
+                                       _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
+    check(rc, p)
+    return mean, row_loss, gy
+
+
+def scale_inplace(data: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
+    """data *= scalar (0-d / 1-element fp32 device tensor); a no-op kernel when the scalar is exactly 1."""
+    require_hip(data, scalar)
+    if not data.is_contiguous() or data.dtype != torch.float32 or scalar.dtype != torch.float32 or scalar.numel() != 1:
+        raise RuntimeError("scale_inplace expects a contiguous fp32 tensor and a one-element fp32 scalar")
+    with _on_device(data.device):
+        check(load().sot_scale_inplace(data.data_ptr(), data.numel(), scalar.data_ptr(), stream_ptr(data.device)))
+    return data
 
 
 def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False, sum_out=None):

@@ -708,7 +708,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
 // ---------------------------------------------------------------------------------------------
 struct BwdArgs {
     FwdArgs f;
-    const float* grad_row;     // dL/d(row_loss): [B] (stride 1) or one broadcast scalar (stride 0)
+    const float* grad_row;     // dL/d(row_loss): [B] (stride 1) or one broadcast scalar (stride 0); null = 1 for every row
     int64_t grad_row_stride;
     float grad_scale;          // multiplies every upstream gradient (1/B of the batch mean)
     float* gx; float* gy;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         if (c.dn) { gSx += gSy; gSy = 0.0; }
         gSx = (!c.prenorm && Sx > kMassEps) ? gSx * rdx * rdx : 0.0;
         gSy = (!c.prenorm && Sy > kMassEps) ? gSy * rdy * rdy : 0.0;
-        const double gr = (double)b.grad_row[rowc * b.grad_row_stride] * (double)b.grad_scale;
+        const double gr = (b.grad_row ? (double)b.grad_row[rowc * b.grad_row_stride] : 1.0) * (double)b.grad_scale;
         if (valid) {
             const bool x_perm = ROWPOS ? c.do_sort : !c.x_ident;
             const bool y_perm = ROWPOS ? c.do_sort : !c.y_ident;
@@ -1040,7 +1040,7 @@ int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t 
 int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V, bool quant,
                 void* workspace, size_t workspace_bytes, void* stream);
 int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx, float* gy,
-                 void* workspace, size_t workspace_bytes, void* stream);
+                 void* workspace, size_t workspace_bytes, void* stream, float* row_loss_out = nullptr, bool* fused = nullptr);
 int run_forward_csr(const float* xw, const float* xp, const int64_t* xoff, int64_t x_nnz, const float* yw, const float* yp,
                     const int64_t* yoff, int64_t y_nnz, int64_t B, int max_n, int max_m, float p, uint32_t flags, float* row_loss,
                     void* stream);
@@ -1314,6 +1314,23 @@ __global__ __launch_bounds__(1024) void sot_reduce_mean_kernel(const float* __re
     }
 }
 
+// data[i] *= *scalar (the upstream gradient of a loss whose gradient sot_w1d_loss_and_grad computed ahead of the backward
+// pass); nothing is touched when the scalar is exactly 1 (a plain loss.backward()).
+__global__ __launch_bounds__(256) void sot_scale_inplace_kernel(float* __restrict__ data, int64_t count, const float* __restrict__ scalar)
+{
+    const float s = *scalar;
+    if (s == 1.0f) return;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t nvec = ((reinterpret_cast<uintptr_t>(data) & 15) == 0) ? count / 4 : 0;
+    float4* d4 = reinterpret_cast<float4*>(data);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        float4 v = d4[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        d4[i] = v;
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) data[i] *= s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Standalone segmented sort (torch.sort(keys, 1) of losses.py:287-288): one workgroup per row.
 // ---------------------------------------------------------------------------------------------
@@ -1420,14 +1437,16 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
+// row_loss_out (loss-and-gradient form): the kernels that can also emit the row losses do so and *fused is set; the caller
+// runs the forward kernel otherwise.  grad_row == nullptr: an upstream gradient of 1 for every row.
 int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx,
-                        float* gy, void* workspace, size_t workspace_bytes, void* stream)
+                        float* gy, void* workspace, size_t workspace_bytes, void* stream, float* row_loss_out, bool* fused)
 {
     Launch l;
     int rc = setup_launch(pr, true, workspace, workspace_bytes, stream, &l);
     if (rc != SOT_OK) return rc;
+    if (fused) *fused = false;
     if (pr->B == 0 || (gx == nullptr && gy == nullptr)) return SOT_OK;
-    if (grad_row == nullptr) return SOT_ERR_NULL_POINTER;
     BwdArgs b{};
     b.f = l.a; b.grad_row = grad_row; b.grad_row_stride = grad_row_stride; b.grad_scale = grad_scale; b.gx = gx; b.gy = gy;
     // row lengths with a compile-time kernel take it (as in run_forward)
@@ -1438,6 +1457,10 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;
 #endif
+    if (full && gx == nullptr && row_loss_out != nullptr) {   // the y-only full-row kernel accumulates the loss on its walk
+        b.f.row_loss = row_loss_out;
+        if (fused) *fused = true;
+    }
     const hipError_t e = full       ? dispatch_backward_full(l.cfg, l.pm, b, l.s)
                          : l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s)
                                     : dispatch_backward<false>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s);
@@ -1588,6 +1611,34 @@ int sot_w1d_backward(const sot_problem* prob, const float* grad_row, int64_t gra
 {
     if (grad_row_stride != 0 && grad_row_stride != 1) return SOT_ERR_BAD_SHAPE;
     return sot::run_backward(prob, grad_row, grad_row_stride, grad_scale, grad_x, grad_y, workspace, workspace_bytes, stream);
+}
+
+int sot_w1d_loss_and_grad(const sot_problem* prob, float* row_loss, double denom, float* mean_out, double* sum_out, float grad_scale,
+                          float* grad_y, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (prob == nullptr) return SOT_ERR_NULL_POINTER;
+    if (prob->B == 0) return SOT_ERR_BAD_SHAPE;  // the mean of zero rows is undefined
+    if (row_loss == nullptr || grad_y == nullptr || (mean_out == nullptr && sum_out == nullptr)) return SOT_ERR_NULL_POINTER;
+    bool fused = false;
+    int rc = sot::run_backward(prob, nullptr, 0, grad_scale, nullptr, grad_y, workspace, workspace_bytes, stream, row_loss, &fused);
+    if (rc != SOT_OK) return rc;
+    if (!fused) {
+        rc = sot::run_forward(prob, row_loss, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes, stream);
+        if (rc != SOT_OK) return rc;
+    }
+    return sot_w1d_reduce_mean(row_loss, prob->B, denom, 0, 0.0f, mean_out, sum_out, stream);
+}
+
+int sot_scale_inplace(float* data, int64_t count, const float* scalar, void* stream)
+{
+    if (count < 0) return SOT_ERR_BAD_SHAPE;
+    if (count == 0) return SOT_OK;
+    if (data == nullptr || scalar == nullptr) return SOT_ERR_NULL_POINTER;
+    const int64_t need = (count + 4 * 256 - 1) / (4 * 256);
+    const int grid = (int)(need < 256 * 16 ? need : 256 * 16);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(sot::sot_scale_inplace_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), data, count, scalar);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
 int sot_w1d_loss(const sot_problem* prob, float* row_loss, double denom, int apply_hinge, float hinge_threshold, float* mean_out,

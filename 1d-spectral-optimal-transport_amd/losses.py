@@ -56,15 +56,26 @@ class _RowLoss(torch.autograd.Function):
         return gx, gy, None, None, None, None, None
 
 
+EARLY_GRADIENT = True   # module switch for the loss-and-gradient form below (tests compare both forms)
+
+
 class _FusedMeanLoss(torch.autograd.Function):
     """losses.py:129-211 with dims=None behind ONE native call (forward kernel + fixed-order batch-mean kernel); the backward feeds the
-    scalar upstream gradient to the HIP backward kernel as a broadcast value scaled by 1/B."""
+    scalar upstream gradient to the HIP backward kernel as a broadcast value scaled by 1/B.
+
+    When only y needs a gradient (the training step: x is the target spectrum) the gradient of the mean is computed
+    together with the loss (sot_w1d_loss_and_grad: one pass over the rows instead of forward + backward) and only rescaled
+    by the upstream scalar in backward (a no-op kernel for a plain ``loss.backward()``)."""
 
     @staticmethod
     def forward(ctx, x, y, xpos, ypos, p, flags, plan):
-        mean, _, _ = nat.loss_fused(x, y, xpos, ypos, p, flags, plan)
-        ctx.save_for_backward(x, y, xpos, ypos)
         ctx.p, ctx.flags, ctx.plan = p, flags, plan
+        ctx.early_gy = None
+        if ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and EARLY_GRADIENT:
+            mean, _, ctx.early_gy = nat.loss_and_grad(x, y, xpos, ypos, p, flags, plan)
+        else:
+            mean, _, _ = nat.loss_fused(x, y, xpos, ypos, p, flags, plan)
+        ctx.save_for_backward(x, y, xpos, ypos)
         return mean
 
     @staticmethod
@@ -73,6 +84,9 @@ class _FusedMeanLoss(torch.autograd.Function):
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             raise NotImplementedError("gradients w.r.t. support positions are not implemented "
                                       "(no reference call site uses them)")
+        if ctx.early_gy is not None:   # consumed once: a second backward through a retained graph recomputes below
+            gy, ctx.early_gy = ctx.early_gy, None
+            return None, nat.scale_inplace(gy, g.float().contiguous()), None, None, None, None, None
         gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, g.float(), need_gx=ctx.needs_input_grad[0],
                                    need_gy=ctx.needs_input_grad[1], plan=ctx.plan, grad_scale=1.0 / x.shape[0])
         return gx, gy, None, None, None, None, None

@@ -148,7 +148,11 @@ class _AudioToLoss(torch.autograd.Function):
         spec_y = nat.stft_mag_forward(audio_estimate, window, n_fft, hop)
         rows_x = spec_x.view(-1, spec_x.shape[-1])
         rows_y = spec_y.view(-1, spec_y.shape[-1])
-        mean, _, _ = nat.loss_fused(rows_x, rows_y, pos_x, pos_y, p, flags, plan)
+        ctx.early_gy = None
+        if ctx.needs_input_grad[1]:   # the gradient w.r.t. the estimate's spectrum comes out of the same pass as the loss
+            mean, _, ctx.early_gy = nat.loss_and_grad(rows_x, rows_y, pos_x, pos_y, p, flags, plan)
+        else:
+            mean, _, _ = nat.loss_fused(rows_x, rows_y, pos_x, pos_y, p, flags, plan)
         ctx.save_for_backward(audio_estimate, window, rows_x, rows_y, pos_x, pos_y)
         ctx.cfg = (n_fft, hop, p, flags, plan, tuple(spec_y.shape))
         return mean
@@ -160,8 +164,12 @@ class _AudioToLoss(torch.autograd.Function):
         n_fft, hop, p, flags, plan, shape = ctx.cfg
         if not ctx.needs_input_grad[1]:
             return (None,) * 10
-        _, gy = nat.backward_rows(rows_x, rows_y, pos_x, pos_y, p, flags, g.float(), need_gx=False, need_gy=True, plan=plan,
-                                  grad_scale=1.0 / rows_x.shape[0])
+        if ctx.early_gy is not None:   # consumed once; a second backward through a retained graph recomputes
+            gy, ctx.early_gy = ctx.early_gy, None
+            nat.scale_inplace(gy, g.float().contiguous())
+        else:
+            _, gy = nat.backward_rows(rows_x, rows_y, pos_x, pos_y, p, flags, g.float(), need_gx=False, need_gy=True, plan=plan,
+                                      grad_scale=1.0 / rows_x.shape[0])
         grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, gy.view(shape))
         return None, grad_audio, None, None, None, None, None, None, None, None
 

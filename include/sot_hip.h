@@ -117,7 +117,7 @@ int sot_w1d_reduce_mean(const float *row_loss, int64_t B, double denom, int appl
 /*
  * Backward of the forward above w.r.t. the weights (closed form of the autograd graph of
  * losses.py:172-313; positions receive no gradient, as in every reference call site).
- * dL/d(row_loss[r]) = grad_scale * grad_row[r * grad_row_stride].  grad_x and/or grad_y may be NULL (trainer.py only needs
+ * dL/d(row_loss[r]) = grad_scale * grad_row[r * grad_row_stride] (grad_row == NULL: 1 for every row).  grad_x and/or grad_y may be NULL (trainer.py only needs
  * grad_y: x is the target spectrum).  Row strides of the gradients equal n and m.
  * Tie convention: gradients of a run of equal quantile levels go to the run's last member in
  * stable-sort order (U before V, lower index first).
@@ -127,6 +127,20 @@ int sot_w1d_backward(const sot_problem *prob,
                      int64_t grad_row_stride, float grad_scale /* multiplies grad_row, e.g. 1/B of the batch mean */,
                      float *grad_x /* [B,n] or NULL */, float *grad_y /* [B,m] or NULL */,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Training form: row losses, their batch mean AND the gradient of `grad_scale * sum_r row_loss[r]` w.r.t. y in one call
+ * (grad_scale = 1/denom: the gradient of the mean that Wasserstein1D.forward returns; trainer.py:220-228 backpropagates
+ * exactly that, x being the target spectrum).  For the row lengths with a compile-time backward kernel this is ONE pass
+ * over the rows (the backward kernel's merge walk also accumulates the loss, bit-identical to sot_w1d_forward) followed by
+ * the reduction kernel; otherwise forward, backward and reduction are enqueued back to back.  No hinge (the hinge changes
+ * which rows receive a gradient).  A caller whose upstream gradient turns out not to be 1 rescales with sot_scale_inplace.
+ */
+int sot_w1d_loss_and_grad(const sot_problem *prob, float *row_loss /* [B] */, double denom, float *mean_out, double *sum_out,
+                          float grad_scale, float *grad_y /* [B,m] */, void *workspace, size_t workspace_bytes, void *stream);
+
+/* data[i] *= *scalar for i < count (device scalar); returns without touching `data` when the scalar is exactly 1. */
+int sot_scale_inplace(float *data, int64_t count, const float *scalar, void *stream);
 
 /*
  * Forward + batch reduction in ONE call: enqueues sot_w1d_forward and sot_w1d_reduce_mean back to back on

@@ -683,3 +683,62 @@ def test_sharded_loss_single_rank_equals_module():
     b.backward()
     torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
     torch.testing.assert_close(y1.grad, y2.grad, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B", [(2048, 70), (1025, 33), (257, 130), (512, 9), (300, 17)])
+@pytest.mark.parametrize("flags,p", [(8, 1.0), (1 | 2 | 4 | 8, 2.0), (4 | 8, 2.0)])
+def test_loss_and_grad_in_one_pass_matches_forward_plus_backward(N, B, flags, p):
+    """sot_w1d_loss_and_grad (the training form: the y-only backward kernel also accumulates the row losses) against the
+    separate forward and backward calls: row losses, mean and gradient bit for bit (N = 300 has no compile-time kernel and
+    takes the three-kernel fallback inside the library)."""
+    from oracle.inputs import gen_inputs
+    nat = native()
+    x, y = gen_inputs("peaky", B, N, N, 99 + N)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.linspace(0, 1, N).to(device())
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2)
+    mean, rows, gy = nat.loss_and_grad(x, y, pos, pos2, p, flags, plan)
+    mean2, rows2, _ = nat.loss_fused(x, y, pos, pos2, p, flags, plan)
+    one = torch.ones((), device=device())
+    _, gy2 = nat.backward_rows(x, y, pos, pos2, p, flags, one, need_gx=False, plan=plan, grad_scale=1.0 / B)
+    assert torch.equal(rows, rows2), float((rows - rows2).abs().max())
+    assert torch.equal(mean, mean2)
+    assert torch.equal(gy, gy2), float((gy - gy2).abs().max())
+    # the rescaling kernel: exactly nothing for 1, a plain product otherwise
+    keep = gy.clone()
+    assert torch.equal(nat.scale_inplace(gy, one), keep)
+    three = torch.full((), 3.0, device=device())
+    assert torch.equal(nat.scale_inplace(gy, three), keep * 3.0)
+
+
+@pytest.mark.gpu
+def test_module_early_gradient_matches_the_two_pass_form():
+    """Wasserstein1D with y.requires_grad only: loss and gradient are identical whether the gradient is computed with the
+    loss (default) or in backward; upstream scaling and a second backward through a retained graph work."""
+    from oracle.inputs import gen_inputs
+    from oracle.make_golden import MODES
+    from sot_amd import losses
+    x, y = gen_inputs("peaky", 64, 1025, 1025, 5)
+    x = x.to(device())
+    pos = torch.linspace(0, 1, 1025).to(device())
+    mod = module_for(MODES["cutoff"])
+    results = []
+    for early in (True, False):
+        losses.EARLY_GRADIENT = early
+        try:
+            yv = y.to(device()).requires_grad_(True)
+            loss = mod(x, yv, x_pos=pos, y_pos=pos.clone())
+            (2.5 * loss).backward(retain_graph=True)
+            g1 = yv.grad.clone()
+            yv.grad = None
+            loss.backward()
+            results.append((loss.detach().clone(), g1, yv.grad.clone()))
+        finally:
+            losses.EARLY_GRADIENT = True
+    (l1, a1, b1), (l2, a2, b2) = results
+    assert torch.equal(l1, l2)
+    assert torch.equal(b1, b2)                      # second backward: recomputed by the backward kernel in both forms
+    torch.testing.assert_close(a1, a2, rtol=2e-7, atol=1e-37)   # 2.5 * (g / B) rounded in one or two steps (subnormals: atol)
+    torch.testing.assert_close(a1, 2.5 * b1, rtol=2e-7, atol=1e-37)
