@@ -70,7 +70,7 @@ EXPORTS = {
                                                   ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp]),
     "sot_stft_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
-                                             _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+                                             _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None
@@ -405,9 +405,13 @@ def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
     return mag
 
 
-def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, grad_mag: torch.Tensor) -> torch.Tensor:
-    """dL/d(audio) [batch, samples] from dL/d(mag) [batch, frames, n_fft/2+1] (sot_stft_mag_backward)."""
-    require_hip(audio, window, grad_mag)
+def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, grad_mag: torch.Tensor,
+                      grad_scale: torch.Tensor = None) -> torch.Tensor:
+    """dL/d(audio) [batch, samples] from dL/d(mag) [batch, frames, n_fft/2+1] (sot_stft_mag_backward); grad_scale: optional
+    one-element fp32 device tensor multiplying grad_mag."""
+    require_hip(audio, window, grad_mag, grad_scale)
+    if grad_scale is not None and grad_scale.numel() != 1:
+        raise RuntimeError("stft_mag_backward: grad_scale must hold one element")
     lib = load()
     if audio.stride(1) != 1:
         audio = audio.contiguous()
@@ -419,8 +423,8 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
                      device=audio.device)
     with _on_device(audio.device):
         check(lib.sot_stft_mag_backward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
-                                        int(n_fft), int(hop), grad_mag.data_ptr(), grad_audio.data_ptr(), ws.data_ptr(), ws.numel(),
-                                        stream_ptr(audio.device)))
+                                        int(n_fft), int(hop), grad_mag.data_ptr(), _ptr(grad_scale), grad_audio.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), stream_ptr(audio.device)))
     return grad_audio
 
 

@@ -120,6 +120,7 @@ struct StftArgs {
     const float* window; int n_fft, logm, hop; int64_t frames;   // logm = log2(n_fft / 2)
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
+    const float* grad_scale;    // backward: optional device scalar multiplying grad_mag (an upstream gradient), or null
     float* grad_audio;          // backward output [batch, samples] (contiguous)
     float* partial;             // backward scratch [batch, groups, span]: each frame group's overlap-added gradient
     int64_t groups; int span;   // span = n_fft + hop * (kFramesPerGroup - 1)
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
     float* const acc = reinterpret_cast<float*>(zall + G::lds_points) + slot * a.span;  // this group's overlap-added gradient [span]
     const float2* win = reinterpret_cast<const float2*>(a.window);
     const float scale = 1.0f / sqrtf((float)G::n);
+    const float up = a.grad_scale ? *a.grad_scale : 1.0f;
     const unsigned total = (unsigned)(a.batch * a.groups), groups = (unsigned)a.groups;
     load_tables<LOGM>(tw, wn);
     const unsigned w = blockIdx.x * G::slots + slot;
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
                 v2f xk, xm;
                 unpack_pair<LOGM>(z, wn, k, xk, xm);
                 const float mk = magnitude(xk), mm = magnitude(xm);
-                const float ck = mk > 0.0f ? g[k] / mk : 0.0f;          // torch: sgn(0) = 0
-                const float cm = mm > 0.0f ? g[m - k] / mm : 0.0f;
+                const float ck = mk > 0.0f ? (g[k] * up) / mk : 0.0f;          // torch: sgn(0) = 0
+                const float cm = mm > 0.0f ? (g[m - k] * up) / mm : 0.0f;
                 v2f hk = (0.5f * ck) * xk, hm = (0.5f * cm) * xm;
                 if (k == 0) { hk = (v2f){ck * xk.x, 0.0f}; hm = (v2f){cm * xm.x, 0.0f}; }   // H_0, H_m are real
                 const v2f sk = hk + cconj(hm);      // H_k + conj(H_{m-k})
@@ -460,8 +462,8 @@ size_t sot_stft_backward_workspace_bytes(int64_t batch, int64_t samples, int n_f
 }
 
 int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, int64_t audio_row_stride, const float* window,
-                          int n_fft, int hop, const float* grad_mag, float* grad_audio, void* workspace, size_t workspace_bytes,
-                          void* stream)
+                          int n_fft, int hop, const float* grad_mag, const float* grad_scale, float* grad_audio, void* workspace,
+                          size_t workspace_bytes, void* stream)
 {
     using namespace sot_stft;
     StftArgs a{};
@@ -472,7 +474,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
     const int64_t span = n_fft + (int64_t)hop * (kFramesPerGroup - 1);
     if (span > 8192) return SOT_ERR_UNSUPPORTED_SIZE;   // the groups' gradients live in LDS
-    a.grad_mag = grad_mag; a.grad_audio = grad_audio;
+    a.grad_mag = grad_mag; a.grad_scale = grad_scale; a.grad_audio = grad_audio;
     a.partial = reinterpret_cast<float*>(workspace);
     a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
     a.span = (int)span;

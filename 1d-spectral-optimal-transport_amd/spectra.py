@@ -164,13 +164,12 @@ class _AudioToLoss(torch.autograd.Function):
         n_fft, hop, p, flags, plan, shape = ctx.cfg
         if not ctx.needs_input_grad[1]:
             return (None,) * 10
-        if ctx.early_gy is not None:   # consumed once; a second backward through a retained graph recomputes
-            gy, ctx.early_gy = ctx.early_gy, None
-            nat.scale_inplace(gy, g.float().contiguous())
+        if ctx.early_gy is not None:   # d mean / d spectrum from the forward pass; the STFT backward applies the upstream scalar
+            grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, ctx.early_gy.view(shape), g.float().contiguous())
         else:
             _, gy = nat.backward_rows(rows_x, rows_y, pos_x, pos_y, p, flags, g.float(), need_gx=False, need_gy=True, plan=plan,
                                       grad_scale=1.0 / rows_x.shape[0])
-        grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, gy.view(shape))
+            grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, gy.view(shape))
         return None, grad_audio, None, None, None, None, None, None, None, None
 
 

@@ -192,11 +192,13 @@ int64_t sot_stft_frames(int64_t samples, int hop);
 int sot_stft_mag_forward(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,
                          const float *window, int n_fft, int hop, float *mag, void *stream);
 /* gradient of a scalar L w.r.t. the audio given dL/d(mag): closed form of abs o stft's autograd (bins with |X| = 0 pass
- * no gradient, as torch's sgn(0) = 0); deterministic (groups of frames overlap-added in a fixed order, no atomics) */
+ * no gradient, as torch's sgn(0) = 0); deterministic (groups of frames overlap-added in a fixed order, no atomics).
+ * grad_scale: optional DEVICE scalar that multiplies grad_mag (the upstream gradient of a loss whose dL/d(mag) was
+ * computed ahead of the backward pass, sot_w1d_loss_and_grad), or NULL. */
 size_t sot_stft_backward_workspace_bytes(int64_t batch, int64_t samples, int n_fft, int hop);
 int sot_stft_mag_backward(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,
-                          const float *window, int n_fft, int hop, const float *grad_mag, float *grad_audio,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          const float *window, int n_fft, int hop, const float *grad_mag, const float *grad_scale,
+                          float *grad_audio, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Additive oscillator bank in front of the STFT in the training step: ddsp.oscillator_bank
  * (ddsp.py:208-263 with use_angular_cumsum=False, sum_sinusoids=True) incl. remove_above_nyquist (ddsp.py:25-49):

@@ -117,6 +117,15 @@ def test_chain_stft_into_sot_loss_matches_reference(tag):
     want, gwant = float(fx[f"{tag}_loss"]), fx[f"{tag}_grad_audio_y"]
     assert abs(float(loss) - want) <= 2e-5 * abs(want)   # the cutoff's knife-edge amplifies the spectra's last-bit differences
     assert np.abs(ay.grad.cpu().numpy() - gwant).max() <= 2e-3 * np.abs(gwant).max()
+    # an upstream factor reaches the audio gradient through the STFT backward's device scalar (and a retained graph can be
+    # walked twice)
+    ay2 = torch.as_tensor(fx[f"{tag}_audio_y"]).to(device()).requires_grad_(True)
+    loss2 = spectra.training_step_slice(mod, ax, ay2, n_fft=n_fft, hop=hop)
+    (3.0 * loss2).backward(retain_graph=True)
+    torch.testing.assert_close(ay2.grad, 3.0 * ay.grad, rtol=2e-5, atol=1e-9)
+    ay2.grad = None
+    loss2.backward()
+    assert torch.equal(ay2.grad, ay.grad)
 
 
 @pytest.mark.gpu
