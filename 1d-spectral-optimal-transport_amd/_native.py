@@ -69,6 +69,8 @@ EXPORTS = {
     "sot_spec_distance_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                   ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp]),
     "sot_stft_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "sot_stft_mag_forward_pair": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int,
+                                                 ctypes.c_int, _vp, _vp]),
     "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                              _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }
@@ -403,6 +405,28 @@ def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
         check(lib.sot_stft_mag_forward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
                                        int(n_fft), int(hop), mag.data_ptr(), stream_ptr(audio.device)))
     return mag
+
+
+def stft_mag_forward_pair(audio_a: torch.Tensor, audio_b: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int):
+    """Two [batch, samples] signals -> their [batch, frames, n_fft/2+1] magnitudes from ONE launch (sot_stft_mag_forward_pair);
+    the two results are the halves of one allocation."""
+    require_hip(audio_a, audio_b, window)
+    lib = load()
+    if audio_a.ndim != 2 or audio_a.shape != audio_b.shape or window.numel() != n_fft:
+        raise RuntimeError("stft_mag_forward_pair expects two audio tensors [batch, samples] of one shape and a window of n_fft samples")
+    if audio_a.stride(1) != 1:
+        audio_a = audio_a.contiguous()
+    if audio_b.stride(1) != 1:
+        audio_b = audio_b.contiguous()
+    window = _aligned8(window.contiguous())
+    batch, samples = audio_a.shape
+    frames = int(lib.sot_stft_frames(samples, hop))
+    mag = torch.empty(2 * batch, frames, n_fft // 2 + 1, dtype=torch.float32, device=audio_a.device)
+    with _on_device(audio_a.device):
+        check(lib.sot_stft_mag_forward_pair(audio_a.data_ptr(), audio_a.stride(0) if batch > 1 else samples, audio_b.data_ptr(),
+                                            audio_b.stride(0) if batch > 1 else samples, batch, samples, window.data_ptr(), int(n_fft),
+                                            int(hop), mag.data_ptr(), stream_ptr(audio_a.device)))
+    return mag[:batch], mag[batch:]
 
 
 def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, grad_mag: torch.Tensor,

@@ -117,6 +117,7 @@ __device__ __forceinline__ int bitrev(int v, int logn) { return (int)(__brev((un
 
 struct StftArgs {
     const float* audio; int64_t batch, samples, row_stride;
+    const float* audio_b; int64_t split, row_stride_b;   // forward of two signals in one launch: clips >= split come from audio_b
     const float* window; int n_fft, logm, hop; int64_t frames;   // logm = log2(n_fft / 2)
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
@@ -187,7 +188,9 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
     const unsigned fr = blockIdx.x * G::slots + slot;
     const bool active = fr < total;
     const unsigned b = active ? fr / frames : 0u, f = active ? fr - b * frames : 0u;
-    load_frame<LOGM>(a, a.audio + (int64_t)b * a.row_stride, (int64_t)f * a.hop, z, active, lid);
+    const float* src = (a.audio_b != nullptr && (int64_t)b >= a.split) ? a.audio_b + ((int64_t)b - a.split) * a.row_stride_b
+                                                                      : a.audio + (int64_t)b * a.row_stride;
+    load_frame<LOGM>(a, src, (int64_t)f * a.hop, z, active, lid);
     fft_inplace<LOGM, false>(z, tw, lid);
     if (active) {
         float* dst = a.mag + (int64_t)fr * G::nb;
@@ -449,6 +452,23 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     a.mag = mag;
     (void)hipGetLastError();
     SOT_STFT_LAUNCH(stft_mag_forward_kernel, batch * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+int sot_stft_mag_forward_pair(const float* audio_a, int64_t row_stride_a, const float* audio_b, int64_t row_stride_b,
+                              int64_t batch_each, int64_t samples, const float* window, int n_fft, int hop, float* mag, void* stream)
+{
+    using namespace sot_stft;
+    if (row_stride_b < samples) return SOT_ERR_BAD_SHAPE;
+    StftArgs a{};
+    const int rc = fill_args(audio_a, 2 * batch_each, samples, row_stride_a, window, n_fft, hop, &a);
+    if (rc != SOT_OK) return rc;
+    if (batch_each == 0) return SOT_OK;
+    if (mag == nullptr || audio_b == nullptr) return SOT_ERR_NULL_POINTER;
+    a.audio_b = audio_b; a.split = batch_each; a.row_stride_b = row_stride_b;
+    a.mag = mag;
+    (void)hipGetLastError();
+    SOT_STFT_LAUNCH(stft_mag_forward_kernel, 2 * batch_each * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

@@ -144,8 +144,7 @@ class _AudioToLoss(torch.autograd.Function):
     def forward(ctx, audio_target, audio_estimate, window, pos_x, pos_y, n_fft, hop, p, flags, plan):
         from . import _native as nat
         audio_estimate = audio_estimate.contiguous()
-        spec_x = nat.stft_mag_forward(audio_target.contiguous(), window, n_fft, hop)
-        spec_y = nat.stft_mag_forward(audio_estimate, window, n_fft, hop)
+        spec_x, spec_y = nat.stft_mag_forward_pair(audio_target.contiguous(), audio_estimate, window, n_fft, hop)
         rows_x = spec_x.view(-1, spec_x.shape[-1])
         rows_y = spec_y.view(-1, spec_y.shape[-1])
         ctx.early_gy = None

@@ -191,6 +191,11 @@ int sot_segmented_sort(const float *keys, int64_t B, int32_t n, int64_t row_stri
 int64_t sot_stft_frames(int64_t samples, int hop);
 int sot_stft_mag_forward(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,
                          const float *window, int n_fft, int hop, float *mag, void *stream);
+/* the same transform of TWO signals of equal shape (target and estimate of a training step) in one launch:
+ * mag[0 : batch_each] belongs to audio_a, mag[batch_each : 2 batch_each] to audio_b */
+int sot_stft_mag_forward_pair(const float *audio_a, int64_t row_stride_a, const float *audio_b, int64_t row_stride_b,
+                              int64_t batch_each, int64_t samples, const float *window, int n_fft, int hop,
+                              float *mag /* [2 * batch_each, frames, n_fft/2+1] */, void *stream);
 /* gradient of a scalar L w.r.t. the audio given dL/d(mag): closed form of abs o stft's autograd (bins with |X| = 0 pass
  * no gradient, as torch's sgn(0) = 0); deterministic (groups of frames overlap-added in a fixed order, no atomics).
  * grad_scale: optional DEVICE scalar that multiplies grad_mag (the upstream gradient of a loss whose dL/d(mag) was

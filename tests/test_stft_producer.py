@@ -185,6 +185,23 @@ def test_hip_stft_other_sizes_against_torch(n_fft, hop, samples, batch):
 
 
 @pytest.mark.gpu
+def test_hip_stft_pair_is_the_two_single_transforms():
+    from gpu_util import device
+    from sot_amd import _native as nat, spectra
+    g = torch.Generator().manual_seed(3)
+    for n_fft, hop, samples, batch in ((2048, 256, 4096, 5), (512, 128, 1000, 3), (64, 16, 90, 7)):
+        a = torch.randn(batch, samples, generator=g).to(device())
+        b = torch.randn(batch + 1, samples, generator=g).to(device())[1:]     # a view with an offset
+        w = spectra._cached_window("hann", n_fft, device())
+        pa, pb = nat.stft_mag_forward_pair(a, b, w, n_fft, hop)
+        assert torch.equal(pa, nat.stft_mag_forward(a, w, n_fft, hop))
+        assert torch.equal(pb, nat.stft_mag_forward(b, w, n_fft, hop))
+        assert pa.is_contiguous() and pb.is_contiguous()
+    with pytest.raises(RuntimeError):
+        nat.stft_mag_forward_pair(a, b[:2], w, n_fft, hop)
+
+
+@pytest.mark.gpu
 def test_hip_stft_errors_and_fallback():
     from gpu_util import device, native
     from sot_amd import spectra
