@@ -65,14 +65,14 @@ EXPORTS = {
                                                     _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
-                                                 _vp, _vp, ctypes.c_size_t, _vp]),
+                                                 _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "sot_spec_distance_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                   ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp]),
     "sot_stft_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sot_stft_mag_forward_pair": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int,
                                                  ctypes.c_int, _vp, _vp]),
     "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
-                                             _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+                                             _vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None
@@ -430,9 +430,10 @@ def stft_mag_forward_pair(audio_a: torch.Tensor, audio_b: torch.Tensor, window: 
 
 
 def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, grad_mag: torch.Tensor,
-                      grad_scale: torch.Tensor = None) -> torch.Tensor:
+                      grad_scale: torch.Tensor = None, accumulate_into: torch.Tensor = None) -> torch.Tensor:
     """dL/d(audio) [batch, samples] from dL/d(mag) [batch, frames, n_fft/2+1] (sot_stft_mag_backward); grad_scale: optional
-    one-element fp32 device tensor multiplying grad_mag."""
+    one-element fp32 device tensor multiplying grad_mag; accumulate_into: an existing contiguous [batch, samples] gradient
+    that the result is added to (and that is returned)."""
     require_hip(audio, window, grad_mag, grad_scale)
     if grad_scale is not None and grad_scale.numel() != 1:
         raise RuntimeError("stft_mag_backward: grad_scale must hold one element")
@@ -442,30 +443,41 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
     window = _aligned8(window.contiguous())
     grad_mag = grad_mag.contiguous()
     batch, samples = audio.shape
-    grad_audio = torch.empty(batch, samples, dtype=torch.float32, device=audio.device)
+    if accumulate_into is not None:
+        require_hip(accumulate_into)
+        if accumulate_into.shape != (batch, samples) or not accumulate_into.is_contiguous():
+            raise RuntimeError("stft_mag_backward: accumulate_into must be a contiguous [batch, samples] tensor")
+        grad_audio = accumulate_into
+    else:
+        grad_audio = torch.empty(batch, samples, dtype=torch.float32, device=audio.device)
     ws = torch.empty(max(1, int(lib.sot_stft_backward_workspace_bytes(batch, samples, int(n_fft), int(hop)))), dtype=torch.uint8,
                      device=audio.device)
     with _on_device(audio.device):
         check(lib.sot_stft_mag_backward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
-                                        int(n_fft), int(hop), grad_mag.data_ptr(), _ptr(grad_scale), grad_audio.data_ptr(), ws.data_ptr(),
-                                        ws.numel(), stream_ptr(audio.device)))
+                                        int(n_fft), int(hop), grad_mag.data_ptr(), _ptr(grad_scale), grad_audio.data_ptr(),
+                                        0 if accumulate_into is None else 1, ws.data_ptr(), ws.numel(), stream_ptr(audio.device)))
     return grad_audio
 
 
 def spec_distance_forward(target: torch.Tensor, value: torch.Tensor, mag_weight: float, logmag_weight: float, eps: float = 1e-5,
-                          l2: bool = False) -> torch.Tensor:
-    """0-d fp32: mag_weight * mean D(t - v) + logmag_weight * mean D(slog t - slog v) (sot_spec_distance_forward)."""
+                          l2: bool = False, accumulate_into: torch.Tensor = None) -> torch.Tensor:
+    """0-d fp32: mag_weight * mean D(t - v) + logmag_weight * mean D(slog t - slog v) (sot_spec_distance_forward);
+    accumulate_into: an existing 0-d fp32 device tensor the distance is added to (and that is returned)."""
     require_hip(target, value)
     lib = load()
     target, value = target.contiguous(), value.contiguous()
     if target.shape != value.shape or target.numel() == 0:
         raise RuntimeError("spec_distance_forward expects two non-empty tensors of the same shape")
-    out = torch.empty((), dtype=torch.float32, device=target.device)
+    if accumulate_into is not None:
+        require_hip(accumulate_into)
+        if accumulate_into.numel() != 1:
+            raise RuntimeError("spec_distance_forward: accumulate_into must hold one element")
+    out = accumulate_into if accumulate_into is not None else torch.empty((), dtype=torch.float32, device=target.device)
     ws = torch.empty(int(lib.sot_spec_distance_workspace_bytes()), dtype=torch.uint8, device=target.device)
     with _on_device(target.device):
         check(lib.sot_spec_distance_forward(target.data_ptr(), value.data_ptr(), target.numel(), float(mag_weight), float(logmag_weight),
-                                            float(eps), int(bool(l2)), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                            stream_ptr(target.device)))
+                                            float(eps), int(bool(l2)), out.data_ptr(), 0 if accumulate_into is None else 1,
+                                            ws.data_ptr(), ws.numel(), stream_ptr(target.device)))
     return out
 
 

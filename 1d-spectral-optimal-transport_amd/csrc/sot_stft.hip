@@ -122,6 +122,7 @@ struct StftArgs {
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
     const float* grad_mag;      // backward input, same shape
     const float* grad_scale;    // backward: optional device scalar multiplying grad_mag (an upstream gradient), or null
+    int accumulate;             // backward: grad_audio += result (the sum over the scales of MSSLoss)
     float* grad_audio;          // backward output [batch, samples] (contiguous)
     float* partial;             // backward scratch [batch, groups, span]: each frame group's overlap-added gradient
     int64_t groups; int span;   // span = n_fft + hop * (kFramesPerGroup - 1)
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftAr
         const int64_t g_hi = min(t / gstep, a.groups - 1);
         float sum = 0.0f;
         for (int64_t g = g_lo; g <= g_hi; ++g) sum += a.partial[(b * a.groups + g) * a.span + (t - g * gstep)];
-        a.grad_audio[idx] = sum;
+        a.grad_audio[idx] = a.accumulate ? a.grad_audio[idx] + sum : sum;
     }
 }
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftAr
 struct DistArgs {
     const float* target; const float* value; int64_t count;
     float mag_weight, logmag_weight, eps; int l2;
-    double* partial; int n_partial; float* out;           // forward
+    double* partial; int n_partial; float* out; int accumulate;   // forward; accumulate: out += d (the sum over the scales of MSSLoss)
     const float* upstream; float grad_scale;               // backward: d(loss)/d(d) as a device scalar, times grad_scale
     float* grad_target; float* grad_value;                 // either may be null
 };
@@ -359,7 +360,10 @@ __global__ __launch_bounds__(kThreads) void spec_distance_finish_kernel(const Di
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.out[0] = (float)(red[0] / (double)a.count);
+    if (threadIdx.x == 0) {
+        const float d = (float)(red[0] / (double)a.count);
+        a.out[0] = a.accumulate ? a.out[0] + d : d;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void spec_distance_backward_kernel(const DistArgs a)
@@ -482,8 +486,8 @@ size_t sot_stft_backward_workspace_bytes(int64_t batch, int64_t samples, int n_f
 }
 
 int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, int64_t audio_row_stride, const float* window,
-                          int n_fft, int hop, const float* grad_mag, const float* grad_scale, float* grad_audio, void* workspace,
-                          size_t workspace_bytes, void* stream)
+                          int n_fft, int hop, const float* grad_mag, const float* grad_scale, float* grad_audio, int accumulate,
+                          void* workspace, size_t workspace_bytes, void* stream)
 {
     using namespace sot_stft;
     StftArgs a{};
@@ -494,7 +498,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
     const int64_t span = n_fft + (int64_t)hop * (kFramesPerGroup - 1);
     if (span > 8192) return SOT_ERR_UNSUPPORTED_SIZE;   // the groups' gradients live in LDS
-    a.grad_mag = grad_mag; a.grad_scale = grad_scale; a.grad_audio = grad_audio;
+    a.grad_mag = grad_mag; a.grad_scale = grad_scale; a.grad_audio = grad_audio; a.accumulate = accumulate;
     a.partial = reinterpret_cast<float*>(workspace);
     a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
     a.span = (int)span;
@@ -511,7 +515,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
 size_t sot_spec_distance_workspace_bytes(void) { return sizeof(double) * (size_t)sot_stft::kDistBlocks; }
 
 int sot_spec_distance_forward(const float* target, const float* value, int64_t count, float mag_weight, float logmag_weight,
-                              float eps, int l2, float* out, void* workspace, size_t workspace_bytes, void* stream)
+                              float eps, int l2, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream)
 {
     using namespace sot_stft;
     if (count < 1) return SOT_ERR_BAD_SHAPE;
@@ -519,7 +523,7 @@ int sot_spec_distance_forward(const float* target, const float* value, int64_t c
     if (workspace_bytes < sot_spec_distance_workspace_bytes()) return SOT_ERR_WORKSPACE;
     DistArgs a{};
     a.target = target; a.value = value; a.count = count; a.mag_weight = mag_weight; a.logmag_weight = logmag_weight; a.eps = eps;
-    a.l2 = l2; a.partial = reinterpret_cast<double*>(workspace); a.out = out;
+    a.l2 = l2; a.partial = reinterpret_cast<double*>(workspace); a.out = out; a.accumulate = accumulate;
     const int64_t need = (count + kThreads - 1) / kThreads;
     a.n_partial = (int)(need < kDistBlocks ? need : kDistBlocks);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -293,10 +293,11 @@ class _MultiScaleSpectral(torch.autograd.Function):
         for size in fft_sizes:
             hop = int(size * (1.0 - 0.75))                      # compute_mag's default overlap (features.py:214-216)
             win = spectra._cached_window(None, size, audio.device)   # window=None -> hann (features.py:203-204)
-            t = nat.stft_mag_forward(target_audio, win, size, hop)
-            v = nat.stft_mag_forward(audio, win, size, hop)
-            d = nat.spec_distance_forward(t, v, mag_weight, logmag_weight, 1e-5, l2)
-            total = d if total is None else total + d
+            if target_audio.shape == audio.shape:
+                t, v = nat.stft_mag_forward_pair(target_audio, audio, win, size, hop)   # one launch for both signals
+            else:
+                t, v = nat.stft_mag_forward(target_audio, win, size, hop), nat.stft_mag_forward(audio, win, size, hop)
+            total = nat.spec_distance_forward(t, v, mag_weight, logmag_weight, 1e-5, l2, accumulate_into=total)   # total += d
             saved += [t, v]
         ctx.save_for_backward(target_audio, audio, *saved)
         ctx.cfg = (tuple(fft_sizes), mag_weight, logmag_weight, l2)
@@ -309,17 +310,16 @@ class _MultiScaleSpectral(torch.autograd.Function):
         fft_sizes, mag_weight, logmag_weight, l2 = ctx.cfg
         need_t, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = g.float().reshape(1)
-        grad_t = torch.zeros_like(target_audio) if need_t else None
-        grad_v = torch.zeros_like(audio) if need_v else None
+        grad_t = grad_v = None   # the first scale's kernel writes the gradient, the later ones add to it
         for i, size in enumerate(fft_sizes):
             hop = int(size * (1.0 - 0.75))
             win = spectra._cached_window(None, size, audio.device)
             t, v = saved[2 * i], saved[2 * i + 1]
             gt, gv = nat.spec_distance_backward(t, v, mag_weight, logmag_weight, g, 1.0, 1e-5, l2, need_target=need_t, need_value=need_v)
             if need_v:
-                grad_v += nat.stft_mag_backward(audio, win, size, hop, gv)
+                grad_v = nat.stft_mag_backward(audio, win, size, hop, gv, accumulate_into=grad_v)
             if need_t:
-                grad_t += nat.stft_mag_backward(target_audio, win, size, hop, gt)
+                grad_t = nat.stft_mag_backward(target_audio, win, size, hop, gt, accumulate_into=grad_t)
         return grad_t, grad_v, None, None, None, None
 
 

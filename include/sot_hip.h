@@ -203,7 +203,8 @@ int sot_stft_mag_forward_pair(const float *audio_a, int64_t row_stride_a, const 
 size_t sot_stft_backward_workspace_bytes(int64_t batch, int64_t samples, int n_fft, int hop);
 int sot_stft_mag_backward(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,
                           const float *window, int n_fft, int hop, const float *grad_mag, const float *grad_scale,
-                          float *grad_audio, void *workspace, size_t workspace_bytes, void *stream);
+                          float *grad_audio, int accumulate /* grad_audio += result instead of = */,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Additive oscillator bank in front of the STFT in the training step: ddsp.oscillator_bank
  * (ddsp.py:208-263 with use_angular_cumsum=False, sum_sinusoids=True) incl. remove_above_nyquist (ddsp.py:25-49):
@@ -227,8 +228,9 @@ int sot_oscillator_bank_backward(const float *freq, const float *amp, int64_t ba
  *   slog(x) = log(x <= eps ? eps : x).  Deterministic (fixed-order fp64 partial sums in the caller-owned workspace). */
 size_t sot_spec_distance_workspace_bytes(void);
 int sot_spec_distance_forward(const float *target, const float *value, int64_t count, float mag_weight,
-                              float logmag_weight, float eps, int l2, float *out, void *workspace,
-                              size_t workspace_bytes, void *stream);
+                              float logmag_weight, float eps, int l2, float *out,
+                              int accumulate /* out[0] += the distance (MSSLoss sums its scales) instead of = */,
+                              void *workspace, size_t workspace_bytes, void *stream);
 /* gradients w.r.t. target and/or value (either may be NULL) given d(loss)/d(out) as a one-element device tensor times
  * grad_scale; |.|' (0) = 0 and no gradient through slog below eps, as torch */
 int sot_spec_distance_backward(const float *target, const float *value, int64_t count, float mag_weight,

@@ -48,3 +48,18 @@ def mss_torch():
         loss = loss + (t - v).abs().mean()
     loss.backward()
 print(f"MSSLoss fwd+bwd, 256 clips x 4096 samples, 6 scales: HIP {ev(mss_hip, 20, 10):7.1f} us   torch.stft composition {ev(mss_torch, 20, 10):7.1f} us")
+
+# the same MSSLoss step replayed from one HIP graph (kernel-bound figure: no Python / autograd / launch overhead per step)
+e_static = est.detach().requires_grad_(True)
+def mss_static():
+    e_static.grad = None
+    mss(audio, e_static).backward()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3): mss_static()
+torch.cuda.current_stream().wait_stream(side)
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr):
+    mss_static()
+print(f"MSSLoss fwd+bwd replayed from one HIP graph: {ev(gr.replay, 50, 10):7.1f} us")
