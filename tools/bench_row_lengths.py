@@ -1,3 +1,5 @@
+"""Every row length with a compile-time kernel against the generic kernels (SOT_FLAG_NO_SPECIALIZE): forward and backward
+w.r.t. y, p = 1 and the paper's cutoff mode, back-to-back launches timed with HIP events.  usage: python tools/bench_row_lengths.py"""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from sot_amd import _native as nat
