@@ -62,7 +62,7 @@ EXPORTS = {
     "sot_oscillator_bank_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp,
                                                    ctypes.c_size_t, _vp]),
     "sot_oscillator_bank_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp,
-                                                    _vp, _vp, ctypes.c_size_t, _vp]),
+                                                    _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
@@ -495,8 +495,9 @@ def spec_distance_backward(target, value, mag_weight, logmag_weight, upstream, g
     return gt, gv
 
 
-def oscillator_bank_forward(freq: torch.Tensor, amp: torch.Tensor, sample_rate: float) -> torch.Tensor:
-    """[batch, samples, sinusoids] envelopes -> [batch, samples] audio (sot_oscillator_bank_forward)."""
+def oscillator_bank_forward(freq: torch.Tensor, amp: torch.Tensor, sample_rate: float, return_workspace: bool = False):
+    """[batch, samples, sinusoids] envelopes -> [batch, samples] audio (sot_oscillator_bank_forward).  return_workspace: also
+    return the scratch buffer (it holds the segment start phases, which oscillator_bank_backward can reuse)."""
     require_hip(freq, amp)
     lib = load()
     if freq.ndim != 3 or freq.shape != amp.shape:
@@ -508,7 +509,7 @@ def oscillator_bank_forward(freq: torch.Tensor, amp: torch.Tensor, sample_rate: 
     with _on_device(freq.device):
         check(lib.sot_oscillator_bank_forward(freq.data_ptr(), amp.data_ptr(), batch, samples, k, float(sample_rate), audio.data_ptr(),
                                               ws.data_ptr(), ws.numel(), stream_ptr(freq.device)))
-    return audio
+    return (audio, ws) if return_workspace else audio
 
 
 def _oscillator_workspace(lib, batch, samples, k, device):
@@ -518,15 +519,16 @@ def _oscillator_workspace(lib, batch, samples, k, device):
     return torch.empty(max(need, 8), dtype=torch.uint8, device=device)
 
 
-def oscillator_bank_backward(freq, amp, sample_rate, grad_audio, need_freq=True, need_amp=True):
+def oscillator_bank_backward(freq, amp, sample_rate, grad_audio, need_freq=True, need_amp=True, forward_workspace=None):
     require_hip(freq, amp, grad_audio)
     lib = load()
     freq, amp, grad_audio = freq.contiguous(), amp.contiguous(), grad_audio.contiguous()
     batch, samples, k = freq.shape
     gf = torch.empty_like(freq) if need_freq else None
     ga = torch.empty_like(amp) if need_amp else None
-    ws = _oscillator_workspace(lib, batch, samples, k, freq.device)
+    ws = forward_workspace if forward_workspace is not None else _oscillator_workspace(lib, batch, samples, k, freq.device)
     with _on_device(freq.device):
         check(lib.sot_oscillator_bank_backward(freq.data_ptr(), amp.data_ptr(), batch, samples, k, float(sample_rate), grad_audio.data_ptr(),
-                                               _ptr(gf), _ptr(ga), ws.data_ptr(), ws.numel(), stream_ptr(freq.device)))
+                                               _ptr(gf), _ptr(ga), ws.data_ptr(), ws.numel(), 0 if forward_workspace is None else 1,
+                                               stream_ptr(freq.device)))
     return gf, ga

@@ -285,7 +285,7 @@ int sot_oscillator_bank_forward(const float* freq, const float* amp, int64_t bat
 
 int sot_oscillator_bank_backward(const float* freq, const float* amp, int64_t batch, int64_t samples, int sinusoids, float sample_rate,
                                  const float* grad_audio, float* grad_freq, float* grad_amp, void* workspace, size_t workspace_bytes,
-                                 void* stream)
+                                 int workspace_from_forward, void* stream)
 {
     using namespace sot_osc;
     if (const int rc = check_common(batch, samples, sinusoids, sample_rate)) return rc;
@@ -305,7 +305,8 @@ int sot_oscillator_bank_backward(const float* freq, const float* amp, int64_t ba
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const unsigned grid = (unsigned)(batch * a.nseg);
     (void)hipGetLastError();
-    if (!launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
+    // the forward of the SAME envelopes left every segment's start phase in the first half of this workspace
+    if (!workspace_from_forward && !launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
     hipLaunchKernelGGL(oscillator_tile_kernel<kBackward>, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kBackward), st, a);
     if (grad_freq != nullptr) {
         if (a.nseg > 1) {

@@ -97,16 +97,17 @@ class _OscillatorBank(torch.autograd.Function):
     def forward(ctx, freq, amp, sample_rate):
         from . import _native as nat
         freq, amp = freq.contiguous(), amp.contiguous()
-        ctx.save_for_backward(freq, amp)
+        audio, ws = nat.oscillator_bank_forward(freq, amp, sample_rate, return_workspace=True)
+        ctx.save_for_backward(freq, amp, ws)   # ws: the segment start phases, reused by the backward
         ctx.sample_rate = sample_rate
-        return nat.oscillator_bank_forward(freq, amp, sample_rate)
+        return audio
 
     @staticmethod
     def backward(ctx, grad_audio):
         from . import _native as nat
-        freq, amp = ctx.saved_tensors
+        freq, amp, ws = ctx.saved_tensors
         gf, ga = nat.oscillator_bank_backward(freq, amp, ctx.sample_rate, grad_audio.float(), need_freq=ctx.needs_input_grad[0],
-                                              need_amp=ctx.needs_input_grad[1])
+                                              need_amp=ctx.needs_input_grad[1], forward_workspace=ws)
         return gf, ga, None
 
 

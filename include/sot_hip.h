@@ -220,7 +220,11 @@ int sot_oscillator_bank_forward(const float *freq, const float *amp, int64_t bat
 /* gradients w.r.t. the envelopes (either may be NULL) given dL/d(audio) */
 int sot_oscillator_bank_backward(const float *freq, const float *amp, int64_t batch, int64_t samples, int sinusoids,
                                  float sample_rate, const float *grad_audio, float *grad_freq, float *grad_amp,
-                                 void *workspace, size_t workspace_bytes, void *stream);
+                                 void *workspace, size_t workspace_bytes,
+                                 int workspace_from_forward /* 1: `workspace` is the buffer sot_oscillator_bank_forward was
+                                    given for the SAME envelopes and has not been written since: its segment start phases
+                                    are reused instead of recomputed */,
+                                 void *stream);
 
 /* ---- Spectral distance of the reference's MSSLoss (losses.py:365-425 with mean_difference
  * losses.py:7-36 and safe_log utils.py:145-151) over `count` magnitudes target[i], value[i]:

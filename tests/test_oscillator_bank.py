@@ -61,7 +61,11 @@ def test_hip_oscillator_bank_against_torch_autograd(batch, samples, k):
     up = torch.randn(batch, samples, generator=g).to(dev)
     f1, a1 = f.clone().requires_grad_(True), a.clone().requires_grad_(True)
     got = spectra.oscillator_bank(f1, a1, 16000)
-    (got * up).sum().backward()
+    (got * up).sum().backward(retain_graph=True)
+    first = (f1.grad.clone(), a1.grad.clone())
+    f1.grad = a1.grad = None
+    (got * up).sum().backward()   # the backward reuses the forward's segment phases: a second walk gives the same bits
+    assert torch.equal(f1.grad, first[0]) and torch.equal(a1.grad, first[1])
     # the same composition in float64 on the fp32-rounded phases is not expressible; compare with the CPU composition
     f2, a2 = f.cpu().clone().requires_grad_(True), a.cpu().clone().requires_grad_(True)
     want = spectra.oscillator_bank(f2, a2, 16000)
