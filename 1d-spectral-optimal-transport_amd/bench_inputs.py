@@ -1,0 +1,43 @@
+"""Seeded synthetic inputs of the BASELINE.json workloads (bench.py's timed inputs and the shapes its `extras` report).
+
+CPU generator => identical tensors on every host with the same torch build.  `spectrum_pairs` is the recipe of
+BASELINE.md §4 (`torch.Generator().manual_seed(seed)`, x drawn before y; "peaky" = U^8, close to real harmonic spectra);
+`ragged_supports` is BASELINE config 4 (per-row amplitude cutoff tau_r = 10^U[-3,-0.3] * max_r -> variable supports) in
+both input forms (zero-masked dense rows and CSR).  tests/test_host_api.py checks that `spectrum_pairs` is the generator
+the golden fixtures were made with (oracle/inputs.gen_inputs), so the stored reference scalars apply to these tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def spectrum_pairs(kind: str, rows: int, n: int, m: int, seed: int):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(rows, n, generator=g)
+    y = torch.rand(rows, m, generator=g)
+    if kind == "peaky":
+        x, y = x ** 8, y ** 8
+    elif kind != "uniform":
+        raise ValueError(kind)
+    return x.contiguous(), y.contiguous()
+
+
+def ragged_supports(rows: int = 8192, n: int = 512, seed: int = 1234):
+    """BASELINE config 4.  Returns dict(dense=(xm, ym), csr=((xw, xp, xoff), (yw, yp, yoff)), max_n, max_m, pos, kept)
+    on the CPU: masked-dense rows (entries below the row's threshold set to 0) and the same supports in CSR form
+    (concatenated kept weights and their positions, int64 offsets [rows + 1])."""
+    x, y = spectrum_pairs("peaky", rows, n, n, seed)
+    g = torch.Generator().manual_seed(seed)
+    tau = 10 ** (-3 + 2.7 * torch.rand(rows, 1, generator=g))
+    keep_x, keep_y = x >= tau * x.amax(1, keepdim=True), y >= tau * y.amax(1, keepdim=True)
+    pos = torch.linspace(0, 1, n)
+
+    def csr(dense, keep):
+        off = torch.zeros(rows + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(keep.sum(1), 0)
+        return dense[keep].contiguous(), pos.expand_as(dense)[keep].contiguous(), off
+
+    zero = torch.zeros(())
+    return {"dense": (torch.where(keep_x, x, zero).contiguous(), torch.where(keep_y, y, zero).contiguous()),
+            "csr": (csr(x, keep_x), csr(y, keep_y)), "max_n": int(keep_x.sum(1).max()), "max_m": int(keep_y.sum(1).max()),
+            "pos": pos, "kept": float(keep_x.sum() + keep_y.sum()) / (2 * rows)}

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- SOT-loss evaluations/s on [B, N_fft] spectrum pairs (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1: when the process is not already a rank (no RANK in the environment) it starts N fresh
+rank processes -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...` as a
+CHILD process, before anything here touches a GPU -- forwards rank 0's JSON line and exits with the children's return
+code; when it already is a rank (the driver launches it that way) WORLD_SIZE must equal --gpus.  Fewer visible GPUs than
+N is an error (non-zero exit), never a 1-GPU number.
 
 A "step" is one pass of the hot path over one batch of synthetic spectrum pairs already resident in
 HBM: Wasserstein1D forward (fused HIP kernel + fixed-order mean).  With N>1 every rank owns its own
@@ -55,17 +61,168 @@ def parse():
                          "overlaps the next step's forward kernel; 0 (default) = 1 on one GPU (per-kernel times then agree "
                          "with rocprofv3), 2 when there is a collective to hide (N > 1)")
     ap.add_argument("--cpu-rows", type=int, default=2048)
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads reported under `extras`")
     return ap.parse_args()
+
+
+# kernel the shared-position forward dispatches for a row length (csrc/sot_forward_full.inc: dispatch_forward_full):
+# threads per row, rows per workgroup, compile-time row length (0: the row fills its geometry)
+FULL_ROW_GEOMETRY = {512: (64, 4, 0), 1024: (128, 2, 0), 2048: (256, 1, 0), 4096: (512, 1, 0), 8192: (1024, 1, 0),
+                     129: (64, 4, 129), 257: (64, 4, 257), 513: (128, 2, 513), 1025: (192, 1, 1025), 2049: (320, 1, 2049)}
+
+
+def forward_kernel_name(n, mode, backward=False):
+    """Name of the dominant kernel as rocprofv3 lists it (template arguments G, CPT, ROWS, PM, LIM, SQ, NX[, WANT_X])."""
+    c = MODES[mode]
+    pm, lim, sq = int(c.get("p", 1)), bool(c.get("limit_quantile_range", False)), bool(c.get("square_dist", False))
+    geo = FULL_ROW_GEOMETRY.get(n)
+    b = lambda v: "true" if v else "false"  # noqa: E731
+    if geo is None or pm not in (1, 2):
+        return "sot_backward_kernel (generic)" if backward else "sot_forward_kernel (generic)"
+    g, rows, nx = geo
+    if backward:
+        return f"sot_backward_full_kernel<{g}, 8, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false>"
+    return f"sot_forward_full_kernel<{g}, 8, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
+
+
+def launcher_command(gpus, argv, port, python=None):
+    """The child command that starts `gpus` rank processes of this script (one per GPU) on this node."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 from a plain process: start the N ranks as a child process tree and forward its output.  Nothing in
+    this (parent) process initialises a GPU: torch.cuda.device_count() only counts devices."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible; refusing to report a "
+                         f"{visible}-GPU number as a {args.gpus}-GPU one\n")
+        return 3
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(launcher_command(args.gpus, argv, port), env=env)  # stdout/stderr inherited: rank 0's JSON line passes through
+    return proc.returncode
+
+
+def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
+    """Secondary measurements outside the contract's timed region (N = 1 only), one entry per workload the README / DESIGN
+    quote: each entry carries the call's time (HIP events on the launch stream around n back-to-back calls), the kernel it
+    is dominated by, the algorithmic bytes of SURVEY 8(d) and their fraction of the 8 TB/s HBM peak.  Inputs rotate over
+    two sets; shapes other than the headline's are smaller than the Infinity Cache and say so ("l3_resident")."""
+    from sot_amd import spectra
+    from sot_amd.bench_inputs import ragged_supports, spectrum_pairs
+    from sot_amd.losses import Wasserstein1D, wasserstein_1d_csr
+    out = {}
+
+    def entry(ms, kernel, nbytes, **kw):
+        return {"ms": ms, "kernel": kernel, "algorithmic_bytes": nbytes, "achieved_gbs": nbytes / (ms * 1e-3) / 1e9,
+                "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, **kw}
+
+    def sot_entries(tag, rows, nbins, pairs, px, py, l3):
+        cut = Wasserstein1D(**MODES["cutoff"]).to(dev)
+        cm = [cut._marshal(x, y, px, py, {}) for x, y in pairs]
+        one = torch.ones(1, device=dev)
+        k = len(cm)
+
+        def fwd(i):
+            x2, y2, xp, yp, flags, plan, _ = cm[i % k]
+            nat.forward_rows(x2, y2, xp, yp, float(cut.p), flags, plan)
+
+        def fwd_mean(i):
+            x2, y2, xp, yp, flags, plan, _ = cm[i % k]
+            nat.loss_fused(x2, y2, xp, yp, float(cut.p), flags, plan)
+
+        def bwd_y(i):
+            x2, y2, xp, yp, flags, plan, _ = cm[i % k]
+            nat.backward_rows(x2, y2, xp, yp, float(cut.p), flags, one, need_gx=False, plan=plan, grad_scale=1.0 / rows)
+
+        def loss_and_grad(i):   # the training form: loss, batch mean and d mean / d y out of one pass over the rows
+            x2, y2, xp, yp, flags, plan, _ = cm[i % k]
+            nat.loss_and_grad(x2, y2, xp, yp, float(cut.p), flags, plan)
+
+        fb = 4 * 2 * nbins + 4
+        with torch.no_grad():
+            out[f"{tag}_cutoff_forward"] = entry(timed(fwd, n), forward_kernel_name(nbins, "cutoff"), rows * fb, l3_resident=l3)
+            out[f"{tag}_cutoff_forward_with_mean"] = entry(timed(fwd_mean, n), forward_kernel_name(nbins, "cutoff") + " + batch mean", rows * fb, l3_resident=l3)
+            out[f"{tag}_cutoff_backward_y"] = entry(timed(bwd_y, n), forward_kernel_name(nbins, "cutoff", backward=True), rows * (fb + 4 * nbins), l3_resident=l3)
+            out[f"{tag}_cutoff_loss_and_grad"] = entry(timed(loss_and_grad, n), forward_kernel_name(nbins, "cutoff", backward=True) + " + batch mean",
+                                                       rows * (fb + 4 * nbins), l3_resident=l3)
+        return cut
+
+    # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
+    B, N = sets[0][0].shape
+    cut = sot_entries(f"b{B}n{N}", B, N, sets, pos_x, pos_y, l3=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
+    ys = [s_[1].clone().requires_grad_(True) for s_ in sets[:2]]
+
+    def autograd_step(i):   # the module through autograd: what a training loop calls
+        yv = ys[i % 2]
+        yv.grad = None
+        cut(sets[i % 2][0], yv, x_pos=pos_x, y_pos=pos_y).backward()
+
+    out[f"b{B}n{N}_cutoff_module_forward_backward"] = entry(timed(autograd_step, n), "autograd: loss_and_grad + scale", B * (12 * N + 4))
+    del ys
+
+    # (2) the paper's own row shape: one-sided spectra of n_fft 2048 (1025 bins), 16384 rows, rfftfreq / max positions
+    g = torch.Generator(device=dev).manual_seed(7)
+    pf = spectra.unit_frequencies(2048, 16000.0, dev)
+    pairs = [(torch.rand(16384, 1025, device=dev, generator=g), torch.rand(16384, 1025, device=dev, generator=g)) for _ in range(2)]
+    sot_entries("b16384n1025", 16384, 1025, pairs, pf, pf.clone(), l3=True)
+    del pairs
+
+    # (3) BASELINE config 4: 8192 x 512 peaky rows with a per-row amplitude cutoff, masked-dense and CSR forms
+    rs = ragged_supports(8192, 512, 1234)
+    xm, ym = (t.to(dev) for t in rs["dense"])
+    (xw, xp_, xo), (yw, yp_, yo) = [tuple(t.to(dev) for t in side) for side in rs["csr"]]
+    p512 = rs["pos"].to(dev)
+    p512b = p512.clone()
+    plan512 = nat.PositionPlan(p512, p512b)
+    kw = dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    flags = 15
+    dense_bytes = 8192 * (8 * 512 + 4)
+    csr_bytes = 8 * (xw.numel() + yw.numel()) + 16 * (8192 + 1) + 4 * 8192
+    with torch.no_grad():
+        out["config4_b8192n512_masked_dense_forward"] = entry(
+            timed(lambda i: nat.forward_rows(xm, ym, p512, p512b, 2.0, flags, plan512), n), forward_kernel_name(512, "cutoff"), dense_bytes,
+            l3_resident=True, mean_kept_support=rs["kept"])
+        out["config4_b8192n512_csr_forward"] = entry(
+            timed(lambda i: wasserstein_1d_csr(xw, xp_, xo, yw, yp_, yo, rs["max_n"], rs["max_m"], **kw), n), "sot_forward_kernel<CSR>",
+            csr_bytes, l3_resident=True, mean_kept_support=rs["kept"])
+    del xm, ym, xw, xp_, yw, yp_
+
+    # (4) BASELINE config 5: 256 harmonic clips -> STFT x2 (n_fft 2048, hop 256, flattop; 16 frames) -> SOT paper mode
+    #     forward + backward into the estimate's audio (4096 rows x 1025 bins)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    target = spectra.harmonic_batch(256, generator=gen, device=dev)
+    estimates = [spectra.harmonic_batch(256, generator=gen, device=dev).requires_grad_(True) for _ in range(2)]
+    mod5 = Wasserstein1D(**MODES["cutoff"]).to(dev)
+
+    def train_step(i):
+        e = estimates[i % 2]
+        e.grad = None
+        spectra.training_step_slice(mod5, target, e).backward()
+
+    ms5 = timed(train_step, n)
+    # bytes the slice must move: both clips' audio in, the estimate's audio gradient out (spectra stay on chip in the ideal)
+    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<192,...,1025,false> + stft backward",
+                                               3 * 256 * 4096 * 4, steps_per_s=1e3 / ms5, rows=4096, bins=1025)
+    return out
 
 
 def cpu_baseline(mode, n, rows, seed):
     """The reference's CPU PyTorch path (op-for-op restatement) on this host's cores, bounded sample.
     ATen's intra-op scaling on this problem saturates well below a big host's core count, so a few thread
     counts are tried (within a ~25 s budget) and the best is reported with the count actually used."""
-    from oracle import torch_restatement as tr
-    from oracle.inputs import gen_inputs
+    from oracle import torch_restatement as tr   # the ONLY use of oracle/ in this file: the timed CPU baseline
+    from sot_amd.bench_inputs import spectrum_pairs
     ncpu = os.cpu_count() or 1
-    x, y = gen_inputs("uniform", rows, n, n, seed)
+    x, y = spectrum_pairs("uniform", rows, n, n, seed)
     pos = torch.linspace(0, 1, n)
     c = MODES[mode]
     kw = dict(p=c.get("p", 1), square_dist=c.get("square_dist", False), dont_normalize=c.get("dont_normalize", False),
@@ -99,6 +256,10 @@ def event_stride(n_lanes):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     # stdout carries exactly ONE line (rank 0's JSON): native libraries print there too (RCCL's version banner at
     # communicator creation), so file descriptor 1 is pointed at stderr for the run and the line goes to the saved descriptor
     sys.stdout.flush()
@@ -106,6 +267,9 @@ def main():
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}\n")
+        sys.exit(4)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SOT_BENCH_FORCE_DIST=1 exercises the RCCL branch even with one rank (used to test it on a 1-GPU box)
     dist_on = world > 1 or (os.environ.get("SOT_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
@@ -120,7 +284,7 @@ def main():
 
     from sot_amd import _native as nat
     from sot_amd.losses import Wasserstein1D
-    from oracle.inputs import gen_inputs
+    from sot_amd.bench_inputs import spectrum_pairs
 
     nat.load(build_if_missing=False)  # must be the prebuilt in-tree library
     B, N = args.rows, args.nfft
@@ -129,7 +293,7 @@ def main():
     pos_y = pos_x.clone()
 
     # set 0: the BASELINE recipe (CPU generator, seed 1234 + rank, x drawn before y); others: device RNG
-    x0, y0 = gen_inputs("uniform", B, N, N, 1234 + rank)
+    x0, y0 = spectrum_pairs("uniform", B, N, N, 1234 + rank)
     sets = [(x0.to(dev), y0.to(dev))]
     g = torch.Generator(device=dev).manual_seed(99 + rank)
     for _ in range(args.sets - 1):
@@ -138,6 +302,7 @@ def main():
     # The rotating inputs are fixed tensors: their marshalled form (contiguous [B, N] views, flag word, position plan) is
     # computed once; a step then is exactly the FFI calls Wasserstein1D.forward makes (no GPU work is skipped).
     marshalled = [mod._marshal(x, y, pos_x, pos_y, {}) for x, y in sets]
+    n_sets = len(sets)
 
     # Steps are independent.  With N > 1 (or --lanes 2) they are issued on TWO alternating HIP streams: one step's batch-mean
     # kernel and its RCCL all-reduce then overlap the next step's forward kernel instead of leaving the GPU idle for the
@@ -269,39 +434,9 @@ def main():
                 x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
                 nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan), sum_out=ring[i % len(ring)])
         extras["ms_per_step_without_collective"] = timed(local_only, n_extra)
-    else:
-        cut = Wasserstein1D(**MODES["cutoff"]).to(dev)
-        ys = [s_[1].clone().requires_grad_(True) for s_ in sets[:2]]
-
-        def fwd_cutoff(i):
-            with torch.no_grad():
-                cut(sets[i % len(sets)][0], sets[i % len(sets)][1], x_pos=pos_x, y_pos=pos_y)
-
-        def fwd_bwd_cutoff(i):
-            yv = ys[i % 2]
-            yv.grad = None
-            cut(sets[i % 2][0], yv, x_pos=pos_x, y_pos=pos_y).backward()
-
-        cm = [cut._marshal(x, y, pos_x, pos_y, {}) for x, y in sets[:2]]
-        one = torch.ones(1, device=dev)
-
-        def fwd_bwd_cutoff_kernels(i):  # the kernels of the autograd step above through the FFI alone (no autograd bookkeeping)
-            x2, y2, xp, yp, flags, plan, _ = cm[i % 2]
-            with torch.no_grad():
-                nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(cut.p), flags, plan))
-                nat.backward_rows(x2, y2, xp, yp, float(cut.p), flags, one, need_gx=False, plan=plan, grad_scale=1.0 / B)
-
-        def loss_and_grad_cutoff(i):  # the training form: loss and d loss / d y out of one pass over the rows (+ the mean kernel)
-            x2, y2, xp, yp, flags, plan, _ = cm[i % 2]
-            with torch.no_grad():
-                nat.loss_and_grad(x2, y2, xp, yp, float(cut.p), flags, plan)
-
-        extras["paper_cutoff_mode_forward_ms_per_step"] = timed(fwd_cutoff, n_extra)
-        # the module through autograd: the gradient w.r.t. y comes out of the same pass as the loss
-        extras["paper_cutoff_mode_forward_backward_ms_per_step"] = timed(fwd_bwd_cutoff, n_extra)
-        extras["paper_cutoff_mode_forward_backward_kernels_ms_per_step"] = timed(fwd_bwd_cutoff_kernels, n_extra)  # separate forward, mean, backward
-        extras["paper_cutoff_mode_loss_and_grad_ms_per_step"] = timed(loss_and_grad_cutoff, n_extra)
-        del ys
+    elif not args.no_extras:
+        del sets[4:], marshalled[4:]   # four rotating sets (512 MiB) still exceed the Infinity Cache
+        extras.update(other_workloads(dev, nat, sets, pos_x, pos_y, timed, n_extra))
     bytes_per_row = 4 * (N + N) + 4  # fwd, shared positions
     achieved = bytes_per_row * B / (kern_ms * 1e-3) / 1e9
 
@@ -326,14 +461,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SOT-2048 config: B={B} rows/GPU x N_fft={N} fp32 spectrum pairs, forward, mode {args.mode} "
-                                   f"({json.dumps(MODES[args.mode])}), shared linspace positions, {len(sets)} rotating input sets "
-                                   f"({len(sets) * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",
+                                   f"({json.dumps(MODES[args.mode])}), shared linspace positions, {n_sets} rotating input sets "
+                                   f"({n_sets * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",
                        "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "prewarm_steps": args.prewarm, "global_rows": world * B,
                        "streams": n_lanes,
                        "collective": "none" if not dist_on else "one RCCL all-reduce(SUM) of the fp64 partial sum per step" + (" (HIP-graph replay)" if args.graph_steps else ""),
                        "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "sot_forward_full_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": forward_kernel_name(N, args.mode),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B},
             "extras": extras,
         }

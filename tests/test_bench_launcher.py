@@ -1,0 +1,64 @@
+"""bench.py --gpus N: the rank launcher (CPU; no GPU is touched).  BASELINE config 3 / SURVEY 8(e): one process per GPU."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launcher_command_starts_one_rank_per_gpu():
+    b = _bench_module()
+    cmd = b.launcher_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29511, python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    k = cmd.index(BENCH)
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]   # the ranks see the same arguments
+
+
+def test_more_gpus_than_visible_is_an_error_not_a_smaller_run():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this host has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""                       # no JSON line: nothing was measured
+    assert "--gpus 2" in r.stderr and "visible" in r.stderr
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 4
+    assert "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_kernel_name_follows_shape_and_mode():
+    b = _bench_module()
+    assert b.forward_kernel_name(2048, "p1") == "sot_forward_full_kernel<256, 8, 1, 1, false, false, 0>"
+    assert b.forward_kernel_name(1025, "cutoff") == "sot_forward_full_kernel<192, 8, 1, 2, true, true, 1025>"
+    assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<192, 8, 1, 2, true, true, 1025, false>"
+    assert "generic" in b.forward_kernel_name(3000, "p1")
+
+
+def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
+    src = open(BENCH).read()
+    body = src.split("def cpu_baseline", 1)
+    assert "from oracle" not in body[0] and "import oracle" not in body[0]
+    after = body[1].split("\ndef ", 1)[1]   # everything behind cpu_baseline()
+    assert "from oracle" not in after and "import oracle" not in after

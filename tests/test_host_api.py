@@ -104,3 +104,20 @@ def test_shard_rows_partition():
             assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_inputs_are_the_fixture_generator():
+    """bench.py draws its timed inputs from the package (sot_amd.bench_inputs), not from oracle/: the tensors must be the
+    ones the golden scalars (tests/golden/manifest.json: _config2_*, _config4_*) were computed on."""
+    import torch
+    from oracle.inputs import gen_inputs
+    from sot_amd.bench_inputs import ragged_supports, spectrum_pairs
+    for kind in ("uniform", "peaky"):
+        a, b = gen_inputs(kind, 5, 67, 61, 1234), spectrum_pairs(kind, 5, 67, 61, 1234)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    rs = ragged_supports(32, 64, 9)
+    xm, ym = rs["dense"]
+    (xw, xp, xo), (yw, yp, yo) = rs["csr"]
+    assert int(xo[-1]) == xw.numel() == int((xm != 0).sum()) and int(yo[-1]) == yw.numel() == int((ym != 0).sum())
+    r = 7
+    assert torch.equal(xw[xo[r]:xo[r + 1]], xm[r][xm[r] != 0]) and torch.equal(xp[xo[r]:xo[r + 1]], rs["pos"][xm[r] != 0])
