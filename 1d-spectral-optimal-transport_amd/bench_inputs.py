@@ -3,8 +3,8 @@
 CPU generator => identical tensors on every host with the same torch build.  `spectrum_pairs` is the recipe of
 BASELINE.md §4 (`torch.Generator().manual_seed(seed)`, x drawn before y; "peaky" = U^8, close to real harmonic spectra);
 `ragged_supports` is BASELINE config 4 (per-row amplitude cutoff tau_r = 10^U[-3,-0.3] * max_r -> variable supports) in
-both input forms (zero-masked dense rows and CSR).  tests/test_host_api.py checks that `spectrum_pairs` is the generator
-the golden fixtures were made with (oracle/inputs.gen_inputs), so the stored reference scalars apply to these tensors.
+both input forms (zero-masked dense rows and CSR).  tests/test_host_api.py checks that `spectrum_pairs` draws exactly the
+tensors the golden fixtures were computed on, so the stored reference scalars apply to them.
 """
 from __future__ import annotations
 
