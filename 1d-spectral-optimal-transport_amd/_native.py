@@ -22,6 +22,8 @@ FLAG_NO_SPECIALIZE = 32  # diagnostic: generic forward kernel only (include/sot_
 
 SOT_OK = 0
 SOT_ERR_INVALID_P = -1
+ABI_VERSION = 2                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
 
@@ -39,7 +41,7 @@ EXPORTS = {
     "sot_abi_version": (ctypes.c_int, []),
     "sot_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "sot_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(SotProblem)]),
-    "sot_w1d_loss_and_grad": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, _vp, _vp, ctypes.c_float, _vp, _vp,
+    "sot_w1d_loss_and_grad": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, _vp, _vp, ctypes.c_float, _vp, _vp, _vp,
                                              ctypes.c_size_t, _vp]),
     "sot_scale_inplace": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp]),
     "sot_prepare_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -49,7 +51,7 @@ EXPORTS = {
     "sot_w1d_backward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, _vp,
                                         ctypes.c_size_t, _vp]),
     "sot_w1d_loss": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp, _vp,
-                                    _vp, ctypes.c_size_t, _vp]),
+                                    _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_quantiles": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, _vp, _vp,
                                          ctypes.c_size_t, _vp]),
     "sot_w1d_forward_csr": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64,
@@ -92,17 +94,20 @@ def load(build_if_missing: bool = True):
         if _lib is not None:
             return _lib
         path = library_path()
-        if not os.path.exists(path):
+        if path == _build.LIB and _build.is_stale():   # missing, or built from other sources than the tree's (build.py: digest)
             if not build_if_missing:
-                raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (build()) first")
-            _build.build()
+                what = "is missing" if not os.path.exists(path) else "was built from different sources than the ones in this tree"
+                raise RuntimeError(f"{path} {what}: run `python __graft_entry__.py` (build()) first")
+            _build.build(force=True)
+        elif not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing")
         lib = ctypes.CDLL(path)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)  # AttributeError here = ABI mismatch, reported loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.sot_abi_version() != 1:
-            raise RuntimeError("libsot_hip.so ABI version mismatch")
+        if lib.sot_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libsot_hip.so has ABI version {lib.sot_abi_version()}, this binding expects {ABI_VERSION}")
         _lib = lib
     return _lib
 
@@ -220,6 +225,50 @@ class PositionPlan:
             torch.cuda.current_stream(device).wait_event(self.ready)
 
 
+_counter_pools = {}   # device index -> ([slots, COMPLETION_COUNTER_WORDS] zero-filled int32 tensor, {stream pointer: slot})
+_COUNTER_SLOTS = 64
+
+
+def completion_counters(device):
+    """Device pointer of the completion-counter words (include/sot_hip.h: sot_w1d_loss) for torch's current stream on
+    `device`, or None when the in-kernel batch mean cannot be used safely: the kernels leave the words zero, so one
+    zero-filled buffer per (device, stream) serves every call that stream orders.  None (-> the separate mean kernel)
+    while a stream is being captured before the device's pool exists (no allocation inside a capture) and when more than
+    _COUNTER_SLOTS streams have asked."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _counter_pools.get(idx)
+    if pool is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        with _lock:
+            pool = _counter_pools.get(idx)
+            if pool is None:
+                buf = torch.zeros(_COUNTER_SLOTS, COMPLETION_COUNTER_WORDS, dtype=torch.int32, device=torch.device("cuda", idx))
+                torch.cuda.current_stream(idx).synchronize()   # once per device: the zero fill is done before any stream uses it
+                pool = _counter_pools[idx] = (buf, {})
+    buf, slots = pool
+    sp = torch._C._cuda_getCurrentRawStream(idx)
+    slot = slots.get(sp)
+    if slot is None:
+        with _lock:
+            slot = slots.get(sp)
+            if slot is None:
+                if len(slots) >= _COUNTER_SLOTS:
+                    return None
+                slot = slots[sp] = len(slots)
+    return buf.data_ptr() + 4 * COMPLETION_COUNTER_WORDS * slot
+
+
+# Batch mean inside the row kernel's last workgroup (one kernel) instead of the separate mean kernel.  OFF by default: on
+# MI355X the hand-off (counter round trips, agent-scope acquire, re-read of the row losses by one workgroup) costs more than
+# the kernel boundary it removes -- 8192 x 2048: 55.1 us per call as one kernel, 46.9 us as two (tools/ab_mean.py, DESIGN.md).
+FUSED_MEAN = os.environ.get("SOT_FUSED_MEAN", "0") == "1"
+
+
+def _want_tail(fused_mean):
+    return FUSED_MEAN if fused_mean is None else bool(fused_mean)
+
+
 def workspace(pr: SotProblem, device) -> torch.Tensor:
     nbytes = load().sot_workspace_bytes(ctypes.byref(pr))
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
@@ -241,26 +290,30 @@ def forward_rows(x, y, xpos, ypos, p, flags, plan=None, out=None) -> torch.Tenso
     return row_loss
 
 
-def loss_fused(x, y, xpos, ypos, p, flags, plan=None, denom=None, hinge=None, want_sum=False):
-    """Forward + batch mean behind one FFI call (sot_w1d_loss: two back-to-back kernels).  Returns (mean 0-d fp32, row_loss [B], sum fp64 or None)."""
+def loss_fused(x, y, xpos, ypos, p, flags, plan=None, denom=None, hinge=None, want_sum=False, fused_mean=None, row_out=None,
+               mean_out=None, sum_out=None):
+    """Forward + batch mean behind one FFI call (sot_w1d_loss): the forward kernel and the mean kernel back to back, or --
+    fused_mean=True (default: module switch FUSED_MEAN) -- ONE kernel whose last workgroup reduces the row losses (same bits).  Returns (mean 0-d fp32, row_loss [B], sum fp64 or None).
+    row_out / mean_out / sum_out: optional preallocated outputs ([B] fp32, 1-element fp32, 1-element fp64)."""
     lib = load()
     dev = x.device
     B = x.shape[0]
-    row_loss = torch.empty(B, dtype=torch.float32, device=dev)
-    mean = torch.empty((), dtype=torch.float32, device=dev)
-    total = torch.empty((), dtype=torch.float64, device=dev) if want_sum else None
+    row_loss = row_out if row_out is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    mean = mean_out if mean_out is not None else torch.empty((), dtype=torch.float32, device=dev)
+    total = sum_out if sum_out is not None else (torch.empty((), dtype=torch.float64, device=dev) if want_sum else None)
     pr = make_problem(x, y, xpos, ypos, p, flags, plan)
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
         rc = lib.sot_w1d_loss(ctypes.byref(pr), row_loss.data_ptr(), float(B if denom is None else denom),
                               0 if hinge is None else 1, 0.0 if hinge is None else float(hinge), mean.data_ptr(),
-                              _ptr(total), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
+                              _ptr(total), completion_counters(dev) if _want_tail(fused_mean) else None,
+                              _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return mean, row_loss, total
 
 
-def loss_and_grad(x, y, xpos, ypos, p, flags, plan=None):
+def loss_and_grad(x, y, xpos, ypos, p, flags, plan=None, fused_mean=None):
     """Training form (sot_w1d_loss_and_grad): (mean 0-d fp32, row_loss [B], d mean / d y [B, m]) -- one pass over the rows
     where a compile-time backward kernel exists."""
     lib = load()
@@ -274,6 +327,7 @@ def loss_and_grad(x, y, xpos, ypos, p, flags, plan=None):
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
         rc = lib.sot_w1d_loss_and_grad(ctypes.byref(pr), row_loss.data_ptr(), float(B), mean.data_ptr(), None, 1.0 / B, gy.data_ptr(),
+                                       completion_counters(dev) if _want_tail(fused_mean) else None,
                                        _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return mean, row_loss, gy

@@ -35,11 +35,28 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
+DIGEST = LIB + ".digest"   # sha256 of the sources the library was built from (git-ignored, travels with the .so)
+
+
+def source_digest() -> str:
+    """Content hash of every source the library is compiled from (+ the compiler flags): robust against copies of the
+    tree that do not preserve modification times, unlike an mtime comparison."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    """True when libsot_hip.so is missing or was built from other sources than the ones in the tree: a stale library
+    behind a changed C signature would be called with mis-marshalled arguments."""
+    if not (os.path.exists(LIB) and os.path.exists(DIGEST)):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(DIGEST) as f:
+        return f.read().strip() != source_digest()
 
 
 def _compile_part(part, extra_flags, verbose: bool) -> str:
@@ -74,6 +91,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(lib + ".tmp", lib)
+    if out is None and not extra_flags:
+        with open(DIGEST, "w") as f:
+            f.write(source_digest() + "\n")
     return lib
 
 

@@ -233,6 +233,96 @@ __device__ __forceinline__ double wave_suffix_incl_scan(double v)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Batch mean inside the kernel that produces the row losses (losses.py:203-211): the workgroup that finishes LAST reduces
+// row_loss[0, B) with the arithmetic of sot_reduce_mean_kernel, operation for operation (1024 "virtual threads" of 8
+// consecutive rows each, DPP wave sums, 16 wave totals added in order), so the result is bit-identical to the separate
+// kernel's and independent of timing.  Nobody waits: a workgroup only learns, from the value its counter add returns,
+// whether it was the last one.  Hand-off protocol (cdna_hip_programming.md Guideline 16): row losses are written with
+// write-through (sc1) stores; every wave drains them (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds to the
+// counter of its shard (blocks b and b + 8 tend to share an XCD: eight shard counters instead of one hot word), the
+// shard's last arriver adds to the top counter, the overall last arriver runs an agent-scope acquire and the workgroup
+// reads the row losses with sc1 loads.  The last arrivers put the counters back to zero: the caller zero-fills
+// `counters` once and may reuse it for every later launch on the same stream (one launch in flight per counter buffer).
+// ---------------------------------------------------------------------------------------------
+struct MeanTail {
+    unsigned* counters;   // [9] device words, zero between launches: 8 shard counters + the top counter; null = no tail
+    double denom;
+    float* mean_out;      // may be null
+    double* sum_out;      // may be null
+    int apply_hinge;
+    float hinge;
+};
+
+__device__ __forceinline__ void store_row_loss(float* row_loss, int64_t row, float v, bool write_through)
+{
+    if (write_through)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(row_loss) + row, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        row_loss[row] = v;
+}
+
+__device__ __forceinline__ float load_row_loss_sc1(const float* row_loss, int64_t row)
+{
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(row_loss) + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Called by every thread of the workgroup after its last row (all BLOCK threads reach it).  `scratch`: >= 17 doubles of LDS
+// that nothing else uses any more.
+template <int BLOCK>
+__device__ __forceinline__ void batch_mean_tail(const MeanTail& mt, const float* row_loss, int64_t B, double* scratch)
+{
+    static_assert(BLOCK % kWave == 0, "whole wavefronts");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row-loss stores have left the CU
+    __syncthreads();
+    int* const flag = reinterpret_cast<int*>(scratch + 16);
+    if (threadIdx.x == 0) {
+        const unsigned nshard = gridDim.x < 8u ? gridDim.x : 8u;
+        const unsigned shard = blockIdx.x % nshard;
+        const unsigned members = (gridDim.x - shard + nshard - 1u) / nshard;
+        int last = 0;
+        unsigned old = __hip_atomic_fetch_add(mt.counters + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == members - 1u) {
+            __hip_atomic_store(mt.counters + shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __hip_atomic_fetch_add(mt.counters + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == nshard - 1u) {
+                __hip_atomic_store(mt.counters + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int vw = threadIdx.x >> 6; vw < 16; vw += BLOCK / kWave) {   // virtual wave vw of sot_reduce_mean_kernel's 16
+        const int64_t v = (int64_t)vw * kWave + lane;                  // virtual thread
+        double acc = 0.0;
+        for (int64_t base = v * 8; base < B; base += 8192) {
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = (base + k < B) ? load_row_loss_sc1(row_loss, base + k) : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float u = w[k];
+                if (mt.apply_hinge) u = (base + k < B) ? fmaxf(u - mt.hinge, 0.0f) : 0.0f;
+                acc += (double)u;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) scratch[vw] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += scratch[w];
+        if (mt.sum_out) *mt.sum_out = tot;
+        if (mt.mean_out) *mt.mean_out = (float)(tot / mt.denom);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Merge-path partition: i0 = number of U elements among the first D merged elements, with U before V on ties (the
 // order of a stable sort of cat(U, V)): P(i) := U[i] <= V[D-1-i] is true for i < i0 and false from i0 on.
 // Branch-free search with a fixed (wave-uniform) number of rounds and the descending steps 2^k + 1, ..., 9, 5, 3, 2, 1

@@ -14,6 +14,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 
 #include "../../include/sot_hip.h"
 #include "sot_device.hpp"
@@ -127,6 +128,8 @@ struct FwdArgs {
     // CSR (ragged) input form: row r owns entries [off[r], off[r+1]) of the concatenated weights/positions;
     // n, m above are then the MAXIMUM row lengths (LDS is sized for them)
     const int64_t* xoff; const int64_t* yoff;
+    // batch mean by the last workgroup to finish (sot_device.hpp: batch_mean_tail); mt.counters == nullptr: not requested
+    MeanTail mt;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -679,7 +682,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         acc = wave_sum(acc);
         if (CSR && bad_row) acc = __int_as_float(0x7fc00000);
         if (NW == 1) {
-            if (t == 0 && valid && a.row_loss) a.row_loss[row] = acc;
+            if (t == 0 && valid && a.row_loss) store_row_loss(a.row_loss, row, acc, a.mt.counters != nullptr);
             __syncthreads();  // this row's LDS reads are done before the next row's staging
         } else {
             if (c.lane == 0) c.red[c.wv] = acc;
@@ -687,7 +690,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             if (t == 0 && valid && a.row_loss) {
                 float tot = c.red[0];
                 for (int w = 1; w < NW; ++w) tot += c.red[w];
-                a.row_loss[row] = tot;  // NaN propagates from any wave of a bad CSR row
+                store_row_loss(a.row_loss, row, tot, a.mt.counters != nullptr);  // NaN propagates from any wave of a bad CSR row
             }
         }
         SOT_STAMP(8);
@@ -695,6 +698,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         if (wg_stamp && wg_row < 12) wgs[2 + wg_row++] = __builtin_readcyclecounter();
 #endif
     }
+    if (a.mt.counters != nullptr) batch_mean_tail<BLOCK>(a.mt, a.row_loss, a.B, reinterpret_cast<double*>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -925,18 +929,30 @@ static inline void allow_full_lds(const void* kernel)
         (void)hipGetLastError();
 }
 
+// Launch state is kept PER DEVICE and behind a mutex: a process may use several GPUs (the binding switches devices per
+// call), and calls arrive from several host threads (autograd runs backward on its own thread; ctypes drops the GIL).
+constexpr int kMaxDevices = 64;
+static inline int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
+
 static inline int device_cu_count()
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        else
-            cus = 256;
-    }
-    return cus;
+    static std::mutex mu;
+    static int cus[kMaxDevices] = {};
+    const int dev = current_device();
+    const bool cacheable = dev >= 0 && dev < kMaxDevices;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cacheable && cus[dev] > 0) return cus[dev];
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (cacheable) cus[dev] = n;
+    return n;
 }
 
 // Experiment knob (never set in production): SOT_DEBUG_EXTRA_LDS=<bytes> pads the dynamic LDS request of the
@@ -981,6 +997,38 @@ static inline int resident_grid(Kernel kern, int block, size_t lds, int64_t want
     }
     const int64_t cap = (int64_t)device_cu_count() * per_cu;
     return (int)(want < cap ? want : cap);
+}
+
+// resident_grid() of one kernel instantiation, cached per device (and per LDS size: the generic kernels' LDS request
+// depends on n, m); the first use on a device also opts the kernel in to the CU's full LDS THERE (hipFuncSetAttribute
+// applies to the current device only).  One cache per call site: `Tag` is the kernel's own function-pointer type.
+struct GridCache {
+    std::mutex mu;
+    struct Entry { size_t lds; int grid; bool attr; } e[kMaxDevices] = {};
+};
+
+template <typename Kernel>
+static inline int cached_resident_grid(GridCache& gc, Kernel kern, int block, size_t lds)
+{
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) {
+        allow_full_lds(reinterpret_cast<const void*>(kern));
+        return resident_grid(kern, block, lds, INT32_MAX);
+    }
+    std::lock_guard<std::mutex> lock(gc.mu);
+    GridCache::Entry& e = gc.e[dev];
+    if (!e.attr) { allow_full_lds(reinterpret_cast<const void*>(kern)); e.attr = true; }
+    if (e.grid == 0 || e.lds != lds) { e.grid = resident_grid(kern, block, lds, INT32_MAX); e.lds = lds; }
+    return e.grid;
+}
+
+// once per device: opt `kernel` in to the full LDS (kernels launched with a fixed grid)
+static inline void allow_full_lds_once(GridCache& gc, const void* kernel)
+{
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) { allow_full_lds(kernel); return; }
+    std::lock_guard<std::mutex> lock(gc.mu);
+    if (!gc.e[dev].attr) { allow_full_lds(kernel); gc.e[dev].attr = true; }
 }
 
 static inline int validate(const sot_problem* pr)
@@ -1038,9 +1086,10 @@ int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx
                    hipStream_t s);
 int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
 int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V, bool quant,
-                void* workspace, size_t workspace_bytes, void* stream);
+                void* workspace, size_t workspace_bytes, void* stream, const MeanTail* mean_tail = nullptr);
 int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx, float* gy,
-                 void* workspace, size_t workspace_bytes, void* stream, float* row_loss_out = nullptr, bool* fused = nullptr);
+                 void* workspace, size_t workspace_bytes, void* stream, float* row_loss_out = nullptr, bool* fused = nullptr,
+                 const MeanTail* mean_tail = nullptr);
 int run_forward_csr(const float* xw, const float* xp, const int64_t* xoff, int64_t x_nnz, const float* yw, const float* yp,
                     const int64_t* yoff, int64_t y_nnz, int64_t B, int max_n, int max_m, float p, uint32_t flags, float* row_loss,
                     void* stream);
@@ -1078,13 +1127,8 @@ static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int
     auto kern = sot_forward_kernel<G, CPT, ROWPOS, QUANT, PM, LIM, VEC, false, SQM>;
     static const size_t extra_lds = debug_extra_lds();
     lds += extra_lds;
-    static int grid_cap = 0;  // per instantiation; LDS size per (n, m) may differ, so cache per lds value
-    static size_t grid_lds = 0;
-    if (grid_cap == 0 || grid_lds != lds) {
-        allow_full_lds(reinterpret_cast<const void*>(kern));
-        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
-        grid_lds = lds;
-    }
+    static GridCache cache;  // per instantiation (function-local static: thread-safe initialisation)
+    const int grid_cap = cached_resident_grid(cache, kern, block, lds);
     const int grid = (int)(want < grid_cap ? want : grid_cap);
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
@@ -1181,13 +1225,8 @@ template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
 static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
 {
     auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM, LIM, VEC>;
-    static int grid_cap = 0;
-    static size_t grid_lds = 0;
-    if (grid_cap == 0 || grid_lds != lds) {
-        allow_full_lds(reinterpret_cast<const void*>(kern));
-        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
-        grid_lds = lds;
-    }
+    static GridCache cache;  // per instantiation (function-local static: thread-safe initialisation)
+    const int grid_cap = cached_resident_grid(cache, kern, block, lds);
     const int grid = (int)(want < grid_cap ? want : grid_cap);
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
@@ -1361,11 +1400,8 @@ int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx
     const int npad = next_pow2(n > m ? n : m);
     const size_t prep_lds = (size_t)npad * 8 + 16;
     if (prep_lds > kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        allow_full_lds(reinterpret_cast<const void*>(sot_prepare_positions_kernel));
-        attr_set = true;
-    }
+    static GridCache cache;
+    allow_full_lds_once(cache, reinterpret_cast<const void*>(sot_prepare_positions_kernel));
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(sot_prepare_positions_kernel, dim3(2), dim3(1024), prep_lds, s, xpos, ypos, n, m, sx, sy, px, py, ident);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
@@ -1417,13 +1453,14 @@ int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t 
 }
 
 int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V,
-                       bool quant, void* workspace, size_t workspace_bytes, void* stream)
+                       bool quant, void* workspace, size_t workspace_bytes, void* stream, const MeanTail* mean_tail)
 {
     Launch l;
     int rc = setup_launch(pr, false, workspace, workspace_bytes, stream, &l);
     if (rc != SOT_OK) return rc;
     if (pr->B == 0) return SOT_OK;
     l.a.row_loss = row_loss;
+    if (mean_tail != nullptr && row_loss != nullptr) l.a.mt = *mean_tail;  // the batch mean comes out of this launch's last workgroup
     l.a.oUq = uq; l.a.oVq = vq; l.a.oQ = Q; l.a.oU = U; l.a.oV = V;
     // row lengths with a compile-time kernel (forward_full_supports: powers of two 512 ... 8192 and n_fft/2 + 1) take it
     bool full = !l.rowpos && !quant && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && forward_full_supports(pr->n, l.vec) &&
@@ -1440,7 +1477,8 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
 // row_loss_out (loss-and-gradient form): the kernels that can also emit the row losses do so and *fused is set; the caller
 // runs the forward kernel otherwise.  grad_row == nullptr: an upstream gradient of 1 for every row.
 int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gx,
-                        float* gy, void* workspace, size_t workspace_bytes, void* stream, float* row_loss_out, bool* fused)
+                        float* gy, void* workspace, size_t workspace_bytes, void* stream, float* row_loss_out, bool* fused,
+                        const MeanTail* mean_tail)
 {
     Launch l;
     int rc = setup_launch(pr, true, workspace, workspace_bytes, stream, &l);
@@ -1459,6 +1497,7 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 #endif
     if (full && gx == nullptr && row_loss_out != nullptr) {   // the y-only full-row kernel accumulates the loss on its walk
         b.f.row_loss = row_loss_out;
+        if (mean_tail != nullptr) b.f.mt = *mean_tail;
         if (fused) *fused = true;
     }
     const hipError_t e = full       ? dispatch_backward_full(l.cfg, l.pm, b, l.s)
@@ -1476,13 +1515,8 @@ template <int G, int CPT, int PM, bool LIM>
 static hipError_t launch_forward_csr(const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s)
 {
     auto kern = sot_forward_kernel<G, CPT, true, false, PM, LIM, false, true>;
-    static int grid_cap = 0;
-    static size_t grid_lds = 0;
-    if (grid_cap == 0 || grid_lds != lds) {
-        allow_full_lds(reinterpret_cast<const void*>(kern));
-        grid_cap = resident_grid(kern, block, lds, INT32_MAX);
-        grid_lds = lds;
-    }
+    static GridCache cache;  // per instantiation (function-local static: thread-safe initialisation)
+    const int grid_cap = cached_resident_grid(cache, kern, block, lds);
     const int grid = (int)(want < grid_cap ? want : grid_cap);
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
@@ -1613,19 +1647,29 @@ int sot_w1d_backward(const sot_problem* prob, const float* grad_row, int64_t gra
     return sot::run_backward(prob, grad_row, grad_row_stride, grad_scale, grad_x, grad_y, workspace, workspace_bytes, stream);
 }
 
+static inline sot::MeanTail make_tail(uint32_t* counters, double denom, int apply_hinge, float hinge, float* mean_out, double* sum_out)
+{
+    sot::MeanTail mt{};
+    mt.counters = counters; mt.denom = denom; mt.apply_hinge = apply_hinge; mt.hinge = hinge; mt.mean_out = mean_out; mt.sum_out = sum_out;
+    return mt;
+}
+
 int sot_w1d_loss_and_grad(const sot_problem* prob, float* row_loss, double denom, float* mean_out, double* sum_out, float grad_scale,
-                          float* grad_y, void* workspace, size_t workspace_bytes, void* stream)
+                          float* grad_y, uint32_t* completion_counters, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (prob == nullptr) return SOT_ERR_NULL_POINTER;
     if (prob->B == 0) return SOT_ERR_BAD_SHAPE;  // the mean of zero rows is undefined
     if (row_loss == nullptr || grad_y == nullptr || (mean_out == nullptr && sum_out == nullptr)) return SOT_ERR_NULL_POINTER;
+    const sot::MeanTail mt = make_tail(completion_counters, denom, 0, 0.0f, mean_out, sum_out);
+    const sot::MeanTail* tail = completion_counters ? &mt : nullptr;
     bool fused = false;
-    int rc = sot::run_backward(prob, nullptr, 0, grad_scale, nullptr, grad_y, workspace, workspace_bytes, stream, row_loss, &fused);
+    int rc = sot::run_backward(prob, nullptr, 0, grad_scale, nullptr, grad_y, workspace, workspace_bytes, stream, row_loss, &fused, tail);
     if (rc != SOT_OK) return rc;
     if (!fused) {
-        rc = sot::run_forward(prob, row_loss, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes, stream);
+        rc = sot::run_forward(prob, row_loss, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes, stream, tail);
         if (rc != SOT_OK) return rc;
     }
+    if (tail != nullptr) return SOT_OK;  // the kernel that wrote the row losses reduced them
     return sot_w1d_reduce_mean(row_loss, prob->B, denom, 0, 0.0f, mean_out, sum_out, stream);
 }
 
@@ -1642,14 +1686,15 @@ int sot_scale_inplace(float* data, int64_t count, const float* scalar, void* str
 }
 
 int sot_w1d_loss(const sot_problem* prob, float* row_loss, double denom, int apply_hinge, float hinge_threshold, float* mean_out,
-                 double* sum_out, void* workspace, size_t workspace_bytes, void* stream)
+                 double* sum_out, uint32_t* completion_counters, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (prob != nullptr && prob->B > 0 && row_loss == nullptr) return SOT_ERR_NULL_POINTER;
     if (mean_out == nullptr && sum_out == nullptr) return SOT_ERR_NULL_POINTER;
     if (prob != nullptr && prob->B == 0) return SOT_ERR_BAD_SHAPE;  // the mean of zero rows is undefined
+    const sot::MeanTail mt = make_tail(completion_counters, denom, apply_hinge, hinge_threshold, mean_out, sum_out);
     const int rc = sot::run_forward(prob, row_loss, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes,
-                                    stream);
-    if (rc != SOT_OK) return rc;
+                                    stream, completion_counters ? &mt : nullptr);
+    if (rc != SOT_OK || completion_counters != nullptr) return rc;
     return sot_w1d_reduce_mean(row_loss, prob->B, denom, apply_hinge, hinge_threshold, mean_out, sum_out, stream);
 }
 
@@ -1661,11 +1706,8 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
     if (keys == nullptr) return SOT_ERR_NULL_POINTER;
     const size_t lds = (size_t)sot::next_pow2(n) * 8;
     if (lds > sot::kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        sot::allow_full_lds(reinterpret_cast<const void*>(sot::sot_segmented_sort_kernel));
-        attr_set = true;
-    }
+    static sot::GridCache cache;
+    sot::allow_full_lds_once(cache, reinterpret_cast<const void*>(sot::sot_segmented_sort_kernel));
     int per_cu = (int)(sot::kLdsLimit / lds);
     if (per_cu > 8) per_cu = 8;
     int64_t cap = (int64_t)sot::device_cu_count() * per_cu;

@@ -188,8 +188,12 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
     if pos is None:
         p0 = unit_frequencies(n_fft, sample_rate, dev)
         pos = _POSITIONS[key] = (p0, p0.clone())
+    # the one-node form differentiates w.r.t. the estimate only (trainer.py: the target is data); a target that asks for a
+    # gradient takes the composed path below, which differentiates through both transforms like losses.py:316-343
+    target_needs_grad = torch.is_grad_enabled() and audio_target.requires_grad
     fused = (audio_target.is_cuda and audio_target.ndim == 2 and audio_estimate.shape == audio_target.shape and
-             hip_stft_supported(n_fft, hop, audio_target.shape[1]) and not getattr(loss_module, "hinge", False))
+             hip_stft_supported(n_fft, hop, audio_target.shape[1]) and not getattr(loss_module, "hinge", False) and
+             not target_needs_grad)
     if fused:
         from .losses import _flags
         flags = _flags(loss_module.square_dist, bool(loss_module.dont_normalize), bool(loss_module.limit_quantile_range),

@@ -139,6 +139,10 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
             x2, y2, xp, yp, flags, plan, _ = cm[i % k]
             nat.loss_fused(x2, y2, xp, yp, float(cut.p), flags, plan)
 
+        def fwd_mean_one_kernel(i):   # the same with the mean in the row kernel's last workgroup (opt-in, see include/sot_hip.h)
+            x2, y2, xp, yp, flags, plan, _ = cm[i % k]
+            nat.loss_fused(x2, y2, xp, yp, float(cut.p), flags, plan, fused_mean=True)
+
         def bwd_y(i):
             x2, y2, xp, yp, flags, plan, _ = cm[i % k]
             nat.backward_rows(x2, y2, xp, yp, float(cut.p), flags, one, need_gx=False, plan=plan, grad_scale=1.0 / rows)
@@ -151,6 +155,8 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         with torch.no_grad():
             out[f"{tag}_cutoff_forward"] = entry(timed(fwd, n), forward_kernel_name(nbins, "cutoff"), rows * fb, l3_resident=l3)
             out[f"{tag}_cutoff_forward_with_mean"] = entry(timed(fwd_mean, n), forward_kernel_name(nbins, "cutoff") + " + batch mean", rows * fb, l3_resident=l3)
+            out[f"{tag}_cutoff_forward_with_in_kernel_mean"] = entry(timed(fwd_mean_one_kernel, n), forward_kernel_name(nbins, "cutoff") + " (mean by its last workgroup)",
+                                                                      rows * fb, l3_resident=l3)
             out[f"{tag}_cutoff_backward_y"] = entry(timed(bwd_y, n), forward_kernel_name(nbins, "cutoff", backward=True), rows * (fb + 4 * nbins), l3_resident=l3)
             out[f"{tag}_cutoff_loss_and_grad"] = entry(timed(loss_and_grad, n), forward_kernel_name(nbins, "cutoff", backward=True) + " + batch mean",
                                                        rows * (fb + 4 * nbins), l3_resident=l3)
@@ -338,8 +344,8 @@ def main():
                 if n_lanes == 2:
                     cur.wait_stream(other)
                 a.record(cur)
-            # same kernels as Wasserstein1D.forward (sot_w1d_loss), issued as two calls so that the HIP events bracket the
-            # dominant kernel (sot_forward_full_kernel: the forward specialised for rows that fill their geometry) alone
+            # same kernels as Wasserstein1D.forward (sot_w1d_loss: the row kernel, then the fixed-order mean kernel), issued as two
+            # calls so that the HIP events bracket the dominant kernel alone (what rocprofv3 lists under its name)
             rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
             if profile is not None:
                 b.record(cur)
@@ -432,7 +438,7 @@ def main():
         def local_only(i):
             with torch.no_grad():
                 x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
-                nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan), sum_out=ring[i % len(ring)])
+                nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[i % 4]), sum_out=ring[i % len(ring)])
         extras["ms_per_step_without_collective"] = timed(local_only, n_extra)
     elif not args.no_extras:
         del sets[4:], marshalled[4:]   # four rotating sets (512 MiB) still exceed the Infinity Cache

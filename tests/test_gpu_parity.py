@@ -742,3 +742,90 @@ def test_module_early_gradient_matches_the_two_pass_form():
     assert torch.equal(b1, b2)                      # second backward: recomputed by the backward kernel in both forms
     torch.testing.assert_close(a1, a2, rtol=2e-7, atol=1e-37)   # 2.5 * (g / B) rounded in one or two steps (subnormals: atol)
     torch.testing.assert_close(a1, 2.5 * b1, rtol=2e-7, atol=1e-37)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(1, 2048), (7, 300), (130, 257), (1000, 1025), (8192, 2048), (65536, 257), (20000, 512)])
+def test_in_kernel_batch_mean_is_bit_identical_to_the_mean_kernel(B, N):
+    """sot_w1d_loss / sot_w1d_loss_and_grad with completion counters: the last workgroup of the row kernel reduces the row
+    losses (losses.py:203-211) in the order of sot_w1d_reduce_mean -- same bits, every time, also with the hinge, from two
+    streams, and the counters are left zero (any later launch works)."""
+    nat = native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(B + N)
+    x, y = torch.rand(B, N, device=dev, generator=g) ** 4, torch.rand(B, N, device=dev, generator=g) ** 4
+    pos = torch.linspace(0, 1, N, device=dev)
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2)
+    for flags, p in ((8, 1.0), (15, 2.0)):
+        rows = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
+        want_mean, want_sum = nat.reduce_mean(rows, want_sum=True)
+        for rep in range(4):
+            mean, rows2, total = nat.loss_fused(x, y, pos, pos2, p, flags, plan, want_sum=True, fused_mean=True)
+            assert torch.equal(mean, want_mean) and torch.equal(total, want_sum) and torch.equal(rows2, rows)
+        two_kernels = nat.loss_fused(x, y, pos, pos2, p, flags, plan, fused_mean=False)[0]
+        assert torch.equal(two_kernels, want_mean)
+        h = float(rows.median())
+        want_h = nat.reduce_mean(rows, hinge=h)
+        assert torch.equal(nat.loss_fused(x, y, pos, pos2, p, flags, plan, hinge=h, fused_mean=True)[0], want_h)
+        m1, r1, g1 = nat.loss_and_grad(x, y, pos, pos2, p, flags, plan, fused_mean=True)
+        m2, r2, g2 = nat.loss_and_grad(x, y, pos, pos2, p, flags, plan, fused_mean=False)
+        assert torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(g1, g2) and torch.equal(m1, want_mean)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for s in (s1, s2, s1, s2, s1, s2):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                outs.append(nat.loss_fused(x, y, pos, pos2, p, flags, plan, fused_mean=True)[0])
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, want_mean) for o in outs)
+    pool = nat._counter_pools[dev.index if dev.index is not None else torch.cuda.current_device()][0]
+    assert int(pool.abs().sum()) == 0   # every launch put its counters back to zero
+
+
+@pytest.mark.gpu
+def test_two_host_threads_share_the_library():
+    """the entry points are safe to call from several Python threads (ctypes releases the GIL; autograd runs
+    backward on its own thread): launch state (occupancy-sized grids, LDS opt-in) is per device and behind a mutex.  Two
+    threads hammer different kernels, first use included, on their own streams; every result equals the single-threaded one."""
+    import threading
+    nat = native()
+    dev = device()
+    shapes = [(300, 257), (70, 2048), (33, 1025), (90, 300), (64, 512), (20, 4096)]
+    g = torch.Generator(device=dev).manual_seed(1)
+    data = []
+    for B, N in shapes:
+        x, y = torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)
+        pos = torch.linspace(0, 1, N, device=dev)
+        data.append((x, y, pos, pos.clone()))
+    torch.cuda.synchronize()
+    results = [[None] * len(shapes) for _ in range(2)]
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(dev)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                order = range(len(shapes)) if k == 0 else reversed(range(len(shapes)))
+                for i in order:
+                    x, y, pos, pos2 = data[i]
+                    for _ in range(20):
+                        rows = nat.forward_rows(x, y, pos, pos2, 2.0, 15)
+                        gx, gy = nat.backward_rows(x, y, pos, pos2, 2.0, 15, torch.ones(1, device=dev), grad_scale=1.0)
+                    results[k][i] = (rows.clone(), gy.clone())
+            s.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (x, y, pos, pos2) in enumerate(data):
+        rows = nat.forward_rows(x, y, pos, pos2, 2.0, 15)
+        _, gy = nat.backward_rows(x, y, pos, pos2, 2.0, 15, torch.ones(1, device=dev), grad_scale=1.0)
+        for k in range(2):
+            assert torch.equal(results[k][i][0], rows) and torch.equal(results[k][i][1], gy)

@@ -24,7 +24,8 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(handle, name), name
     assert set(sot_amd._native.EXPORTS) == declared
     handle.sot_abi_version.restype = ctypes.c_int
-    assert handle.sot_abi_version() == 1
+    m = re.search(r"#define SOT_ABI_VERSION (\d+)", header)
+    assert handle.sot_abi_version() == int(m.group(1)) == sot_amd._native.ABI_VERSION   # header, library and binding agree
     handle.sot_status_string.restype = ctypes.c_char_p
     assert b"p>=1" in handle.sot_status_string(-1)
 
@@ -121,3 +122,20 @@ def test_bench_inputs_are_the_fixture_generator():
     assert int(xo[-1]) == xw.numel() == int((xm != 0).sum()) and int(yo[-1]) == yw.numel() == int((ym != 0).sum())
     r = 7
     assert torch.equal(xw[xo[r]:xo[r + 1]], xm[r][xm[r] != 0]) and torch.equal(xp[xo[r]:xo[r + 1]], rs["pos"][xm[r] != 0])
+
+
+def test_stale_library_is_detected_by_content_not_by_mtime(tmp_path, monkeypatch):
+    """_native.load() refuses (or rebuilds) a libsot_hip.so that was built from other sources than the tree's: the digest
+    next to the library is a content hash, so a copy of the tree that resets modification times changes nothing."""
+    import sot_amd
+    b = sot_amd.build
+    b.build()
+    assert not b.is_stale()
+    os.utime(b.DEPS[0])                        # newer mtime, same content: still current
+    assert not b.is_stale()
+    monkeypatch.setattr(b, "DIGEST", str(tmp_path / "other.digest"))
+    assert b.is_stale()                         # no digest -> stale
+    (tmp_path / "other.digest").write_text("0" * 64 + "\n")
+    assert b.is_stale()                         # digest of other sources -> stale
+    (tmp_path / "other.digest").write_text(b.source_digest() + "\n")
+    assert not b.is_stale()

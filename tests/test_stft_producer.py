@@ -293,3 +293,28 @@ def test_spec_distance_kernels_against_torch():
         gt, gv = nat.spec_distance_backward(t, v, mw, lw, up, 2.0, 1e-5, l2, need_target=True, need_value=True)
         for gg, rr in ((gt, tt.grad), (gv, vv.grad)):
             assert float((gg - 3.0 * rr).abs().max()) <= 1e-5 * float(rr.abs().max()) * 3.0
+
+
+@pytest.mark.gpu
+def test_training_step_slice_differentiates_the_target_when_asked():
+    """losses.py:316-343 backpropagates through both transforms: a target that requires a gradient must receive the one
+    the composed path (STFT -> module) gives, not a silent None from the one-node form."""
+    from sot_amd import spectra
+    from sot_amd.losses import Wasserstein1D
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    target = spectra.harmonic_batch(3, generator=g, device=dev)
+    estimate = spectra.harmonic_batch(3, generator=g, device=dev)
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+    t1, e1 = target.clone().requires_grad_(True), estimate.clone().requires_grad_(True)
+    spectra.training_step_slice(mod, t1, e1).backward()
+    t2, e2 = target.clone().requires_grad_(True), estimate.clone().requires_grad_(True)
+    pos = spectra.unit_frequencies(2048, 16000.0, dev)
+    mod(spectra.stft_magnitude(t2), spectra.stft_magnitude(e2), x_pos=pos, y_pos=pos.clone()).backward()
+    assert t1.grad is not None and float(t1.grad.abs().max()) > 0
+    torch.testing.assert_close(t1.grad, t2.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(e1.grad, e2.grad, rtol=1e-5, atol=1e-9)
+    # the default (target without gradient) still runs the one-node form and agrees with it on the estimate
+    e3 = estimate.clone().requires_grad_(True)
+    spectra.training_step_slice(mod, target, e3).backward()
+    torch.testing.assert_close(e3.grad, e2.grad, rtol=2e-5, atol=1e-9)
