@@ -78,3 +78,31 @@ def harmonic_audio_pair(nb=2, seed=11, n_samples=4096, sr=16000.0):
         return 0.9 * sig / sig.abs().amax(dim=1, keepdim=True)
 
     return additive(), additive()
+
+
+def exact_harmonic_clips(clips=256, seed=2026, n_samples=4096, sr=16000.0):
+    """Harmonic clips that are BIT-IDENTICAL on every host: the parameter distribution of the reference's
+    SimpleSinusoidDataset (synthetic_data.py:76-118: f0 ~ U[40,1950] Hz, 8 amplitudes ~ U[0.4,1], the partials after
+    max(1, n_active), n_active ~ U{0..7}, muted; items peak-normalised to 0.9, :232-237), drawn from numpy's MT19937 and
+    synthesised with IEEE basic operations only (+, -, *, floor, abs on float64; the sine is the parabola
+    y = 4x(1-|x|), y += 0.225 (y|y| - y) of the phase wrapped to [-1, 1)), so no libm / SIMD variant enters.  Used where a
+    fixture holds reference OUTPUTS for inputs too large to store (tests/golden/config5_256.npz stores their sha256).
+    Returns (target, estimate) float32 [clips, n_samples]."""
+    rs = np.random.RandomState(seed)
+    t = np.arange(n_samples, dtype=np.float64) / sr
+    k = np.arange(1, 9, dtype=np.float64).reshape(1, 8, 1)
+
+    def batch():
+        f0 = 40.0 + (1950.0 - 40.0) * rs.rand(clips, 1, 1)
+        amps = 0.4 + 0.6 * rs.rand(clips, 8, 1)
+        n_active = rs.randint(0, 8, size=(clips, 1, 1))
+        keep = ((k <= np.maximum(n_active, 1)) & (f0 * k < sr / 2)).astype(np.float64)
+        cycles = f0 * k * t.reshape(1, 1, -1)
+        x = 2.0 * (cycles - np.floor(cycles)) - 1.0          # phase in [-1, 1): sin(pi x) ~ parabola below
+        y = 4.0 * x * (1.0 - np.abs(x))
+        y = y + 0.225 * (y * np.abs(y) - y)
+        sig = (amps * keep * y).sum(axis=1)
+        peak = np.abs(sig).max(axis=1, keepdims=True)
+        return torch.from_numpy((0.9 * sig / (peak + 1e-7)).astype(np.float32))
+
+    return batch(), batch()
