@@ -19,6 +19,8 @@ FLAG_DONT_NORMALIZE = 2
 FLAG_LIMIT_Q = 4
 FLAG_REQUIRE_SORT = 8
 FLAG_NO_SPECIALIZE = 32  # diagnostic: generic forward kernel only (include/sot_hip.h)
+FLAG_SAME_GRID = 64      # both measures live on one grid: the p = 1 forward runs the merge-free kernel (include/sot_hip.h)
+FLAG_NO_AREA = 128       # diagnostic: ignore FLAG_SAME_GRID
 
 SOT_OK = 0
 SOT_ERR_INVALID_P = -1
@@ -82,7 +84,8 @@ _lock = threading.Lock()
 
 
 def library_path() -> str:
-    return _build.LIB
+    """The in-tree library, or a diagnostic variant named by SOT_LIB_PATH (tools/: A/B builds; never set in production)."""
+    return os.environ.get("SOT_LIB_PATH") or _build.LIB
 
 
 def load(build_if_missing: bool = True):
@@ -182,7 +185,7 @@ def make_problem(x, y, xpos, ypos, p, flags, plan=None) -> SotProblem:
     pr.B, pr.n, pr.m = B, n, m
     pr.x_row_stride = x.stride(0) if B > 1 else n
     pr.y_row_stride = y.stride(0) if B > 1 else m
-    pr.p, pr.flags = float(p), int(flags)
+    pr.p, pr.flags = float(p), int(flags) | (FLAG_SAME_GRID if (plan is not None and plan.same_grid) else 0)
     if plan is not None:
         pr.xpos, pr.ypos = plan.xpos_sorted.data_ptr(), plan.ypos_sorted.data_ptr()
         pr.xperm, pr.yperm = plan.xperm.data_ptr(), plan.yperm.data_ptr()
@@ -218,6 +221,18 @@ class PositionPlan:
             # the plan is cached and may be consumed from other streams: they wait on this event (see use_plan)
             self.ready = torch.cuda.Event()
             self.ready.record(torch.cuda.current_stream(dev))
+        # Do both measures live on ONE grid (every reference call site: y_pos = x_pos.clone(), the fixed_x buffer)?  Then
+        # the p = 1 forward has a merge-free form (SOT_FLAG_SAME_GRID).  Decided once per plan: trivially for one tensor
+        # passed twice, by a device comparison (one host synchronisation per PLAN, not per call) otherwise -- skipped, i.e.
+        # answered "no", while a stream capture is in progress.
+        if n != m:
+            self.same_grid = False
+        elif xpos.data_ptr() == ypos.data_ptr():
+            self.same_grid = True
+        elif torch.cuda.is_current_stream_capturing():
+            self.same_grid = False
+        else:
+            self.same_grid = bool(torch.equal(self.xpos_sorted, self.ypos_sorted))
 
     def use_on_current_stream(self, device):
         """Order the current stream after the kernel that produced this plan (no-op on the producing stream)."""

@@ -1080,6 +1080,7 @@ hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs
                              hipStream_t s);
 hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
 hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, hipStream_t s);
+hipError_t dispatch_area_full(const FwdArgs& a, hipStream_t s);
 bool forward_full_supports(int n, bool aligned16);
 bool backward_full_supports(int n, bool aligned16);
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
@@ -1111,6 +1112,7 @@ template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, cons
 #if !(SOT_PART & 128)
 hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+hipError_t dispatch_area_full(const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 bool forward_full_supports(int, bool) { return false; }
 bool backward_full_supports(int, bool) { return false; }
 #endif
@@ -1468,7 +1470,10 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;
 #endif
-    const hipError_t e = full       ? dispatch_forward_full(l.cfg, l.pm, l.a, l.lds, l.want, l.block, l.s)
+    // p = 1 on one grid shared by both measures, no cutoff: the merge-free kernel (sot_forward_full.inc: sot_area_full_kernel)
+    const bool area = full && l.pm == 1 && (pr->flags & SOT_FLAG_SAME_GRID) && !(pr->flags & (SOT_FLAG_LIMIT_Q | SOT_FLAG_NO_AREA));
+    const hipError_t e = area       ? dispatch_area_full(l.a, l.s)
+                         : full     ? dispatch_forward_full(l.cfg, l.pm, l.a, l.lds, l.want, l.block, l.s)
                          : l.rowpos ? dispatch_forward<true>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s)
                                     : dispatch_forward<false>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;

@@ -71,7 +71,7 @@ FULL_ROW_GEOMETRY = {512: (64, 4, 0), 1024: (128, 2, 0), 2048: (256, 1, 0), 4096
                      129: (64, 4, 129), 257: (64, 4, 257), 513: (128, 2, 513), 1025: (192, 1, 1025), 2049: (320, 1, 2049)}
 
 
-def forward_kernel_name(n, mode, backward=False):
+def forward_kernel_name(n, mode, backward=False, same_grid=True):
     """Name of the dominant kernel as rocprofv3 lists it (template arguments G, CPT, ROWS, PM, LIM, SQ, NX[, WANT_X])."""
     c = MODES[mode]
     pm, lim, sq = int(c.get("p", 1)), bool(c.get("limit_quantile_range", False)), bool(c.get("square_dist", False))
@@ -80,6 +80,8 @@ def forward_kernel_name(n, mode, backward=False):
     if geo is None or pm not in (1, 2):
         return "sot_backward_kernel (generic)" if backward else "sot_forward_kernel (generic)"
     g, rows, nx = geo
+    if pm == 1 and not lim and not backward and same_grid:   # p = 1 on one grid: the merge-free kernel (sot_area_full_kernel)
+        return f"sot_area_full_kernel<{g}, 8, {rows}, {b(sq)}, {nx}>"
     if backward:
         return f"sot_backward_full_kernel<{g}, 8, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false>"
     return f"sot_forward_full_kernel<{g}, 8, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
@@ -162,8 +164,20 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
                                                        rows * (fb + 4 * nbins), l3_resident=l3)
         return cut
 
-    # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
+    # (0) the headline workload through the general (merge) kernel: p = 1 on one grid normally takes the merge-free kernel
     B, N = sets[0][0].shape
+    p1 = Wasserstein1D(**MODES["p1"]).to(dev)
+    pm = [p1._marshal(x, y, pos_x, pos_y, {}) for x, y in sets]
+
+    def p1_merge(i):
+        x2, y2, xp, yp, flags, plan, _ = pm[i % len(pm)]
+        nat.forward_rows(x2, y2, xp, yp, 1.0, flags | nat.FLAG_NO_AREA, plan)
+
+    with torch.no_grad():
+        out[f"b{B}n{N}_p1_forward_merge_kernel"] = entry(timed(p1_merge, n), forward_kernel_name(N, "p1", same_grid=False), B * (8 * N + 4),
+                                                         l3_resident=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
+
+    # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
     cut = sot_entries(f"b{B}n{N}", B, N, sets, pos_x, pos_y, l3=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
     ys = [s_[1].clone().requires_grad_(True) for s_ in sets[:2]]
 

@@ -52,6 +52,14 @@ typedef enum sot_status {
                                       bit-identical for 512/2048/8192 and agree to the last bits otherwise;
                                       the tests compare the two                                              */
 
+#define SOT_FLAG_SAME_GRID 64u     /* the caller guarantees that xpos and ypos hold the SAME values (n == m, equal element by
+                                      element after sorting; shared positions only): what every reference call site passes
+                                      (y_pos = x_pos.clone(), trainer.py:191; the fixed_x buffer).  For p == 1 without
+                                      SOT_FLAG_LIMIT_Q the forward then evaluates the area between the two CDFs on that grid,
+                                      sum_i |U_i - V_i| (pos_{i+1} - pos_i) -- the same W_1, no merge (<= 3e-7 from the merge
+                                      kernel's value).  A wrong guarantee gives wrong results                                */
+#define SOT_FLAG_NO_AREA 128u      /* diagnostic: ignore SOT_FLAG_SAME_GRID (always the merge kernel)                         */
+
 /* One batch of spectrum pairs.  Mirrors the arguments of Wasserstein1D.forward
  * (losses.py:129) after its [batch,time,N] -> [B,N] reshape (losses.py:157-170). */
 typedef struct sot_problem {

@@ -700,7 +700,10 @@ def test_loss_and_grad_in_one_pass_matches_forward_plus_backward(N, B, flags, p)
     pos2 = pos.clone()
     plan = nat.PositionPlan(pos, pos2)
     mean, rows, gy = nat.loss_and_grad(x, y, pos, pos2, p, flags, plan)
-    mean2, rows2, _ = nat.loss_fused(x, y, pos, pos2, p, flags, plan)
+    # (p = 1 on one grid: the forward alone would take the merge-free kernel, whose rows agree to 2e-6, not bit for bit)
+    mean2, rows2, _ = nat.loss_fused(x, y, pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)
+    rows3 = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
+    torch.testing.assert_close(rows3, rows, rtol=2e-6, atol=1e-12)
     one = torch.ones((), device=device())
     _, gy2 = nat.backward_rows(x, y, pos, pos2, p, flags, one, need_gx=False, plan=plan, grad_scale=1.0 / B)
     assert torch.equal(rows, rows2), float((rows - rows2).abs().max())
@@ -770,7 +773,7 @@ def test_in_kernel_batch_mean_is_bit_identical_to_the_mean_kernel(B, N):
         assert torch.equal(nat.loss_fused(x, y, pos, pos2, p, flags, plan, hinge=h, fused_mean=True)[0], want_h)
         m1, r1, g1 = nat.loss_and_grad(x, y, pos, pos2, p, flags, plan, fused_mean=True)
         m2, r2, g2 = nat.loss_and_grad(x, y, pos, pos2, p, flags, plan, fused_mean=False)
-        assert torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(g1, g2) and torch.equal(m1, want_mean)
+        assert torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(g1, g2) and torch.equal(m1, nat.reduce_mean(r1))
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         outs = []
         for s in (s1, s2, s1, s2, s1, s2):
@@ -937,3 +940,74 @@ def test_config5_full_size_training_step_matches_reference():
     # tie between two levels may route a run's gradient to another member, a different valid subgradient)
     assert np.median(err[clean]) <= 5e-6 and np.percentile(err[clean], 99) <= 1e-4 and err[clean].max() <= 1e-3
     assert cos >= 0.99                                        # all clips: flipped rows move single clips, not the batch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B", [(129, 700), (257, 530), (512, 1030), (513, 300), (1024, 333), (1025, 261), (2048, 520), (2049, 77), (4096, 70),
+                                 (8192, 35)])
+@pytest.mark.parametrize("flags", [0, 1, 2, 1 | 2])
+def test_p1_same_grid_merge_free_kernel(N, B, flags):
+    """p = 1 with both measures on one grid (SOT_FLAG_SAME_GRID, set by the binding from the position plan): the forward
+    evaluates sum_i |U_i - V_i| (pos_{i+1} - pos_i) instead of merging the CDFs (losses.py:295-313).  Same value: against the
+    merge kernel (SOT_FLAG_NO_AREA) to 2e-6 per row, against the C oracle to 1e-5, peaky and uniform rows, square_dist and
+    dont_normalize (total masses differ: the clamp of losses.py:220 matters), odd row lengths, a non-uniform grid."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import gen_inputs
+    nat = native()
+    dev = device()
+    for kind in ("peaky", "uniform"):
+        x, y = gen_inputs(kind, B, N, N, N + B)
+        x[0] = 0.0                                   # zero row (mass guard)
+        y[1] = x[1]                                  # identical distributions -> 0
+        pos = torch.sort(torch.rand(N, generator=torch.Generator().manual_seed(N)) ** 2).values   # non-uniform grid
+        xd, yd, pd = x.to(dev), y.to(dev), pos.to(dev)
+        pd2 = pd.clone()
+        plan = nat.PositionPlan(pd, pd2)
+        assert plan.same_grid
+        f = flags | nat.FLAG_REQUIRE_SORT
+        area = nat.forward_rows(xd, yd, pd, pd2, 1.0, f, plan).cpu().numpy().astype(np.float64)
+        merge = nat.forward_rows(xd, yd, pd, pd2, 1.0, f | nat.FLAG_NO_AREA, plan).cpu().numpy().astype(np.float64)
+        want = so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=1.0, flags=f).astype(np.float64)
+        scale = np.maximum(np.abs(want), 1e-12)
+        assert np.all(np.abs(area - merge) <= 2e-6 * np.maximum(np.abs(merge), 1e-12) + 1e-12), float(np.max(np.abs(area - merge) / scale))
+        assert np.all(np.abs(area - want) <= 1e-5 * scale + 1e-12), float(np.max(np.abs(area - want) / scale))
+        assert area[1] == 0.0
+
+
+@pytest.mark.gpu
+def test_p1_same_grid_dispatch_conditions():
+    """The merge-free kernel is only taken when it applies: p == 1, no quantile cutoff, one grid for both measures.  Unsorted
+    shared positions (same values both sides) still qualify after the plan's sort; different grids, p = 2 and the cutoff
+    keep the merge kernel (results then equal the NO_AREA ones bit for bit)."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import gen_inputs
+    from sot_amd.losses import Wasserstein1D
+    nat = native()
+    dev = device()
+    B, N = 64, 2048
+    x, y = gen_inputs("peaky", B, N, N, 77)
+    xd, yd = x.to(dev), y.to(dev)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+    pos = torch.linspace(0, 1, N)[perm]                      # unsorted, same on both sides
+    pd, pd2 = pos.to(dev), pos.to(dev).clone()
+    plan = nat.PositionPlan(pd, pd2)
+    assert plan.same_grid
+    got = nat.forward_rows(xd, yd, pd, pd2, 1.0, 8, plan).cpu().numpy()
+    want = so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=1.0, flags=8)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-12)
+    other = torch.sort(torch.rand(N, generator=torch.Generator().manual_seed(2))).values.to(dev)
+    plan2 = nat.PositionPlan(torch.linspace(0, 1, N, device=dev), other)
+    assert not plan2.same_grid
+    lin = torch.linspace(0, 1, N, device=dev)
+    plan3 = nat.PositionPlan(lin, lin.clone())
+    for p, f in ((2.0, 8), (1.0, 8 | 4), (2.0, 15)):         # p = 2 / cutoff: the flag changes nothing
+        a = nat.forward_rows(xd, yd, lin, lin, p, f, plan3)
+        b = nat.forward_rows(xd, yd, lin, lin, p, f | nat.FLAG_NO_AREA, plan3)
+        assert torch.equal(a, b)
+    # the module (metrics.py:148 form: fixed_x grid, p = 1) goes through the plan and therefore through the merge-free kernel
+    mod = Wasserstein1D(p=1, fixed_x=N).to(dev)
+    with torch.no_grad():
+        m = float(mod(xd, yd))
+    w = float(np.mean(so.forward(x.numpy(), y.numpy(), np.linspace(0, 1, N, dtype=np.float32), np.linspace(0, 1, N, dtype=np.float32), p=1.0,
+                                 flags=8).astype(np.float64)))
+    assert abs(m - w) <= 1e-5 * abs(w)

@@ -8,22 +8,23 @@ for rnd in range(3):
     for name in names:
         code = f"""
 import sys; sys.path.insert(0, {ROOT!r})
+import os
+os.environ['SOT_LIB_PATH'] = {ROOT!r} + '/tools/ablate_libs/' + {name!r} + '.so'
 import sot_amd, torch
-sot_amd.build.LIB = {ROOT!r} + '/tools/ablate_libs/' + {name!r} + '.so'
 from sot_amd import _native as nat
 nat.load(build_if_missing=False)
 dev = torch.device('cuda:0'); B, N = {int(os.environ.get('AB_B', '8192'))}, {int(os.environ.get('AB_N', '2048'))}
 g = torch.Generator(device=dev).manual_seed(0)
-sets = [(torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)) for _ in range(6)]
+sets = [(torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)) for _ in range({int(os.environ.get('AB_SETS', '6'))})]
 pos = torch.linspace(0, 1, N, device=dev); pos2 = pos.clone()
 plan = nat.PositionPlan(pos, pos2)
-for i in range(500): nat.forward_rows(*sets[i % 6], pos, pos2, {pval}, {mode_flags}, plan)
+for i in range(500): nat.forward_rows(*sets[i % len(sets)], pos, pos2, {pval}, {mode_flags}, plan)
 res = []
 for rep in range(3):
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for i in range(200): nat.forward_rows(*sets[i % 6], pos, pos2, {pval}, {mode_flags}, plan)
+    for i in range(200): nat.forward_rows(*sets[i % len(sets)], pos, pos2, {pval}, {mode_flags}, plan)
     b.record(); torch.cuda.synchronize()
     res.append(round(a.elapsed_time(b) * 5, 1))
 print(res)
