@@ -12,6 +12,8 @@ include/sot_hip.h); this file only reshapes, marshals pointers and wires autogra
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 
 from . import _native as nat
@@ -27,6 +29,27 @@ def safe_divide(numerator, denominator, eps=1e-7):
     safe_denominator = torch.where(denominator <= eps,
                                    torch.tensor(eps, dtype=torch.float32, device=denominator.device), denominator)
     return numerator / safe_denominator
+
+
+_warned = set()
+
+
+def warn_once(key, message):
+    """One warning per distinct situation (e.g. per unsupported transform size), not one per call."""
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(message, stacklevel=3)
+
+
+def _as_float32(*tensors):
+    """The kernels compute in float32 (include/sot_hip.h).  float64 inputs -- which the reference tolerates (SURVEY 8b;
+    utils.py:135-142 promotes) -- are converted on the way in, and the caller converts the result back to float64: same
+    interface, float32 arithmetic (said once, in a warning)."""
+    if not any(t is not None and t.dtype == torch.float64 for t in tensors):
+        return tensors, None   # float32 passes through; half / bfloat16 are refused by the binding (TypeError), not upcast
+    warn_once("float64", "sot_amd computes in float32: float64 inputs are converted to float32 and the result back to float64 "
+                         "(the reference would have computed in float64)")
+    return tuple(t.float() if (t is not None and t.dtype == torch.float64) else t for t in tensors), torch.float64
 
 
 def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized=False):
@@ -180,12 +203,15 @@ def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, requ
     def shared_row(t):
         return t[0] if (t.ndim == 2 and t.shape[0] > 1 and t.stride(0) == 0) else t
     upos, vpos = shared_row(u_values), shared_row(v_values)
+    (u_weights, v_weights, upos, vpos), out_dtype = _as_float32(u_weights, v_weights, upos, vpos)
     x, y, upos, vpos = _prepare(u_weights, v_weights, upos, vpos)
     flags = _flags(False, False, limit_quantile_range, require_sort, prenormalized=True)
     plan = _functional_plans.get(upos, vpos) if (require_sort and upos.ndim == 1) else None
     if return_quantiles:
-        return nat.quantiles(x, y, upos, vpos, p, flags, plan)
-    return _RowLoss.apply(x, y, upos, vpos, float(p), flags, plan)
+        out = nat.quantiles(x, y, upos, vpos, p, flags, plan)
+        return out if out_dtype is None else tuple(t.to(out_dtype) for t in out)
+    rows = _RowLoss.apply(x, y, upos, vpos, float(p), flags, plan)
+    return rows if out_dtype is None else rows.to(out_dtype)
 
 
 def wasserstein_1d_csr(x_weights, x_positions, x_offsets, y_weights, y_positions, y_offsets, max_n, max_m, p=1,
@@ -219,6 +245,7 @@ class Wasserstein1D(torch.nn.Module):
         else:
             self.register_buffer("fixed_x", None)
         self._plans = _PlanCache()
+        self._out_dtype = None
 
     def _marshal(self, x, y, x_pos, y_pos, kwargs):
         if (x_pos is None or y_pos is None) and self.fixed_x is None:
@@ -227,6 +254,7 @@ class Wasserstein1D(torch.nn.Module):
 
         x_pos_ = self.fixed_x if x_pos is None else x_pos
         y_pos_ = self.fixed_x if y_pos is None else y_pos
+        (x, y, x_pos_, y_pos_), self._out_dtype = _as_float32(x, y, x_pos_, y_pos_)
 
         original_shape = x.shape[:-1]
         if x.ndim == 3:
@@ -259,6 +287,13 @@ class Wasserstein1D(torch.nn.Module):
         return loss
 
     def forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
+        out = self._forward(x, y, x_pos, y_pos, **kwargs)
+        dt = self._out_dtype   # set by _marshal: the promoted input dtype when it is not float32
+        if dt is None:
+            return out
+        return [t.to(dt) for t in out] if isinstance(out, list) else out.to(dt)
+
+    def _forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
         if kwargs.get("return_quantiles", False):
             x2, y2, x_pos_, y_pos_, flags, plan, original_shape = self._marshal(x, y, x_pos, y_pos, kwargs)
             out = nat.quantiles(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
@@ -346,6 +381,10 @@ class MSSLoss(torch.nn.Module):
         native_ok = (audio.is_cuda and target_audio.is_cuda and dims is None and audio.ndim == 2 and audio.shape == target_audio.shape and
                      (self.mag_weight > 0 or self.logmag_weight > 0) and
                      all(spectra.hip_stft_supported(s, int(s * 0.25), audio.shape[1]) for s in self.fft_sizes))
+        if audio.is_cuda and not native_ok:
+            warn_once(("mss", dims is not None, self.fft_sizes),
+                      "MSSLoss: this call runs the torch composition instead of the HIP kernels (`dims` given, FFT sizes outside "
+                      "64..2048, shapes that differ, or both weights zero)")
         if native_ok:
             return _MultiScaleSpectral.apply(target_audio.float(), audio.float(), self.fft_sizes, float(self.mag_weight),
                                              float(self.logmag_weight), kind == "L2")

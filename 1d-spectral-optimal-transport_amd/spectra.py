@@ -73,6 +73,10 @@ def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, windo
     outside hip_stft_supported() run torch.stft."""
     if audio.is_cuda and audio.ndim == 2 and hip_stft_supported(n_fft, hop, audio.shape[1]):
         return _StftMagnitude.apply(audio.float(), _cached_window(window, n_fft, audio.device), int(n_fft), int(hop))
+    if audio.is_cuda:   # not silent: a GPU tensor that leaves the HIP path says so, once per size
+        from .losses import warn_once
+        warn_once(("stft", int(n_fft), int(hop), audio.ndim), f"stft_magnitude: n_fft={n_fft}, hop={hop}, audio.ndim={audio.ndim} is outside what "
+                  "the HIP STFT kernels take (2-D audio, n_fft a power of two in [64, 2048]); running torch.stft (rocFFT) instead")
     return stft_magnitude_torch(audio, n_fft, hop, window)
 
 

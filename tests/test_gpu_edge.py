@@ -98,3 +98,30 @@ def test_gradients_only_where_requested():
     y.grad = None
     mod(x, y, x_pos=pos, y_pos=pos).backward()
     torch.testing.assert_close(g3, 3.0 * y.grad, rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_float64_inputs_are_accepted_like_the_reference():
+    """inputs may be float64 (the reference promotes, utils.py:135-142).  Here they are computed in float32 and the
+    result -- value and gradient -- comes back in float64, with one warning."""
+    import warnings
+    from sot_amd.losses import Wasserstein1D, wasserstein_1d
+    native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(9, 300, device=dev, generator=g, dtype=torch.float64)
+    y = torch.rand(9, 300, device=dev, generator=g, dtype=torch.float64).requires_grad_(True)
+    pos = torch.linspace(0, 1, 300, device=dev, dtype=torch.float64)
+    mod = Wasserstein1D(p=2, square_dist=True).to(dev)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = mod(x, y, x_pos=pos, y_pos=pos.clone())
+    assert out.dtype == torch.float64
+    out.backward()
+    assert y.grad is not None and y.grad.dtype == torch.float64 and torch.isfinite(y.grad).all()
+    y32 = y.detach().float().requires_grad_(True)
+    ref = mod(x.float(), y32, x_pos=pos.float(), y_pos=pos.float().clone())
+    ref.backward()
+    assert float(out) == float(ref) and torch.equal(y.grad.float(), y32.grad)
+    rows = wasserstein_1d(pos.expand(9, 300), pos.expand(9, 300), x / x.sum(1, keepdim=True), y.detach() / y.detach().sum(1, keepdim=True))
+    assert rows.dtype == torch.float64 and rows.shape == (9,)
