@@ -9,8 +9,10 @@ torch plumbing.  Mirrors, without copying, the behaviour of
   * features.TorchSTFT / compute_mag / stft (features.py:85-113, 191-237): window from scipy.signal.get_window,
     `normalized=True`, `center=False`, end-padding so that every sample is covered (utils.pad_for_stft,
     utils.py:252-275), magnitude, output [batch, frames, bins];
-  * synthetic_data.SimpleSinusoidDataset's signal distribution (synthetic_data.py:331-345): f0 ~ U[40,1950] Hz,
-    up to 8 harmonic partials with amplitudes ~ U[0.4,1], 4096 samples @ 16 kHz, peak-normalised to 0.9.
+  * synthetic_data.SimpleSinusoidDataset (synthetic_data.py:76-118, 174-201, 232-237; settings :331-345): f0 ~ U[40,1950] Hz,
+    8 harmonic partials with amplitudes ~ U[0.4,1] of which the first max(1, n_active) sound, the frame-rate controls go
+    through synths.Sinusoidal (synths.py:43-128: Hann-window / linear upsampling, oscillator bank), 4096 samples @ 16 kHz,
+    every item divided by its peak + 1e-7 and scaled to 0.9 -- pinned by tests/golden/synth_generator.npz.
 """
 from __future__ import annotations
 
@@ -127,17 +129,86 @@ def oscillator_bank(frequency_envelopes: torch.Tensor, amplitude_envelopes: torc
     return torch.sum(a * torch.sin(phases), dim=-1)
 
 
-def harmonic_batch(batch: int, n_samples: int = 4096, sample_rate: float = 16000.0, generator=None, device="cuda"):
-    """Random harmonic clips on `device`: f0 ~ U[40,1950] Hz, n_active ~ U{1..8} partials, amplitudes ~ U[0.4,1]."""
+def upsample_window(frames: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """[batch, n_frames, channels] -> [batch, n_samples, channels] with half-overlapping Hann windows: the reference's
+    amplitude upsampler (`ddsp.resample(method="window", add_endpoint=True)` -> `upsample_with_windows`, ddsp.py:121-205, used
+    by synths.py:95-102).  The last frame is held for one more step, n_samples must be a multiple of n_frames; with
+    hop = n_samples / n_frames and w = hann(2 hop), sample t = a hop + u receives frames[a] w[u + hop] + frames[a + 1] w[u]
+    (two products, one sum -- what the reference's fold() adds up; bit-identical on the same device type)."""
+    frames = frames.float()
+    batch, n_frames, channels = frames.shape
+    if n_frames >= n_samples:
+        raise ValueError(f"Upsample with windows cannot be used for downsampling: {n_frames} frames, {n_samples} timesteps")
+    if n_samples % n_frames != 0:
+        raise ValueError(f"the target number of timesteps ({n_samples}) must be divisible by the number of frames ({n_frames})")
+    hop = n_samples // n_frames
+    held = torch.cat([frames, frames[:, -1:, :]], dim=1)                       # add_endpoint
+    w = torch.hann_window(2 * hop, device=frames.device)
+    lead = (held[:, :-1, None, :] * w[None, None, hop:, None])                 # frames[a]     * w[u + hop]
+    follow = (held[:, 1:, None, :] * w[None, None, :hop, None])                # frames[a + 1] * w[u]
+    return (lead + follow).reshape(batch, n_samples, channels)
+
+
+def upsample_linear(frames: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """[batch, n_frames, channels] -> [batch, n_samples, channels]: the reference's frequency upsampler
+    (`ddsp.resample(method="bilinear", add_endpoint=True)`, ddsp.py:53-118 -> F.interpolate(align_corners=False))."""
+    x = frames.float().permute(0, 2, 1)[:, :, :, None]
+    y = torch.nn.functional.interpolate(x, size=[n_samples, 1], mode="bilinear", align_corners=False)
+    return y[:, :, :, 0].permute(0, 2, 1).contiguous()
+
+
+def sinusoidal_synth(amplitudes: torch.Tensor, frequencies: torch.Tensor, n_samples: int, sample_rate: int = 16000,
+                     harmonic: bool = True) -> torch.Tensor:
+    """The reference's `synths.Sinusoidal(amp_scale_fn=None, freq_scale_fn=None)` (synths.py:43-128): frame-rate controls
+    [batch, frames, sinusoids] (frequencies [batch, frames, 1] when `harmonic`: integer multiples of f0, ddsp.py:6-22) ->
+    partials at or above Nyquist muted (ddsp.py:25-49) -> amplitudes upsampled with overlapping Hann windows, frequencies
+    linearly -> oscillator bank (the HIP kernels behind `oscillator_bank`; differentiable w.r.t. both controls)."""
+    amplitudes, frequencies = amplitudes.float(), frequencies.float()
+    if harmonic:
+        k = amplitudes.shape[-1]
+        frequencies = frequencies * torch.linspace(1.0, float(k), k, device=frequencies.device)
+    amplitudes = torch.where(frequencies >= sample_rate / 2.0, torch.zeros_like(amplitudes), amplitudes)
+    return oscillator_bank(upsample_linear(frequencies, n_samples), upsample_window(amplitudes, n_samples), sample_rate)
+
+
+def harmonic_parameters(size: int, seed: int, n_sinusoids: int = 8, freq_min: float = 40.0, freq_max: float = 1950.0,
+                        amp_min: float = 0.4, amp_max: float = 1.0, n_sinusoids_min: int = 1):
+    """The parameter draws of the reference's `SimpleSinusoidDataset.setup()` (synthetic_data.py:76-118) after
+    `torch.manual_seed(seed)`, harmonic case: frequency [size, 1] ~ U[freq_min, freq_max), weights [size, n] ~ U[amp_min,
+    amp_max) with the partials after the first max(1, n_active) muted, n_active ~ U{n_min - 1 .. n - 1} (sequential mask).
+    CPU generator, same call order as the reference: identical values for the same seed."""
+    g = torch.Generator().manual_seed(seed)
+    freqs = torch.rand(size, 1, generator=g) * (freq_max - freq_min) + freq_min
+    weights = torch.rand(size, n_sinusoids, generator=g) * (amp_max - amp_min) + amp_min
+    n_active = torch.randint(low=n_sinusoids_min - 1, high=n_sinusoids, size=(size,), generator=g)
+    mask = torch.arange(1, n_sinusoids).expand(size, n_sinusoids - 1) < n_active.unsqueeze(1)
+    mask = torch.cat((torch.ones(size, 1, dtype=torch.bool), mask), dim=1)
+    return freqs, weights * mask.float()
+
+
+def harmonic_items(frequency: torch.Tensor, weights: torch.Tensor, n_samples: int = 4096, sample_rate: int = 16000,
+                   n_frames: int = 16) -> torch.Tensor:
+    """The audio `x` of the reference's dataset items (synthetic_data.py:174-201 generate_sinusoids + :232-237): the controls
+    held constant over `n_frames` frames -> `sinusoidal_synth` -> every clip divided by (its peak + 1e-7) and scaled to 0.9."""
+    amps = weights.float().unsqueeze(1).repeat(1, n_frames, 1)
+    f0 = frequency.float().reshape(-1, 1, 1).repeat(1, n_frames, 1)
+    signal = sinusoidal_synth(amps, f0, n_samples, sample_rate, harmonic=True)
+    return signal / (signal.abs().amax(dim=1, keepdim=True) + 1e-7) * 0.9
+
+
+def harmonic_batch(batch: int, n_samples: int = 4096, sample_rate: float = 16000.0, generator=None, device="cuda", seed=None):
+    """`batch` harmonic clips with the reference dataset's distribution and synthesis (harmonic_parameters + harmonic_items)
+    on `device`.  seed: the torch.manual_seed the reference would have been given; otherwise the draws come from `generator`
+    (a device generator) with the same distribution."""
     dev = torch.device(device)
-    f0 = 40 + (1950 - 40) * torch.rand(batch, 1, 1, generator=generator, device=dev)
-    amps = 0.4 + 0.6 * torch.rand(batch, 8, 1, generator=generator, device=dev)
-    n_active = torch.randint(1, 9, (batch, 1, 1), generator=generator, device=dev)
-    k = torch.arange(1, 9, device=dev).view(1, 8, 1)
-    t = torch.arange(n_samples, device=dev).view(1, 1, -1) / sample_rate
-    keep = ((k <= n_active) & (f0 * k < sample_rate / 2)).float()
-    sig = (amps * keep * torch.sin(2 * torch.pi * f0 * k * t)).sum(1)
-    return 0.9 * sig / sig.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
+    if seed is not None:
+        freqs, weights = harmonic_parameters(batch, seed)
+        return harmonic_items(freqs.to(dev), weights.to(dev), n_samples, int(sample_rate))
+    freqs = 40 + (1950 - 40) * torch.rand(batch, 1, generator=generator, device=dev)
+    amps = 0.4 + 0.6 * torch.rand(batch, 8, generator=generator, device=dev)
+    n_active = torch.randint(0, 8, (batch, 1), generator=generator, device=dev)
+    keep = torch.arange(8, device=dev).view(1, 8) < n_active.clamp_min(1)
+    return harmonic_items(freqs, amps * keep.float(), n_samples, int(sample_rate))
 
 
 class _AudioToLoss(torch.autograd.Function):

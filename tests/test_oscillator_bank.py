@@ -90,3 +90,55 @@ def test_hip_oscillator_bank_only_amplitude_gradient_and_errors():
         nat.oscillator_bank_forward(f, a.detach()[:, :, :2], 16000.0)
     with pytest.raises(RuntimeError):
         nat.oscillator_bank_forward(f.cpu(), a.detach().cpu(), 16000.0)
+
+
+def _synth_fixture():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "synth_generator.npz"))
+
+
+def test_generator_parameters_and_upsamplers_match_reference_on_cpu():
+    """SURVEY 8f row 2, generator half, on the CPU (torch ops; the same functions run on the GPU): the parameter draws of
+    SimpleSinusoidDataset.setup() (synthetic_data.py:76-118), the two envelope upsamplers of synths.py:95-113 and the
+    whole item pipeline (generate_sinusoids :174-201 + item normalisation :232-237) against what the reference itself
+    produced (oracle/make_golden_synth.py).  Bit for bit: same ATen kernels, same operation order."""
+    from sot_amd import spectra
+    fx = _synth_fixture()
+    f, w = spectra.harmonic_parameters(520, int(fx["seed"]))
+    assert np.array_equal(f[:256].numpy(), fx["frequency"]) and np.array_equal(w[:256].numpy(), fx["weights"])
+    assert set((fx["weights"] > 0).sum(1).tolist()) <= set(range(1, 8))      # 1..7 sounding partials, never the 8th
+    assert np.array_equal(spectra.upsample_window(torch.tensor(fx["amp_frames"]), 4096).numpy(), fx["amp_window_4096"])
+    assert np.array_equal(spectra.upsample_linear(torch.tensor(fx["freq_frames"]), 4096).numpy(), fx["freq_bilinear_4096"])
+    x = spectra.harmonic_items(torch.tensor(fx["frequency"][:12]), torch.tensor(fx["weights"][:12])).numpy()
+    assert np.array_equal(x, fx["x"]) and abs(np.abs(x).max() - 0.9) < 1e-6
+    audio = spectra.sinusoidal_synth(torch.tensor(fx["amp_frames"]), torch.tensor(fx["f0_frames"]), 4096).numpy()
+    assert np.array_equal(audio, fx["synth_audio"])
+    with pytest.raises(ValueError):
+        spectra.upsample_window(torch.zeros(1, 16, 2), 4100)              # not a multiple of the frame count (ddsp.py:163-170)
+
+
+@pytest.mark.gpu
+def test_generator_on_the_gpu_matches_reference_items():
+    """The same pipeline on the GPU: upsamplers on torch's device ops, oscillator bank on the HIP kernels.  Items and the
+    time-varying synthesiser output against the reference's audio: <= 2e-5 of the peak (the phase of a 4096-sample clip reaches
+    ~5e3 rad, so one ulp of a frequency envelope is worth ~3e-4 rad at its end)."""
+    from sot_amd import spectra
+    fx = _synth_fixture()
+    dev = torch.device("cuda:0")
+    a = spectra.upsample_window(torch.tensor(fx["amp_frames"]).to(dev), 4096).cpu().numpy()
+    np.testing.assert_allclose(a, fx["amp_window_4096"], rtol=0, atol=3e-7)     # the device's hann window differs from the CPU's by an ulp
+    b = spectra.upsample_linear(torch.tensor(fx["freq_frames"]).to(dev), 4096).cpu().numpy()
+    np.testing.assert_allclose(b, fx["freq_bilinear_4096"], rtol=3e-7, atol=0)
+    x = spectra.harmonic_items(torch.tensor(fx["frequency"][:12]).to(dev), torch.tensor(fx["weights"][:12]).to(dev)).cpu().numpy()
+    assert np.abs(x - fx["x"]).max() <= 2e-5 * 0.9, float(np.abs(x - fx["x"]).max())
+    audio = spectra.sinusoidal_synth(torch.tensor(fx["amp_frames"]).to(dev), torch.tensor(fx["f0_frames"]).to(dev), 4096).cpu().numpy()
+    assert np.abs(audio - fx["synth_audio"]).max() <= 2e-5 * np.abs(fx["synth_audio"]).max()
+    # the seeded batch generator = these parameters through that pipeline; gradients flow to the frame-rate controls
+    clips = spectra.harmonic_batch(12, device=dev, seed=int(fx["seed"]))
+    # (harmonic_parameters(12, seed) draws differ from the first 12 of a 520-item draw: only shapes / peak are checked here)
+    assert clips.shape == (12, 4096) and abs(float(clips.abs().max()) - 0.9) < 1e-5
+    amp = torch.tensor(fx["amp_frames"]).to(dev).requires_grad_(True)
+    f0 = torch.tensor(fx["f0_frames"]).to(dev).requires_grad_(True)
+    spectra.sinusoidal_synth(amp, f0, 4096).square().mean().backward()
+    assert torch.isfinite(amp.grad).all() and torch.isfinite(f0.grad).all() and float(amp.grad.abs().max()) > 0
