@@ -233,6 +233,27 @@ __device__ __forceinline__ double wave_suffix_incl_scan(double v)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Synchronisation of ONE row group.  A row that is owned by a single wavefront (64 threads: 129 / 257 / 512-bin rows) never
+// exchanges data with the other rows of its workgroup, and the LDS executes one wave's instructions in issue order: a
+// compiler-level ordering point is all it needs.  Rows of several wavefronts use the workgroup barrier (all row groups of a
+// workgroup execute the same number of them).  SOT_WAVE_ROWS=0 restores workgroup barriers everywhere (A/B switch).
+// ---------------------------------------------------------------------------------------------
+#ifndef SOT_WAVE_ROWS
+#define SOT_WAVE_ROWS 1
+#endif
+template <int NW>
+__device__ __forceinline__ void row_sync()
+{
+    if constexpr (NW == 1 && SOT_WAVE_ROWS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Batch mean inside the kernel that produces the row losses (losses.py:203-211): the workgroup that finishes LAST reduces
 // row_loss[0, B) with the arithmetic of sot_reduce_mean_kernel, operation for operation (1024 "virtual threads" of 8
 // consecutive rows each, DPP wave sums, 16 wave totals added in order), so the result is bit-identical to the separate

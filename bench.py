@@ -66,9 +66,9 @@ def parse():
 
 
 # kernel the shared-position forward dispatches for a row length (csrc/sot_forward_full.inc: dispatch_forward_full):
-# threads per row, rows per workgroup, compile-time row length (0: the row fills its geometry)
-FULL_ROW_GEOMETRY = {512: (64, 4, 0), 1024: (128, 2, 0), 2048: (256, 1, 0), 4096: (512, 1, 0), 8192: (1024, 1, 0),
-                     129: (64, 4, 129), 257: (64, 4, 257), 513: (128, 2, 513), 1025: (192, 1, 1025), 2049: (320, 1, 2049)}
+# threads per row, contiguous elements per thread, rows per workgroup, compile-time row length (0: the row fills its geometry)
+FULL_ROW_GEOMETRY = {512: (64, 8, 4, 0), 1024: (128, 8, 2, 0), 2048: (256, 8, 1, 0), 4096: (512, 8, 1, 0), 8192: (1024, 8, 1, 0),
+                     129: (64, 3, 4, 129), 257: (64, 5, 4, 257), 513: (64, 9, 4, 513), 1025: (128, 9, 2, 1025), 2049: (256, 9, 1, 2049)}
 
 
 def forward_kernel_name(n, mode, backward=False, same_grid=True):
@@ -79,12 +79,12 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True):
     b = lambda v: "true" if v else "false"  # noqa: E731
     if geo is None or pm not in (1, 2):
         return "sot_backward_kernel (generic)" if backward else "sot_forward_kernel (generic)"
-    g, rows, nx = geo
+    g, cpt, rows, nx = geo
     if pm == 1 and not lim and not backward and same_grid:   # p = 1 on one grid: the merge-free kernel (sot_area_full_kernel)
-        return f"sot_area_full_kernel<{g}, 8, {rows}, {b(sq)}, {nx}>"
+        return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, {nx}>"
     if backward:
-        return f"sot_backward_full_kernel<{g}, 8, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false>"
-    return f"sot_forward_full_kernel<{g}, 8, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
+        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false>"
+    return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
 
 
 def launcher_command(gpus, argv, port, python=None):
@@ -230,7 +230,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
 
     ms5 = timed(train_step, n)
     # bytes the slice must move: both clips' audio in, the estimate's audio gradient out (spectra stay on chip in the ideal)
-    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<192,...,1025,false> + stft backward",
+    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<128, 9, 2, ..., 1025, false> + stft backward",
                                                3 * 256 * 4096 * 4, steps_per_s=1e3 / ms5, rows=4096, bins=1025)
     return out
 
@@ -470,10 +470,13 @@ def main():
         except Exception:
             parity = None
         traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")))
-            if pj.get("workload") == f"B={B},N={N},{args.mode}":
-                traffic = pj["hbm_bytes_per_launch"]
+        try:  # HBM bytes per launch of THIS kernel on THIS workload from the committed rocprofv3 PMC passes (profiles/), if present
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+                pj = json.load(open(path))
+                if pj.get("workload") == f"B={B},N={N},{args.mode}" and pj.get("kernel") == forward_kernel_name(N, args.mode):
+                    traffic = pj["hbm_bytes_per_launch"]
+                    break
         except Exception:
             traffic = None
         rec = {

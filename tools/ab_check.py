@@ -4,8 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for name in sys.argv[1:]:
     code = f"""
 import sys; sys.path.insert(0, {ROOT!r})
+import os
+os.environ['SOT_LIB_PATH'] = {ROOT!r} + '/tools/ablate_libs/' + {name!r} + '.so'
 import numpy as np, torch, sot_amd
-sot_amd.build.LIB = {ROOT!r} + '/tools/ablate_libs/' + {name!r} + '.so'
 from sot_amd import _native as nat
 nat.load(build_if_missing=False)
 from oracle.inputs import gen_inputs

@@ -18,13 +18,20 @@ g = torch.Generator(device=dev).manual_seed(0)
 sets = [(torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)) for _ in range({int(os.environ.get('AB_SETS', '6'))})]
 pos = torch.linspace(0, 1, N, device=dev); pos2 = pos.clone()
 plan = nat.PositionPlan(pos, pos2)
-for i in range(500): nat.forward_rows(*sets[i % len(sets)], pos, pos2, {pval}, {mode_flags}, plan)
+call = {os.environ.get('AB_CALL', 'fwd')!r}
+one = torch.ones(1, device=dev)
+def run(i):
+    x, y = sets[i % len(sets)]
+    if call == 'fwd': nat.forward_rows(x, y, pos, pos2, {pval}, {mode_flags}, plan)
+    elif call == 'lg': nat.loss_and_grad(x, y, pos, pos2, {pval}, {mode_flags}, plan)
+    else: nat.backward_rows(x, y, pos, pos2, {pval}, {mode_flags}, one, need_gx=(call == 'bwdxy'), plan=plan, grad_scale=1.0 / B)
+for i in range(500): run(i)
 res = []
 for rep in range(3):
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for i in range(200): nat.forward_rows(*sets[i % len(sets)], pos, pos2, {pval}, {mode_flags}, plan)
+    for i in range(200): run(i)
     b.record(); torch.cuda.synchronize()
     res.append(round(a.elapsed_time(b) * 5, 1))
 print(res)

@@ -6,7 +6,7 @@ TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 30 --warmup 5 --no-cpu-baseline $*"
+ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
 pass() { # name, counters...
   local name=$1; shift
