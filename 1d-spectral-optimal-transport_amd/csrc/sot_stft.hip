@@ -32,6 +32,23 @@ constexpr int kMaxFft = 2048;
 
 #include "sot_stft_tables.inc"      // kPassTw, kWn (csrc/gen/make_stft_tables.py)
 
+#ifndef SOT_STFT_WAVE_FRAMES
+#define SOT_STFT_WAVE_FRAMES 1
+#endif
+
+// synchronisation of one frame slot (see Geo::wave_sync): the LDS executes a wavefront's instructions in issue order
+template <bool WAVE>
+__device__ __forceinline__ void slot_sync()
+{
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));   // one complex point; arithmetic maps to v_pk_*_f32
 
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) { return a.xx * b + a.yy * (v2f){-b.y, b.x}; }
@@ -53,7 +70,14 @@ __host__ __device__ constexpr int zi(int i) { return i + (i >> 5); }
 template <int LOGM>
 struct Geo {
     static constexpr int logm = LOGM, m = 1 << LOGM, n = 2 * m, nb = m + 1;
-    static constexpr int tpf = (m / 4 > 16) ? m / 4 : 16;
+    // threads per frame slot: one radix-4 butterfly per thread and pass (m/4), at least 16.  Slots of at most one wavefront
+    // (n_fft <= 512) synchronise with a compiler-level ordering point instead of the workgroup barrier (slot_sync): n_fft 512
+    // forward 10.7 -> 10.3 us, backward 30.2 -> 28.7 us for 8192 frames.  (Shrinking the slots of n_fft 1024 / 2048 to one
+    // wavefront -- 2 / 4 butterflies per thread and pass, SOT_STFT_WAVE_FRAMES=2 -- was measured slower: n_fft 2048 forward
+    // 24.6 -> 29.4 us, backward 53 -> 104 us.)
+    static constexpr int tpf_full = (m / 4 > 16) ? m / 4 : 16;
+    static constexpr int tpf = (SOT_STFT_WAVE_FRAMES == 2 && tpf_full > 64) ? 64 : tpf_full;
+    static constexpr bool wave_sync = (SOT_STFT_WAVE_FRAMES != 0) && tpf <= 64;
     static constexpr int slots = kThreads / tpf;
     static constexpr int zpoints = zi(m);
     static constexpr int table_points = m + m / 2 + 2;
@@ -81,7 +105,7 @@ __device__ __forceinline__ void fft_inplace(v2f* z, const v2f* tw, int lid)
 {
     using G = Geo<LOGM>;
     if (LOGM & 1) {  // stage 1: half = 1, twiddle 1
-        __syncthreads();
+        slot_sync<G::wave_sync>();
         for (int j = lid; j < G::m / 2; j += G::tpf) {
             const int p0 = zi(2 * j), p1 = zi(2 * j + 1);
             const v2f a = z[p0], b = z[p1];
@@ -92,7 +116,7 @@ __device__ __forceinline__ void fft_inplace(v2f* z, const v2f* tw, int lid)
 #pragma unroll
     for (int s = (LOGM & 1) ? 2 : 1; s <= LOGM; s += 2) {
         const int h = 1 << (s - 1);       // half size of stage s; stage s+1 has half size 2h
-        __syncthreads();
+        slot_sync<G::wave_sync>();
         for (int j = lid; j < G::m / 4; j += G::tpf) {
             const int pos = j & (h - 1);
             const int i0 = ((j >> (s - 1)) << (s + 1)) + pos;
@@ -110,7 +134,7 @@ __device__ __forceinline__ void fft_inplace(v2f* z, const v2f* tw, int lid)
             z[p3] = b1 - d2;
         }
     }
-    __syncthreads();
+    slot_sync<G::wave_sync>();
 }
 
 __device__ __forceinline__ int bitrev(int v, int logn) { return (int)(__brev((unsigned)v) >> (32 - logn)); }
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
     const float scale = 1.0f / sqrtf((float)G::n);  // normalized=True: frame_length^-0.5
     const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;   // < 2^31 (host)
     load_tables<LOGM>(tw, wn);
+    if constexpr (G::wave_sync) __syncthreads();   // the tables are shared by the slots, which then run wave-synchronised
     const unsigned fr = blockIdx.x * G::slots + slot;
     const bool active = fr < total;
     const unsigned b = active ? fr / frames : 0u, f = active ? fr - b * frames : 0u;
@@ -220,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int m = G::m;
     const int slot = threadIdx.x / G::tpf, lid = threadIdx.x - slot * G::tpf;
-    constexpr int kPairIters = 3;   // m/2 + 1 pairs (k, m-k) over tpf >= m/4 threads
+    constexpr int kPairIters = (m / 2 + 1 + G::tpf - 1) / G::tpf;   // m/2 + 1 pairs (k, m-k) over the slot's threads (3 at m/4 threads)
     v2f* const zall = reinterpret_cast<v2f*>(smem_f);
     v2f* const z = zall + slot * G::zpoints;
     v2f* const tw = zall + G::slots * G::zpoints;
@@ -231,6 +256,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
     const float up = a.grad_scale ? *a.grad_scale : 1.0f;
     const unsigned total = (unsigned)(a.batch * a.groups), groups = (unsigned)a.groups;
     load_tables<LOGM>(tw, wn);
+    if constexpr (G::wave_sync) __syncthreads();
     const unsigned w = blockIdx.x * G::slots + slot;
     const bool active = w < total;
     const unsigned b = active ? w / groups : 0u, grp = active ? w - b * groups : 0u;
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
         const int64_t f = f_begin + fi;
         const bool has = active && f < a.frames;   // idle slots / missing frames run the same passes on zeros
         const int64_t t0 = f * a.hop;
-        __syncthreads();
+        slot_sync<G::wave_sync>();
         load_frame<LOGM>(a, src, t0, z, has, lid);
         fft_inplace<LOGM, false>(z, tw, lid);
         // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
                 gm[r] = cconj(sk) + mul_i(cmul(wk, cconj(dk)));
             }
         }
-        __syncthreads();
+        slot_sync<G::wave_sync>();
 #pragma unroll
         for (int r = 0; r < kPairIters; ++r) {
             const int k = lid + r * G::tpf;
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
             }
         }
     }
-    __syncthreads();
+    slot_sync<G::wave_sync>();
     if (active) {
         float* dst = a.partial + (int64_t)w * a.span;
         for (int t = lid; t < a.span; t += G::tpf) dst[t] = acc[t];
