@@ -230,6 +230,151 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// n_fft = 2048, one WAVEFRONT per frame (SOT_STFT_WAVE_KERNEL): the 1024-point complex transform of the packed frame as five
+// radix-4 decimation-in-frequency stages on 16 points per lane.  With the index written in base 4, i = (d4 d3 d2 d1 d0), a lane
+// keeps two digits in its 16 registers and the other three are its lane number: stages 1-2 (digits d4, d3) on
+// r = 4 d4 + d3, lane = 16 d2 + 4 d1 + d0 (element 64 r + lane: the load is coalesced), one exchange through the wave's LDS
+// buffer, stages 3-4 (d2, d1), a second exchange, stage 5 (d0); the results are written to LDS in natural frequency order
+// (k = q4 + 4 q3 + 16 q2 + 64 q1 + 256 q0) for the pairwise unpacking of the real transform.  No workgroup barrier inside the
+// frame loop (slot_sync<true>), twiddles W_1024^j from one LDS table per workgroup, 4 frames in flight per workgroup in a
+// persistent grid.  Index algebra checked against numpy's FFT (6e-14) before it was written down here.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWaveBuf = 64 * 17;   // v2f slots of one wave's exchange buffer: [lane][16 registers + 1 pad]; >= zi(1024) = 1056
+
+// radix-4 butterfly, outputs q = 0..3: sum_p a_p W_4^{p q} (forward: W_4 = -i; INVERSE: +i)
+template <bool INVERSE>
+__device__ __forceinline__ void bf4(const v2f a0, const v2f a1, const v2f a2, const v2f a3, v2f& o0, v2f& o1, v2f& o2, v2f& o3)
+{
+    const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    const v2f rot = INVERSE ? mul_i(d13) : mul_mi(d13);
+    o0 = s02 + s13; o1 = d02 + rot; o2 = s02 - s13; o3 = d02 - rot;
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ v2f twid(const v2f* tw, int j) { const v2f w = tw[j & 1023]; return INVERSE ? cconj(w) : w; }
+
+// r[q] = z[64 q + lane] on entry; on return the transform sits in zl[zi(k)], k = 0 .. 1023 (after the caller's slot_sync)
+template <bool INVERSE>
+__device__ __forceinline__ void fft1024_wave(v2f (&r)[16], v2f* zl, const v2f* tw, int lane)
+{
+    v2f o[16];
+    // stage 1 (digit d4; registers 4 p + d3): twiddle W_1024^{(64 d3 + lane) q}
+#pragma unroll
+    for (int d3 = 0; d3 < 4; ++d3) {
+        const int j = 64 * d3 + lane;
+        bf4<INVERSE>(r[d3], r[4 + d3], r[8 + d3], r[12 + d3], o[d3], o[4 + d3], o[8 + d3], o[12 + d3]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) o[4 * q + d3] = cmul(o[4 * q + d3], twid<INVERSE>(tw, j * q));
+    }
+    // stage 2 (digit d3; registers 4 q4 + p): twiddle W_256^{lane q} = W_1024^{4 lane q}
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        bf4<INVERSE>(o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3], r[4 * q4], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) r[4 * q4 + q] = cmul(r[4 * q4 + q], twid<INVERSE>(tw, 4 * lane * q));
+    }
+    // exchange 1: register (q4, q3) of lane (d2, d1, d0) -> register (d2, d1) of lane (q4, q3, d0)
+    {
+        const int d0 = lane & 3, rr = lane >> 2;   // rr = 4 d2 + d1
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zl[(4 * q + d0) * 17 + rr] = r[q];
+        slot_sync<true>();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = zl[lane * 17 + q];
+        slot_sync<true>();
+    }
+    // stage 3 (digit d2; registers 4 p + d1): twiddle W_64^{(4 d1 + d0) q} = W_1024^{16 (4 d1 + d0) q}
+    const int d0 = lane & 3;
+#pragma unroll
+    for (int d1 = 0; d1 < 4; ++d1) {
+        const int j = 16 * (4 * d1 + d0);
+        bf4<INVERSE>(r[d1], r[4 + d1], r[8 + d1], r[12 + d1], o[d1], o[4 + d1], o[8 + d1], o[12 + d1]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) o[4 * q + d1] = cmul(o[4 * q + d1], twid<INVERSE>(tw, j * q));
+    }
+    // stage 4 (digit d1; registers 4 q2 + p): twiddle W_16^{d0 q} = W_1024^{64 d0 q}
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+        bf4<INVERSE>(o[4 * q2], o[4 * q2 + 1], o[4 * q2 + 2], o[4 * q2 + 3], r[4 * q2], r[4 * q2 + 1], r[4 * q2 + 2], r[4 * q2 + 3]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) r[4 * q2 + q] = cmul(r[4 * q2 + q], twid<INVERSE>(tw, 64 * d0 * q));
+    }
+    // exchange 2: register (q2, q1) of lane (q4, q3, d0) -> register (d0, q1) of lane (q4, q3, q2)
+    {
+        const int hi = lane >> 2;   // 4 q4 + q3
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zl[(4 * hi + (q >> 2)) * 17 + 4 * d0 + (q & 3)] = r[q];
+        slot_sync<true>();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = zl[lane * 17 + q];
+        slot_sync<true>();
+    }
+    // stage 5 (digit d0; registers 4 p + q1), no twiddle; result (q4 q3 q2 q1 q0) is frequency k = q4 + 4 q3 + 16 q2 + 64 q1 + 256 q0
+    const int kb = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) {
+        bf4<INVERSE>(r[q1], r[4 + q1], r[8 + q1], r[12 + q1], o[q1], o[4 + q1], o[8 + q1], o[12 + q1]);
+#pragma unroll
+        for (int q0 = 0; q0 < 4; ++q0) zl[zi(kb + 64 * q1 + 256 * q0)] = o[4 * q0 + q1];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const StftArgs a)
+{
+    constexpr int LOGM = 10, m = 1024, n = 2048, nb = m + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    v2f* const tw = reinterpret_cast<v2f*>(smem_f);          // W_1024^j, j < 1024
+    v2f* const wn = tw + 1024;                                // W_2048^k, k <= 512 (+ pad)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    v2f* const zl = wn + 520 + wave * kWaveBuf;
+    // W_1024^{256 a + b} = W_2048^{2 b} (-i)^a  (exact quarter turns of the committed table)
+    for (int j = threadIdx.x; j < 1024; j += kThreads) {
+        const float2 t = kWn[2 * (j & 255)];
+        v2f w = (v2f){t.x, t.y};
+        const int qa = j >> 8;
+        if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w; else if (qa == 3) w = mul_i(w);
+        tw[j] = w;
+    }
+    for (int k = threadIdx.x; k <= 512; k += kThreads) { const float2 t = kWn[k]; wn[k] = (v2f){t.x, t.y}; }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)n);
+    const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;
+    const float2* win = reinterpret_cast<const float2*>(a.window);
+    for (unsigned fr = blockIdx.x * 4 + wave; fr < total; fr += gridDim.x * 4) {
+        const unsigned b = fr / frames, f = fr - b * frames;
+        const float* src = (a.audio_b != nullptr && (int64_t)b >= a.split) ? a.audio_b + ((int64_t)b - a.split) * a.row_stride_b
+                                                                          : a.audio + (int64_t)b * a.row_stride;
+        const int64_t t0 = (int64_t)f * a.hop;
+        const bool inside = t0 + n <= a.samples;
+        v2f r[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = 64 * q + lane;
+            const int64_t t = t0 + 2 * i;
+            const float2 w = win[i];
+            float v0, v1;
+            if (inside) { v0 = src[t] * w.x; v1 = src[t + 1] * w.y; }
+            else { v0 = (t < a.samples) ? src[t] * w.x : 0.0f; v1 = (t + 1 < a.samples) ? src[t + 1] * w.y : 0.0f; }
+            r[q] = (v2f){v0, v1};
+        }
+        fft1024_wave<false>(r, zl, tw, lane);
+        slot_sync<true>();
+        float* dst = a.mag + (int64_t)fr * nb;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int k = lane + 64 * j;
+            if (k <= m / 2) {
+                v2f xk, xm;
+                unpack_pair<LOGM>(zl, wn, k, xk, xm);
+                dst[k] = magnitude(xk) * scale;
+                dst[m - k] = magnitude(xm) * scale;
+            }
+        }
+        slot_sync<true>();   // the unpack reads are issued before the next frame's exchange writes
+    }
+}
+
 // Backward.  With Zin_k = g_k X_k / |X_k| (k = 0 .. m) the gradient of the windowed frame is
 //   y_i = Re(sum_{k=0}^{m} Zin_k e^{+2 pi i k i / n}) / sqrt(n),
 // i.e. the (unnormalised) inverse real transform of the Hermitian spectrum H_k = Zin_k / 2 (0 < k < m), H_0 = Re Zin_0,
@@ -464,6 +609,36 @@ static void launch_slots(void (*kernel)(const StftArgs), int64_t work, size_t ex
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, a);
 }
 
+// OFF by default.  Measured (MI355X, 256 clips x 16 frames, tools/ab_stft.py): forward 24.2 us against 24.7 us for the slot
+// kernel, forward of a pair 52.5 against 42.3 us.  The kernel is correct (tests/test_stft_producer.py passes with it) and does
+// a frame in ~1000 instructions per lane without a workgroup barrier, but at 16-32 frames per CU there is no steady state to
+// amortise anything over: a frame's dependent chain (loads -> five stages -> unpack) on ONE wavefront at two waves per SIMD
+// (194 VGPRs) takes longer than the same frame spread over four wavefronts.  It is the form to switch on for batches of
+// >= 64 frames per CU, after a register diet (the two 16-point arrays).
+#ifndef SOT_STFT_WAVE_KERNEL
+#define SOT_STFT_WAVE_KERNEL 0
+#endif
+// n_fft 2048: the one-wavefront-per-frame kernel, persistent grid (3 workgroups of 4 frames per CU fit the LDS); returns
+// false for other sizes (the caller launches the slot kernel)
+static bool launch_forward_wave(const StftArgs& a, int64_t frames_total, hipStream_t st)
+{
+    if (!SOT_STFT_WAVE_KERNEL || a.logm != 10) return false;
+    const size_t lds = (1024 + 520 + 4 * (size_t)kWaveBuf) * sizeof(float2);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {   // idempotent per device; a benign race sets it twice
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_forward_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            (void)hipGetLastError();
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int64_t want = (frames_total + 3) / 4;
+    const int64_t cap = 256 * 3;
+    hipLaunchKernelGGL(stft_mag_forward_wave_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(kThreads), lds, st, a);
+    return true;
+}
+
 }  // namespace sot_stft
 
 extern "C" {
@@ -481,7 +656,8 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     if (mag == nullptr) return SOT_ERR_NULL_POINTER;
     a.mag = mag;
     (void)hipGetLastError();
-    SOT_STFT_LAUNCH(stft_mag_forward_kernel, batch * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
+    if (!launch_forward_wave(a, batch * a.frames, reinterpret_cast<hipStream_t>(stream)))
+        SOT_STFT_LAUNCH(stft_mag_forward_kernel, batch * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -498,7 +674,8 @@ int sot_stft_mag_forward_pair(const float* audio_a, int64_t row_stride_a, const 
     a.audio_b = audio_b; a.split = batch_each; a.row_stride_b = row_stride_b;
     a.mag = mag;
     (void)hipGetLastError();
-    SOT_STFT_LAUNCH(stft_mag_forward_kernel, 2 * batch_each * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
+    if (!launch_forward_wave(a, 2 * batch_each * a.frames, reinterpret_cast<hipStream_t>(stream)))
+        SOT_STFT_LAUNCH(stft_mag_forward_kernel, 2 * batch_each * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
