@@ -46,6 +46,8 @@ EXPORTS = {
     "sot_w1d_loss_and_grad": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, _vp, _vp, ctypes.c_float, _vp, _vp, _vp,
                                              ctypes.c_size_t, _vp]),
     "sot_scale_inplace": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp]),
+    "sot_profile_next_launch": (ctypes.c_int, [ctypes.c_int]),
+    "sot_profile_elapsed_ms": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     "sot_prepare_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sot_w1d_forward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_reduce_mean": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_float,
@@ -346,6 +348,18 @@ def loss_and_grad(x, y, xpos, ypos, p, flags, plan=None, fused_mean=None):
                                        _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return mean, row_loss, gy
+
+
+def profile_next_launch(slot: int):
+    """Arm kernel-attached timing (sot_profile_next_launch) for this thread's next launch of a compile-time-length kernel."""
+    check(load().sot_profile_next_launch(int(slot)))
+
+
+def profile_elapsed_ms(slot: int) -> float:
+    """Duration of the launch that slot timed (waits for it)."""
+    ms = ctypes.c_float()
+    check(load().sot_profile_elapsed_ms(int(slot), ctypes.byref(ms)))
+    return float(ms.value)
 
 
 def scale_inplace(data: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:

@@ -10,6 +10,7 @@
 // positions, each with one sentinel slot) from staging to the final reduction; HBM traffic per
 // row is 4(n+m) bytes in and 4 bytes out (the algorithmic minimum of SURVEY §8d).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <limits.h>
 #include <math.h>
@@ -1060,6 +1061,19 @@ static inline WsLayout ws_layout(int n, int m)
     return w;
 }
 
+// ---- kernel-attached timing (sot_profile_next_launch, include/sot_hip.h): when armed by the calling thread, the next launch of
+// a full-row kernel goes through hipExtLaunchKernelGGL with a start / stop event pair of the library's ring, i.e. the events
+// bracket the dispatch itself (what rocprofv3's kernel trace measures) instead of stream time around it.
+bool profile_take(hipEvent_t* start, hipEvent_t* stop);
+
+template <typename Kernel, typename Args>
+static inline void launch_maybe_profiled(Kernel kern, int grid, int block, size_t lds, hipStream_t s, const Args& a)
+{
+    hipEvent_t e0, e1;
+    if (profile_take(&e0, &e1)) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
+}
+
 // ---- cross-part host interface (the parts are linked into one shared library) ---------------------------
 struct Launch {
     FwdArgs a;
@@ -1579,7 +1593,51 @@ int run_forward_csr(const float* xw, const float* xp, const int64_t* xoff, int64
 // C ABI (include/sot_hip.h)
 // =============================================================================================
 #if SOT_PART & 16
+namespace sot {
+constexpr int kProfileSlots = 64;
+static hipEvent_t g_prof_start[kProfileSlots], g_prof_stop[kProfileSlots];
+static bool g_prof_made[kProfileSlots];
+static std::mutex g_prof_mu;
+static thread_local int t_prof_armed = -1;   // slot the calling thread armed for its next full-row launch
+
+bool profile_take(hipEvent_t* start, hipEvent_t* stop)
+{
+    const int slot = t_prof_armed;
+    if (slot < 0) return false;
+    t_prof_armed = -1;
+    *start = g_prof_start[slot]; *stop = g_prof_stop[slot];
+    return true;
+}
+}  // namespace sot
+
 extern "C" {
+
+int sot_profile_next_launch(int slot)
+{
+    if (slot < 0 || slot >= sot::kProfileSlots) return SOT_ERR_BAD_SHAPE;
+    {
+        std::lock_guard<std::mutex> lock(sot::g_prof_mu);
+        if (!sot::g_prof_made[slot]) {
+            if (hipEventCreate(&sot::g_prof_start[slot]) != hipSuccess || hipEventCreate(&sot::g_prof_stop[slot]) != hipSuccess) {
+                (void)hipGetLastError();
+                return SOT_ERR_LAUNCH;
+            }
+            sot::g_prof_made[slot] = true;
+        }
+    }
+    sot::t_prof_armed = slot;
+    return SOT_OK;
+}
+
+int sot_profile_elapsed_ms(int slot, float* ms)
+{
+    if (slot < 0 || slot >= sot::kProfileSlots || ms == nullptr || !sot::g_prof_made[slot]) return SOT_ERR_BAD_SHAPE;
+    if (hipEventSynchronize(sot::g_prof_stop[slot]) != hipSuccess || hipEventElapsedTime(ms, sot::g_prof_start[slot], sot::g_prof_stop[slot]) != hipSuccess) {
+        (void)hipGetLastError();
+        return SOT_ERR_LAUNCH;
+    }
+    return SOT_OK;
+}
 
 int sot_abi_version(void) { return SOT_ABI_VERSION; }
 

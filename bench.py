@@ -17,7 +17,7 @@ cannot serve them.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- dominant kernel (sot_forward_full_kernel: the forward specialised for rows that fill their geometry): algorithmic bytes per launch / average launch
-                  duration measured with HIP events on the launch stream inside the timed region;
+                  duration measured live with HIP events attached to its dispatches inside the timed region;
   cpu_baseline -- the op-for-op torch restatement of the reference (oracle/torch_restatement.py,
                   kind "port") timed on this host's cores on a bounded sample of the same workload.
 """
@@ -267,11 +267,16 @@ def cpu_baseline(mode, n, rows, seed):
                       f"{tried} on a {ncpu}-cpu host (torch {torch.__version__} CPU)", "scalar": float(val)}
 
 
-# Launches of the timed region that are bracketed by HIP events: every 4th with one stream (an event pair costs ~2 us of
-# stream time), every 16th with two alternating streams (the bracketed launch is isolated from the other stream: a pipeline
-# bubble of ~12 us; per-step time 52.4 us at stride 4, 43.2 us at stride 16).
-def event_stride(n_lanes):
-    return int(os.environ.get("SOT_BENCH_EVENT_STRIDE", "4" if n_lanes == 1 else "16"))
+# Launches of the timed region whose dominant kernel is timed: the library attaches a HIP start / stop event pair to the kernel
+# dispatch itself (sot_profile_next_launch -> hipExtLaunchKernelGGL: what rocprofv3's kernel trace measures; an event pair
+# recorded on the stream AROUND the call adds 2-3 us of stream time to a 30 us kernel and delays the step).  The library keeps
+# 64 such pairs, so every max(4, ceil(K / 64))-th step of the timed region is timed.
+PROFILE_SLOTS = 64
+
+
+def event_stride(steps):
+    # never more than every 4th step: a timed dispatch is preceded / followed by its event packets (+ ~8 us when EVERY step is timed)
+    return int(os.environ.get("SOT_BENCH_EVENT_STRIDE", str(max(4, -(-steps // PROFILE_SLOTS)))))
 
 
 def main():
@@ -326,18 +331,15 @@ def main():
 
     # Steps are independent.  With N > 1 (or --lanes 2) they are issued on TWO alternating HIP streams: one step's batch-mean
     # kernel and its RCCL all-reduce then overlap the next step's forward kernel instead of leaving the GPU idle for the
-    # collective's latency.  Every 16th step of the timed region is then bracketed by HIP events on the stream it runs on and
-    # isolated from the other stream (it waits for it, and the other stream's next step waits for the closing event), so the
-    # event pair times the forward kernel alone.  Measured with one rank through RCCL: 61.7 us/step with everything on one
-    # stream, 44-47 us like this.  All work, collectives included, completes inside the timed region (device-wide
-    # synchronize at its end).  On one GPU the default is ONE stream: consecutive forward kernels then never share the GPU
-    # and rocprofv3's per-kernel durations agree with the event-bracketed ones (--lanes 2 on one GPU: 42.9 instead of
-    # 48.5 us per step, 191 instead of 169 M rows/s, but overlapped kernel durations in a profile).
+    # collective's latency (measured with one rank through RCCL in round 1: 61.7 us/step with everything on one stream, 44-47 us
+    # like this).  All work, collectives included, completes inside the timed region (device-wide synchronize at its end).  On
+    # one GPU the default is ONE stream: consecutive forward kernels then never share the GPU and rocprofv3's per-kernel
+    # durations agree with the kernel-attached ones (with two streams a timed kernel may share the GPU with the other stream's).
     graph_mode = bool(args.graph_steps)   # --graph-steps: single stream, the whole step replayed from a HIP graph (opt-in)
     n_lanes = args.lanes if args.lanes else (2 if dist_on else 1)
     if graph_mode:
         n_lanes = 1
-    EVENT_STRIDE = event_stride(n_lanes)
+    EVENT_STRIDE = event_stride(args.steps)
     default_stream = torch.cuda.current_stream()
     lanes = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     ring = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(4)]   # local / global fp64 sums (N > 1)
@@ -354,17 +356,9 @@ def main():
                 cur, other = lanes[i & 1], lanes[1 - (i & 1)]
                 torch.cuda.set_stream(cur)
             if profile is not None:
-                a, b = profile
-                if n_lanes == 2:
-                    cur.wait_stream(other)
-                a.record(cur)
-            # same kernels as Wasserstein1D.forward (sot_w1d_loss: the row kernel, then the fixed-order mean kernel), issued as two
-            # calls so that the HIP events bracket the dominant kernel alone (what rocprofv3 lists under its name)
+                nat.profile_next_launch(profile)   # start / stop events attached to the next row-kernel dispatch
+            # same kernels as Wasserstein1D.forward (sot_w1d_loss: the row kernel, then the fixed-order mean kernel)
             rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
-            if profile is not None:
-                b.record(cur)
-                if n_lanes == 2:
-                    other.wait_event(b)
             if not dist_on:
                 return nat.reduce_mean(rows)
             # N > 1: local kernels -> ONE all-reduce(SUM) of the fp64 partial sum over RCCL -> global mean
@@ -392,7 +386,7 @@ def main():
     first_t = step(0)  # parity value on set 0 (global mean when N > 1)
     torch.cuda.synchronize()  # every stream
     first = float(first_t) * (inv_global_rows if dist_on else 1.0)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    timed_slots = []
 
     barrier()
     torch.cuda.synchronize()
@@ -412,7 +406,11 @@ def main():
         if graphs is not None:
             graphs[i % len(graphs)].replay()
         else:
-            out = step(i, events[i] if i % EVENT_STRIDE == 0 else None)
+            if i % EVENT_STRIDE == 0 and len(timed_slots) < PROFILE_SLOTS:
+                timed_slots.append(len(timed_slots))
+                out = step(i, timed_slots[-1])
+            else:
+                out = step(i)
     host_enqueue = time.perf_counter() - t0   # when the host is done issuing work (diagnostic: is the loop host-bound?)
     torch.cuda.synchronize()
     barrier()
@@ -425,14 +423,12 @@ def main():
     del out
     leave_lanes()  # back to the default stream for the secondary measurements
 
-    if graphs is not None:  # events cannot sit inside a replay: time the dominant kernel eagerly after the timed region
-        for i in range(min(args.steps, 50)):
-            step(i, events[i])
+    if graphs is not None:  # a replay carries no kernel-attached events: time the dominant kernel eagerly after the timed region
+        timed_slots = list(range(min(args.steps, 50)))
+        for i in timed_slots:
+            step(i, i)
         torch.cuda.synchronize()
-        events = events[:min(args.steps, 50)]
-    if graphs is None:
-        events = events[::EVENT_STRIDE]  # the launches that were bracketed inside the timed region
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    kern_ms = sum(nat.profile_elapsed_ms(sl) for sl in timed_slots) / len(timed_slots)
 
     def timed(fn, n):  # secondary measurements (outside the contract's timed region), HIP events on the launch stream
         for i in range(3):
@@ -446,7 +442,19 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    extras = {"host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps}
+    extras = {"host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps, "kernel_timing": f"kernel-attached HIP events on {len(timed_slots)} "
+              f"launches of the timed region (every {EVENT_STRIDE}th step)"}
+    with torch.no_grad():   # the same kernel between two events recorded on the stream around the call (round 1's method)
+        x2, y2, xp, yp, flags, plan, _ = marshalled[0]
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for k, (ea, eb) in enumerate(pairs):
+            x2, y2, xp, yp, flags, plan, _ = marshalled[k % len(marshalled)]
+            ea.record()
+            nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[0])
+            eb.record()
+            nat.reduce_mean(rowbuf[0])
+        torch.cuda.synchronize()
+        extras["kernel_ms_between_stream_events"] = sum(ea.elapsed_time(eb) for ea, eb in pairs) / len(pairs)
     n_extra = max(10, min(args.steps, 50))
     if dist_on:  # BASELINE config 3: report the step with and without the collective
         def local_only(i):

@@ -149,6 +149,16 @@ int sot_w1d_loss_and_grad(const sot_problem *prob, float *row_loss /* [B] */, do
                           float grad_scale, float *grad_y /* [B,m] */, uint32_t *completion_counters /* or NULL */,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Kernel-attached timing for benchmarks: arm slot `slot` (0 .. 63) for the calling host thread; the NEXT launch of a kernel with
+ * the row length at compile time (sot_w1d_forward / _loss / _backward / _loss_and_grad on such rows) is then issued with a
+ * start / stop event pair attached to the dispatch itself (hipExtLaunchKernelGGL), so sot_profile_elapsed_ms() -- which waits
+ * for that launch -- returns the kernel's own duration, the figure rocprofv3's kernel trace reports, free of the stream time
+ * an event pair recorded around the call adds.  Not graph-capturable; no effect on results.
+ */
+int sot_profile_next_launch(int slot);
+int sot_profile_elapsed_ms(int slot, float *ms);
+
 /* data[i] *= *scalar for i < count (device scalar); returns without touching `data` when the scalar is exactly 1. */
 int sot_scale_inplace(float *data, int64_t count, const float *scalar, void *stream);
 
