@@ -253,6 +253,19 @@ __device__ __forceinline__ void row_sync()
     }
 }
 
+// "does any thread of the row group see `flag`" + the row group's synchronisation point
+template <int NW>
+__device__ __forceinline__ bool row_any(bool flag)
+{
+    if constexpr (NW == 1 && SOT_WAVE_ROWS) {
+        const bool any = __builtin_amdgcn_ballot_w64(flag) != 0ull;
+        row_sync<NW>();
+        return any;
+    } else {
+        return __syncthreads_or(flag ? 1 : 0) != 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Batch mean inside the kernel that produces the row losses (losses.py:203-211): the workgroup that finishes LAST reduces
 // row_loss[0, B) with the arithmetic of sot_reduce_mean_kernel, operation for operation (1024 "virtual threads" of 8

@@ -291,10 +291,10 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
         for (int e = t; e < n; e += G) c.PX[e] = xp[e];
         for (int e = t; e < m; e += G) c.PY[e] = yp[e];
     }
-    const bool need_sort = __syncthreads_or(unsorted) != 0;  // also the barrier after the loads
+    const bool need_sort = row_any<G / kWave>(unsorted != 0);  // also the barrier after the loads
     if (need_sort) {
-        bitonic_sort_kv(c.PX, IX, npx, t, G, [] { __syncthreads(); });
-        bitonic_sort_kv(c.PY, IY, npy, t, G, [] { __syncthreads(); });
+        bitonic_sort_kv(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });
+        bitonic_sort_kv(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
     }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -302,7 +302,7 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
         ix[k] = (need_sort && e < n) ? IX[e] : e;
         iy[k] = (need_sort && e < m) ? IY[e] : e;
     }
-    __syncthreads();
+    row_sync<G / kWave>();
     if (t == 0) { c.PX[n] = c.PX[n - 1]; c.PY[m] = c.PY[m - 1]; }
     for (int e = t; e < c.pad; e += G) { c.PX[e - c.pad] = c.PX[0]; c.U[e - c.pad] = 0.0f; }  // pads sit at the first position
 }
@@ -337,7 +337,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             mass_chunk_sums<G, false>(U, c.partx, c.mpx, t);
             if (!c.dn) mass_chunk_sums<G, false>(V, c.party, c.mpy, (t + G / 2) & (G - 1));
         }
-        __syncthreads();
+        row_sync<G / kWave>();
         SOT_STAMP(2);
         // columns + fold by ONE wave per array (wave 0: x, wave 1: y; a single-wave row group does both
         // in its two half-waves): the 32 column totals are exchanged through this wave's own LDS slots.
@@ -372,7 +372,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
             if (col == 0) { Sv[half] = S; Sv[2 + half] = 1.0f / guard_mass(S); }
         }
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        row_sync<G / kWave>();
         SOT_STAMP(3);
         Sx = Sv[0];
         Sy = c.dn ? Sx : Sv[1];
@@ -458,7 +458,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     double exx = (SOT_ABLATE & 16) ? 0.0 : wave_shift_right1(inx), exy = (SOT_ABLATE & 16) ? 0.0 : wave_shift_right1(iny);
     if (NW > 1 && c.lane == kWave - 1) { c.wtot[c.wv] = inx; c.wtot[NW + c.wv] = iny; }
     SOT_STAMP(4);
-    __syncthreads();  // every raw weight has been read (also through permutations) before U/V are rewritten
+    row_sync<G / kWave>();  // every raw weight has been read (also through permutations) before U/V are rewritten
     if (NW > 1) {
         double ox = 0.0, oy = 0.0;
         for (int w = 0; w < c.wv; ++w) { ox += c.wtot[w]; oy += c.wtot[NW + w]; }
@@ -485,7 +485,7 @@ __device__ __forceinline__ void build_cdfs(const FwdArgs& a, const RowCtx<G>& c,
     }
     if (ROWPOS && t == 0) { U[n] = INFINITY; V[m] = INFINITY; }
     __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
+    row_sync<G / kWave>();
 }
 
 // left rank of q in a sorted LDS array: #{A_i < q}  (torch.searchsorted side='left', losses.py:219)
@@ -572,7 +572,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
             load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
             load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
         }
-        __syncthreads();
+        row_sync<G / kWave>();
         SOT_STAMP(1);
         float wx[CPT], wy[CPT];
         float Sx, Sy;
@@ -684,10 +684,10 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const 
         if (CSR && bad_row) acc = __int_as_float(0x7fc00000);
         if (NW == 1) {
             if (t == 0 && valid && a.row_loss) store_row_loss(a.row_loss, row, acc, a.mt.counters != nullptr);
-            __syncthreads();  // this row's LDS reads are done before the next row's staging
+            row_sync<G / kWave>();  // this row's LDS reads are done before the next row's staging
         } else {
             if (c.lane == 0) c.red[c.wv] = acc;
-            __syncthreads();
+            row_sync<G / kWave>();
             if (t == 0 && valid && a.row_loss) {
                 float tot = c.red[0];
                 for (int w = 1; w < NW; ++w) tot += c.red[w];
@@ -753,7 +753,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
             load_row<G, CPT, VEC>(a.x + r * a.xs, n, t, rx);
             load_row<G, CPT, VEC>(a.y + r * a.ys, m, t, ry);
         }
-        __syncthreads();
+        row_sync<G / kWave>();
         float wx[CPT], wy[CPT];
         float Sx, Sy;
         build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy);
@@ -817,7 +817,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        row_sync<G / kWave>();
 
         // ---- reverse cumsums (fp64), normalisation terms, scatter to the original columns -------------
         const int e0 = t * CPT;
@@ -837,7 +837,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         double exx = totwx - pinx, exy = totwy - piny;
         if (NW > 1) {
             if (c.lane == 0) { c.wtot[c.wv] = totwx; c.wtot[NW + c.wv] = totwy; }
-            __syncthreads();
+            row_sync<G / kWave>();
             double ox = 0.0, oy = 0.0;
             for (int w = NW - 1; w > c.wv; --w) { ox += c.wtot[w]; oy += c.wtot[NW + w]; }
             exx += ox;
@@ -859,9 +859,9 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         doty = wave_sum(doty);
         double totx = dotx, toty = doty;
         if (NW > 1) {
-            __syncthreads();  // wtot is reused
+            row_sync<G / kWave>();  // wtot is reused
             if (c.lane == 0) { c.wtot[c.wv] = dotx; c.wtot[NW + c.wv] = doty; }
-            __syncthreads();
+            row_sync<G / kWave>();
             totx = 0.0; toty = 0.0;
             for (int w = 0; w < NW; ++w) { totx += c.wtot[w]; toty += c.wtot[NW + w]; }
         }
@@ -914,7 +914,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
                 }
             }
         }
-        __syncthreads();  // GU/GV/wtot reads done before the next row reuses LDS
+        row_sync<G / kWave>();  // GU/GV/wtot reads done before the next row reuses LDS
     }
 }
 
