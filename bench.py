@@ -382,7 +382,8 @@ def main():
 
     enter_lanes()
     for i in range(args.prewarm + args.warmup):
-        out = step(i)
+        # the first launches also create the library's timing event pairs (one per slot), outside the timed region
+        out = step(i, i if i < PROFILE_SLOTS else None)
     first_t = step(0)  # parity value on set 0 (global mean when N > 1)
     torch.cuda.synchronize()  # every stream
     first = float(first_t) * (inv_global_rows if dist_on else 1.0)
