@@ -129,7 +129,7 @@ def test_generator_on_the_gpu_matches_reference_items():
     a = spectra.upsample_window(torch.tensor(fx["amp_frames"]).to(dev), 4096).cpu().numpy()
     np.testing.assert_allclose(a, fx["amp_window_4096"], rtol=0, atol=3e-7)     # the device's hann window differs from the CPU's by an ulp
     b = spectra.upsample_linear(torch.tensor(fx["freq_frames"]).to(dev), 4096).cpu().numpy()
-    np.testing.assert_allclose(b, fx["freq_bilinear_4096"], rtol=1e-6, atol=0)   # x0 + l (x1 - x0) on the device: a few ulps
+    np.testing.assert_allclose(b, fx["freq_bilinear_4096"], rtol=3e-7, atol=0)
     x = spectra.harmonic_items(torch.tensor(fx["frequency"][:12]).to(dev), torch.tensor(fx["weights"][:12]).to(dev)).cpu().numpy()
     assert np.abs(x - fx["x"]).max() <= 2e-5 * 0.9, float(np.abs(x - fx["x"]).max())
     audio = spectra.sinusoidal_synth(torch.tensor(fx["amp_frames"]).to(dev), torch.tensor(fx["f0_frames"]).to(dev), 4096).cpu().numpy()
