@@ -445,6 +445,23 @@ def main():
 
     extras = {"host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps, "kernel_timing": f"kernel-attached HIP events on {len(timed_slots)} "
               f"launches of the timed region (every {EVENT_STRIDE}th step)"}
+    if not dist_on and n_lanes == 1 and not graph_mode:
+        # the same steps pipelined over two HIP streams (what --lanes 2 times, and what N > 1 does to hide the collective): a step's
+        # launch gap, pipeline fill / drain and mean kernel then overlap its neighbour's row kernel.  Not the default on one GPU:
+        # overlapped kernels share the chip, so their individual durations (kernel_ms, rocprofv3) stop describing the kernel.
+        k2 = max(40, min(args.steps, 200))
+        torch.cuda.synchronize()
+        for ln in lanes:
+            ln.wait_stream(default_stream)
+        t2 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(k2):
+                x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(marshalled)]
+                with torch.cuda.stream(lanes[i & 1]):
+                    nat.reduce_mean(nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[i % 4]))
+        torch.cuda.synchronize()
+        extras["two_streams_ms_per_step"] = 1e3 * (time.perf_counter() - t2) / k2
+        extras["two_streams_rows_per_s"] = B / (extras["two_streams_ms_per_step"] * 1e-3)
     with torch.no_grad():   # the same kernel between two events recorded on the stream around the call (round 1's method)
         x2, y2, xp, yp, flags, plan, _ = marshalled[0]
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
