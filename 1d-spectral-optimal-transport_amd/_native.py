@@ -24,7 +24,12 @@ FLAG_NO_AREA = 128       # diagnostic: ignore FLAG_SAME_GRID
 
 SOT_OK = 0
 SOT_ERR_INVALID_P = -1
-ABI_VERSION = 2                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+SOT_ERR_BAD_SHAPE = -2
+SOT_ERR_UNSUPPORTED_SIZE = -3
+SOT_ERR_NULL_POINTER = -4
+SOT_ERR_WORKSPACE = -5
+SOT_ERR_LAUNCH = -6
+ABI_VERSION = 3                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -69,6 +74,10 @@ EXPORTS = {
                                                    ctypes.c_size_t, _vp]),
     "sot_oscillator_bank_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _vp, _vp,
                                                     _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
+    "sot_synth_envelopes_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                   ctypes.c_float, _vp, _vp, _vp]),
+    "sot_synth_envelopes_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                    ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
@@ -615,3 +624,38 @@ def oscillator_bank_backward(freq, amp, sample_rate, grad_audio, need_freq=True,
                                                _ptr(gf), _ptr(ga), ws.data_ptr(), ws.numel(), 0 if forward_workspace is None else 1,
                                                stream_ptr(freq.device)))
     return gf, ga
+
+
+def synth_envelopes_forward(amp_frames, freq_frames, window, n_samples: int, sample_rate: float, harmonic: bool):
+    """Frame-rate controls [batch, frames, K] (+ [batch, frames, 1] f0 when harmonic) -> sample-rate (amplitude, frequency)
+    envelopes [batch, n_samples, K] (sot_synth_envelopes_forward)."""
+    require_hip(amp_frames, freq_frames, window)
+    lib = load()
+    amp_frames, freq_frames, window = amp_frames.contiguous(), freq_frames.contiguous(), window.contiguous()
+    batch, frames, k = amp_frames.shape
+    if freq_frames.shape != ((batch, frames, 1) if harmonic else (batch, frames, k)) or window.numel() * frames != 2 * n_samples:
+        raise RuntimeError("synth_envelopes_forward: control shapes / window length do not fit")
+    amp_env = torch.empty(batch, n_samples, k, dtype=torch.float32, device=amp_frames.device)
+    freq_env = torch.empty_like(amp_env)
+    with _on_device(amp_frames.device):
+        check(lib.sot_synth_envelopes_forward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
+                                              int(n_samples), float(sample_rate), amp_env.data_ptr(), freq_env.data_ptr(),
+                                              stream_ptr(amp_frames.device)))
+    return amp_env, freq_env
+
+
+def synth_envelopes_backward(amp_frames, freq_frames, window, n_samples, sample_rate, harmonic, grad_amp_env, grad_freq_env, need_amp=True,
+                             need_freq=True):
+    require_hip(*[t for t in (amp_frames, freq_frames, window, grad_amp_env, grad_freq_env) if t is not None])
+    lib = load()
+    amp_frames, freq_frames, window = amp_frames.contiguous(), freq_frames.contiguous(), window.contiguous()
+    batch, frames, k = amp_frames.shape
+    ga = torch.empty_like(amp_frames) if need_amp else None
+    gf = torch.empty_like(freq_frames) if need_freq else None
+    gae = grad_amp_env.contiguous() if grad_amp_env is not None else None
+    gfe = grad_freq_env.contiguous() if grad_freq_env is not None else None
+    with _on_device(amp_frames.device):
+        check(lib.sot_synth_envelopes_backward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
+                                               int(n_samples), float(sample_rate), _ptr(gae), _ptr(gfe), _ptr(ga), _ptr(gf),
+                                               stream_ptr(amp_frames.device)))
+    return ga, gf

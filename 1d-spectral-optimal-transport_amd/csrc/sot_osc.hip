@@ -247,9 +247,166 @@ inline bool launch_segment_starts(const OscArgs& a, hipStream_t st)
     return launched();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Envelope upsampling of the synthesiser in front of the oscillator bank (synths.Sinusoidal.get_controls / get_signal,
+// synths.py:62-113): frame-rate controls [batch, frames, sinusoids] -> sample-rate envelopes [batch, samples, sinusoids].
+//   frequencies: harmonic -> f0 * k (ddsp.get_harmonic_frequencies, ddsp.py:6-22);  amplitudes of partials whose FRAME-rate
+//   frequency is at or above Nyquist are zeroed (ddsp.remove_above_nyquist, ddsp.py:25-49);
+//   amplitudes : ddsp.resample(method="window", add_endpoint=True) = half-overlapping Hann windows (ddsp.py:121-205): with
+//                hop = samples / frames, sample t = a hop + u gets  A[a] w[u + hop] + A[min(a + 1, frames - 1)] w[u]  (two products,
+//                one sum -- what the reference's fold() adds up); `window` is torch.hann_window(2 hop) as the caller computed it;
+//   frequencies: ddsp.resample(method="bilinear", add_endpoint=True) = F.interpolate(align_corners=False): source index
+//                s = max(fma(scale, t + 0.5, -0.5), 0), scale = frames / samples, i0 = min(int(s), frames - 1), l = s - i0, and -- the
+//                operation order of ATen's CPU kernel, found by matching its output bit for bit --  fma(1 - l, F[i0], l * F[i1]).
+// The backward hands every frame the weighted sum of the gradients of the samples it contributed to (fixed order: deterministic).
+// ---------------------------------------------------------------------------------------------
+struct EnvArgs {
+    const float* amp; const float* freq;     // [batch, frames, K]; freq [batch, frames, 1] when harmonic
+    const float* window;                     // [2 hop]
+    int64_t batch; int frames, K, harmonic; int64_t samples; int hop; float nyquist, scale;
+    float* amp_env; float* freq_env;         // forward outputs [batch, samples, K]
+    const float* g_amp_env; const float* g_freq_env;   // backward inputs (either may be null)
+    float* g_amp; float* g_freq;             // backward outputs [batch, frames, K] / [batch, frames, K or 1] (either may be null)
+};
+
+__device__ __forceinline__ float frame_freq(const EnvArgs& a, int64_t b, int f, int k)
+{
+    return a.harmonic ? a.freq[b * a.frames + f] * (float)(k + 1) : a.freq[(b * a.frames + f) * a.K + k];
+}
+
+__device__ __forceinline__ void linear_taps(const EnvArgs& a, int64_t t, int& i0, int& i1, float& l0, float& l1)
+{
+    float s = fmaf(a.scale, (float)t + 0.5f, -0.5f);   // one rounding, like the contracted expression of ATen's CPU build
+    s = s < 0.0f ? 0.0f : s;
+    i0 = min((int)s, a.frames - 1);
+    i1 = min(i0 + 1, a.frames - 1);
+    l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(kThreads) void synth_envelopes_forward_kernel(const EnvArgs a)
+{
+    const int64_t total = a.batch * a.samples * a.K;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        const int k = (int)(idx % a.K);
+        const int64_t bt = idx / a.K;
+        const int64_t b = bt / a.samples, t = bt - b * a.samples;
+        // amplitude: overlapping Hann windows over the Nyquist-masked frames
+        const int fa = (int)(t / a.hop), u = (int)(t - (int64_t)fa * a.hop), fb = min(fa + 1, a.frames - 1);
+        float A0 = a.amp[(b * a.frames + fa) * a.K + k], A1 = a.amp[(b * a.frames + fb) * a.K + k];
+        if (frame_freq(a, b, fa, k) >= a.nyquist) A0 = 0.0f;
+        if (frame_freq(a, b, fb, k) >= a.nyquist) A1 = 0.0f;
+        a.amp_env[idx] = A0 * a.window[u + a.hop] + A1 * a.window[u];
+        // frequency: linear interpolation in ATen's operation order
+        int i0, i1; float l0, l1;
+        linear_taps(a, t, i0, i1, l0, l1);
+        a.freq_env[idx] = fmaf(l0, frame_freq(a, b, i0, k), l1 * frame_freq(a, b, i1, k));
+    }
+}
+
+// one workgroup per (clip, frame): thread (sub, k) adds up its share of the frame's samples in ascending order, thread k then adds
+// the `subs` partial sums in order
+__global__ __launch_bounds__(kThreads) void synth_envelopes_backward_kernel(const EnvArgs a)
+{
+    extern __shared__ double red[];                     // [2][subs * K]
+    const int64_t b = blockIdx.x / a.frames;
+    const int f = (int)(blockIdx.x - b * a.frames);
+    const int K = a.K, subs = max(1, kThreads / K);
+    const int64_t tlo = max((int64_t)0, (int64_t)(f - 1) * a.hop), thi = min(a.samples, (int64_t)(f + 2) * a.hop);
+    const int64_t span = thi - tlo, per = (span + subs - 1) / subs;
+    for (int item = threadIdx.x; item < subs * K; item += kThreads) {
+        const int k = item % K, sub = item / K;
+        double ga = 0.0, gf = 0.0;
+        const int64_t t1 = min(thi, tlo + (sub + 1) * per);
+        for (int64_t t = tlo + sub * per; t < t1; ++t) {
+            const int64_t e = (b * a.samples + t) * K + k;
+            if (a.g_amp_env != nullptr) {
+                const int fa = (int)(t / a.hop), u = (int)(t - (int64_t)fa * a.hop), fb = min(fa + 1, a.frames - 1);
+                const float g = a.g_amp_env[e];
+                if (fa == f) ga += (double)(g * a.window[u + a.hop]);
+                if (fb == f) ga += (double)(g * a.window[u]);
+            }
+            if (a.g_freq_env != nullptr) {
+                int i0, i1; float l0, l1;
+                linear_taps(a, t, i0, i1, l0, l1);
+                const float g = a.g_freq_env[e];
+                if (i0 == f) gf += (double)(g * l0);
+                if (i1 == f) gf += (double)(g * l1);
+            }
+        }
+        red[item] = ga; red[subs * K + item] = gf;
+    }
+    __syncthreads();
+    double f0_sum = 0.0;   // harmonic: d/d f0 = sum_k (k + 1) d/d f_k, added in ascending k by thread 0
+    for (int k = threadIdx.x; k < K; k += kThreads) {
+        double ga = 0.0, gf = 0.0;
+        for (int sub = 0; sub < subs; ++sub) { ga += red[sub * K + k]; gf += red[subs * K + sub * K + k]; }
+        if (a.g_amp != nullptr) a.g_amp[(b * a.frames + f) * K + k] = (frame_freq(a, b, f, k) >= a.nyquist) ? 0.0f : (float)ga;
+        if (a.g_freq != nullptr && !a.harmonic) a.g_freq[(b * a.frames + f) * K + k] = (float)gf;
+        red[k] = gf;       // this thread's own slot of sub-range 0: safe to overwrite after it has read its column
+    }
+    if (a.g_freq != nullptr && a.harmonic) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < K; ++k) f0_sum += (double)(k + 1) * red[k];
+            a.g_freq[b * a.frames + f] = (float)f0_sum;
+        }
+    }
+}
+
+static int fill_env_args(int64_t batch, int frames, int sinusoids, int harmonic, int64_t samples, float sample_rate, EnvArgs* a)
+{
+    if (batch < 0 || frames < 1 || sinusoids < 1 || samples < 1 || !(sample_rate > 0.0f)) return SOT_ERR_BAD_SHAPE;
+    if (frames >= samples || samples % frames != 0) return SOT_ERR_BAD_SHAPE;   // ddsp.py:155-170: upsampling only, whole hops
+    if (sinusoids > kMaxSinusoids || samples > kMaxSamples || batch * (int64_t)frames > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
+    a->batch = batch; a->frames = frames; a->K = sinusoids; a->harmonic = harmonic; a->samples = samples;
+    a->hop = (int)(samples / frames); a->nyquist = sample_rate / 2.0f; a->scale = (float)frames / (float)samples;
+    return SOT_OK;
+}
+
 }  // namespace sot_osc
 
 extern "C" {
+
+int sot_synth_envelopes_forward(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames,
+                                int sinusoids, int harmonic, int64_t samples, float sample_rate, float* amp_env, float* freq_env,
+                                void* stream)
+{
+    using namespace sot_osc;
+    EnvArgs a{};
+    if (const int rc = fill_env_args(batch, frames, sinusoids, harmonic, samples, sample_rate, &a)) return rc;
+    if (batch == 0) return SOT_OK;
+    if (!amp_frames || !freq_frames || !window || !amp_env || !freq_env) return SOT_ERR_NULL_POINTER;
+    a.amp = amp_frames; a.freq = freq_frames; a.window = window; a.amp_env = amp_env; a.freq_env = freq_env;
+    const int64_t total = batch * samples * sinusoids;
+    const int64_t want = (total + kThreads - 1) / kThreads;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_envelopes_forward_kernel, dim3((unsigned)(want < 256 * 16 ? want : 256 * 16)), dim3(kThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+int sot_synth_envelopes_backward(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames,
+                                 int sinusoids, int harmonic, int64_t samples, float sample_rate, const float* grad_amp_env,
+                                 const float* grad_freq_env, float* grad_amp_frames, float* grad_freq_frames, void* stream)
+{
+    using namespace sot_osc;
+    EnvArgs a{};
+    if (const int rc = fill_env_args(batch, frames, sinusoids, harmonic, samples, sample_rate, &a)) return rc;
+    if (batch == 0) return SOT_OK;
+    if (!amp_frames || !freq_frames || !window) return SOT_ERR_NULL_POINTER;
+    if ((grad_amp_frames && !grad_amp_env) || (grad_freq_frames && !grad_freq_env)) return SOT_ERR_NULL_POINTER;
+    a.amp = amp_frames; a.freq = freq_frames; a.window = window;
+    a.g_amp_env = grad_amp_frames ? grad_amp_env : nullptr; a.g_freq_env = grad_freq_frames ? grad_freq_env : nullptr;
+    a.g_amp = grad_amp_frames; a.g_freq = grad_freq_frames;
+    const int subs = kThreads / sinusoids > 0 ? kThreads / sinusoids : 1;
+    const size_t lds = 2 * sizeof(double) * (size_t)subs * sinusoids;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_envelopes_backward_kernel, dim3((unsigned)(batch * frames)), dim3(kThreads), lds,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
 
 size_t sot_oscillator_bank_workspace_bytes(int64_t batch, int64_t samples, int sinusoids)
 {

@@ -158,6 +158,52 @@ def upsample_linear(frames: torch.Tensor, n_samples: int) -> torch.Tensor:
     return y.permute(0, 2, 1).contiguous()
 
 
+_HANN = {}
+
+
+def _hann_on(device, hop: int) -> torch.Tensor:
+    """torch.hann_window(2 hop) as the CPU computes it (the reference's dataset is synthesised on the CPU), resident on `device`."""
+    key = (str(device), hop)
+    if key not in _HANN:
+        _HANN[key] = torch.hann_window(2 * hop).to(device)
+    return _HANN[key]
+
+
+def _envelope_kernels_apply(amplitudes, frequencies, n_samples, harmonic) -> bool:
+    if amplitudes.ndim != 3 or frequencies.ndim != 3:
+        return False
+    batch, frames, k = amplitudes.shape
+    want = (batch, frames, 1) if harmonic else (batch, frames, k)
+    return (tuple(frequencies.shape) == want and 1 <= frames < n_samples <= (1 << 20) and n_samples % frames == 0 and 1 <= k <= 512
+            and batch >= 1)
+
+
+class _SynthEnvelopes(torch.autograd.Function):
+    """sot_synth_envelopes_forward / _backward (include/sot_hip.h): harmonic frequencies, Nyquist mask, window and linear
+    upsampling of synths.Sinusoidal.get_controls / get_signal in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, frequencies, amplitudes, n_samples, sample_rate, harmonic):
+        from . import _native as nat
+        frequencies, amplitudes = frequencies.contiguous(), amplitudes.contiguous()
+        window = _hann_on(amplitudes.device, n_samples // amplitudes.shape[1])
+        amp_env, freq_env = nat.synth_envelopes_forward(amplitudes, frequencies, window, n_samples, sample_rate, harmonic)
+        ctx.save_for_backward(frequencies, amplitudes, window)
+        ctx.cfg = (n_samples, sample_rate, harmonic)
+        return freq_env, amp_env
+
+    @staticmethod
+    def backward(ctx, grad_freq_env, grad_amp_env):
+        from . import _native as nat
+        frequencies, amplitudes, window = ctx.saved_tensors
+        n_samples, sample_rate, harmonic = ctx.cfg
+        need_f, need_a = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ga, gf = nat.synth_envelopes_backward(amplitudes, frequencies, window, n_samples, sample_rate, harmonic,
+                                              grad_amp_env.float() if need_a else None, grad_freq_env.float() if need_f else None,
+                                              need_amp=need_a, need_freq=need_f)
+        return gf, ga, None, None, None
+
+
 def sinusoidal_synth(amplitudes: torch.Tensor, frequencies: torch.Tensor, n_samples: int, sample_rate: int = 16000,
                      harmonic: bool = True) -> torch.Tensor:
     """The reference's `synths.Sinusoidal(amp_scale_fn=None, freq_scale_fn=None)` (synths.py:43-128): frame-rate controls
@@ -165,6 +211,9 @@ def sinusoidal_synth(amplitudes: torch.Tensor, frequencies: torch.Tensor, n_samp
     partials at or above Nyquist muted (ddsp.py:25-49) -> amplitudes upsampled with overlapping Hann windows, frequencies
     linearly -> oscillator bank (the HIP kernels behind `oscillator_bank`; differentiable w.r.t. both controls)."""
     amplitudes, frequencies = amplitudes.float(), frequencies.float()
+    if amplitudes.is_cuda and _envelope_kernels_apply(amplitudes, frequencies, n_samples, harmonic):
+        freq_env, amp_env = _SynthEnvelopes.apply(frequencies, amplitudes, int(n_samples), float(sample_rate), bool(harmonic))
+        return oscillator_bank(freq_env, amp_env, sample_rate)
     if harmonic:
         k = amplitudes.shape[-1]
         frequencies = frequencies * torch.linspace(1.0, float(k), k, device=frequencies.device)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 2   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 3   /* bumped on every change of a signature below; the binding checks it */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -254,6 +254,22 @@ int sot_oscillator_bank_backward(const float *freq, const float *amp, int64_t ba
                                     given for the SAME envelopes and has not been written since: its segment start phases
                                     are reused instead of recomputed */,
                                  void *stream);
+
+/* ---- Envelope upsampling of the synthesiser in front of the oscillator bank (synths.Sinusoidal.get_controls /
+ * get_signal, synths.py:62-113 with amp_scale_fn = freq_scale_fn = None): frame-rate controls [batch, frames, sinusoids] ->
+ * sample-rate envelopes [batch, samples, sinusoids] for sot_oscillator_bank_*.  harmonic != 0: freq_frames is [batch, frames, 1]
+ * and partial k gets f0 * (k + 1) (ddsp.py:6-22).  Amplitudes of partials whose frame-rate frequency is >= sample_rate / 2 are
+ * zeroed (ddsp.py:25-49), then upsampled with half-overlapping Hann windows (`window` = torch.hann_window(2 * samples / frames),
+ * [2 hop] floats; ddsp.py:121-205, add_endpoint); frequencies are interpolated linearly (F.interpolate, align_corners=False, in
+ * ATen's operation order): bit-identical to the reference's CPU result.  samples must be a multiple of frames, frames < samples.
+ * The backward takes the gradients w.r.t. the two envelopes and returns those w.r.t. the controls (either output may be NULL;
+ * grad_freq_frames is [batch, frames, 1] when harmonic).  Deterministic. */
+int sot_synth_envelopes_forward(const float *amp_frames, const float *freq_frames, const float *window, int64_t batch, int frames,
+                                int sinusoids, int harmonic, int64_t samples, float sample_rate, float *amp_env, float *freq_env,
+                                void *stream);
+int sot_synth_envelopes_backward(const float *amp_frames, const float *freq_frames, const float *window, int64_t batch, int frames,
+                                 int sinusoids, int harmonic, int64_t samples, float sample_rate, const float *grad_amp_env,
+                                 const float *grad_freq_env, float *grad_amp_frames, float *grad_freq_frames, void *stream);
 
 /* ---- Spectral distance of the reference's MSSLoss (losses.py:365-425 with mean_difference
  * losses.py:7-36 and safe_log utils.py:145-151) over `count` magnitudes target[i], value[i]:

@@ -142,3 +142,98 @@ def test_generator_on_the_gpu_matches_reference_items():
     f0 = torch.tensor(fx["f0_frames"]).to(dev).requires_grad_(True)
     spectra.sinusoidal_synth(amp, f0, 4096).square().mean().backward()
     assert torch.isfinite(amp.grad).all() and torch.isfinite(f0.grad).all() and float(amp.grad.abs().max()) > 0
+
+
+def _cpu_envelopes(amp, freq, n_samples, sample_rate, harmonic):
+    """The reference's composition on CPU torch ops (pinned bit for bit by test_generator_parameters_and_upsamplers_match_
+    reference_on_cpu): harmonic frequencies, Nyquist mask, window / linear upsampling."""
+    from sot_amd import spectra
+    if harmonic:
+        k = amp.shape[-1]
+        freq = freq * torch.linspace(1.0, float(k), k, dtype=freq.dtype)
+    amp = torch.where(freq >= sample_rate / 2.0, torch.zeros_like(amp), amp)
+    if amp.dtype == torch.float64:   # the float64 form of the same two upsamplers, for gradient checks
+        hop = n_samples // amp.shape[1]
+        held = torch.cat([amp, amp[:, -1:, :]], dim=1)
+        w = torch.hann_window(2 * hop).double()
+        a = (held[:, :-1, None, :] * w[None, None, hop:, None] + held[:, 1:, None, :] * w[None, None, :hop, None]).reshape(amp.shape[0], n_samples, -1)
+        f = torch.nn.functional.interpolate(freq.permute(0, 2, 1), size=n_samples, mode="linear", align_corners=False).permute(0, 2, 1)
+        return a, f
+    return spectra.upsample_window(amp, n_samples), spectra.upsample_linear(freq, n_samples)
+
+
+def test_envelope_entry_points_validate_on_the_host():
+    import ctypes
+    from sot_amd import _native as nat
+    lib = nat.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    call = lambda batch, frames, k, samples, rate=16000.0, a=p: lib.sot_synth_envelopes_forward(a, p, p, batch, frames, k, 0, samples, rate, p, p, None)
+    assert call(1, 16, 2, 4100) == nat.SOT_ERR_BAD_SHAPE          # not whole hops (ddsp.py:163-170)
+    assert call(1, 16, 2, 16) == nat.SOT_ERR_BAD_SHAPE            # not an upsampling (ddsp.py:155-160)
+    assert call(1, 0, 2, 16) == nat.SOT_ERR_BAD_SHAPE and call(1, 4, 0, 16) == nat.SOT_ERR_BAD_SHAPE and call(1, 4, 2, 16, rate=0.0) == nat.SOT_ERR_BAD_SHAPE
+    assert call(1, 4, 513, 16) == nat.SOT_ERR_UNSUPPORTED_SIZE and call(1, 4, 2, 1 << 21) == nat.SOT_ERR_UNSUPPORTED_SIZE
+    assert call(0, 4, 2, 16) == nat.SOT_OK                        # an empty batch is a no-op
+    assert call(1, 4, 2, 16, a=None) == nat.SOT_ERR_NULL_POINTER
+    assert lib.sot_synth_envelopes_backward(p, p, p, 1, 4, 2, 0, 16, 16000.0, None, None, p, None, None) == nat.SOT_ERR_NULL_POINTER
+
+
+@pytest.mark.gpu
+def test_hip_envelopes_match_reference_bit_for_bit():
+    """sot_synth_envelopes_forward against the reference's own ddsp.resample outputs (tests/golden/synth_generator.npz) and, with
+    harmonic frequencies and partials above Nyquist, against the CPU composition pinned to the reference: identical bits."""
+    from sot_amd import _native as nat
+    fx = _synth_fixture()
+    dev = torch.device("cuda:0")
+    hann = torch.hann_window(512).to(dev)
+    a, f = nat.synth_envelopes_forward(torch.tensor(fx["amp_frames"]).to(dev), torch.tensor(fx["freq_frames"]).to(dev), hann, 4096, 16000.0, False)
+    assert np.array_equal(a.cpu().numpy(), fx["amp_window_4096"]) and np.array_equal(f.cpu().numpy(), fx["freq_bilinear_4096"])
+    amp, f0 = torch.tensor(fx["amp_frames"]), torch.tensor(fx["f0_frames"])
+    assert float((f0 * 8).max()) > 8000 > float(f0.min())           # some partials are above Nyquist in some frames only
+    a, f = nat.synth_envelopes_forward(amp.to(dev), f0.to(dev), hann, 4096, 16000.0, True)
+    wa, wf = _cpu_envelopes(amp, f0, 4096, 16000.0, True)
+    assert torch.equal(a.cpu(), wa) and torch.equal(f.cpu(), wf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,frames,k,samples,harmonic", [(1, 1, 1, 2, False), (3, 16, 8, 4096, True), (2, 7, 5, 7 * 33, False), (2, 250, 60, 1000, True),
+                                                              (1, 4, 300, 64, False), (5, 64, 8, 64 * 250, True), (2, 3, 512, 12, True)])
+def test_hip_envelopes_forward_and_backward_against_torch(batch, frames, k, samples, harmonic):
+    from sot_amd import _native as nat, spectra
+    g = torch.Generator().manual_seed(batch * 1000 + frames + k)
+    amp = torch.rand(batch, frames, k, generator=g)
+    freq = (60 + 2500 * torch.rand(batch, frames, 1, generator=g)) if harmonic else 100 + 9000 * torch.rand(batch, frames, k, generator=g)
+    dev = torch.device("cuda:0")
+    hann = torch.hann_window(2 * (samples // frames)).to(dev)
+    a, f = nat.synth_envelopes_forward(amp.to(dev), freq.to(dev), hann, samples, 16000.0, harmonic)
+    wa, wf = _cpu_envelopes(amp, freq, samples, 16000.0, harmonic)
+    assert torch.equal(a.cpu(), wa) and torch.equal(f.cpu(), wf)
+    # backward: against CPU autograd of the same composition -- in float32 (the reference's own arithmetic: the same
+    # interpolation weights, sums in another order) and in float64 (whose weights differ from the float32 ones by ~frames * 6e-8)
+    ga_env, gf_env = torch.randn(batch, samples, k, generator=g), torch.randn(batch, samples, k, generator=g)
+    ga, gf = nat.synth_envelopes_backward(amp.to(dev), freq.to(dev), hann, samples, 16000.0, harmonic, ga_env.to(dev), gf_env.to(dev))
+    for dtype, tol in ((torch.float32, 4e-6), (torch.float64, 2e-6 + 2e-7 * frames)):
+        ampr, freqr = amp.detach().clone().to(dtype).requires_grad_(True), freq.detach().clone().to(dtype).requires_grad_(True)
+        ea, ef = _cpu_envelopes(ampr, freqr, samples, 16000.0, harmonic)
+        ((ea * ga_env.to(dtype)).sum() + (ef * gf_env.to(dtype)).sum()).backward()
+        for got, want in ((ga, ampr.grad), (gf, freqr.grad)):
+            assert got.shape == want.shape
+            assert float((got.cpu().double() - want.double()).abs().max()) <= tol * max(1.0, float(want.abs().max())), (dtype, tol)
+    # deterministic, and either gradient alone
+    ga2, none = nat.synth_envelopes_backward(amp.to(dev), freq.to(dev), hann, samples, 16000.0, harmonic, ga_env.to(dev), None, need_freq=False)
+    assert none is None and torch.equal(ga2, ga)
+    none, gf2 = nat.synth_envelopes_backward(amp.to(dev), freq.to(dev), hann, samples, 16000.0, harmonic, None, gf_env.to(dev), need_amp=False)
+    assert none is None and torch.equal(gf2, gf)
+    # through the module function: autograd of the whole synthesiser vs the torch-op composition on the GPU
+    if samples >= 64:
+        a1, f1 = amp.to(dev).requires_grad_(True), freq.to(dev).requires_grad_(True)
+        audio = spectra.sinusoidal_synth(a1, f1, samples, 16000, harmonic=harmonic)
+        audio.square().mean().backward()
+        a2, f2 = amp.to(dev).requires_grad_(True), freq.to(dev).requires_grad_(True)
+        fr = f2 * torch.linspace(1.0, float(k), k, device=dev) if harmonic else f2
+        am = torch.where(fr >= 8000.0, torch.zeros_like(a2), a2)
+        want = spectra.oscillator_bank(spectra.upsample_linear(fr, samples), spectra.upsample_window(am, samples), 16000)
+        want.square().mean().backward()
+        assert float((audio - want).detach().abs().max()) <= 1e-4 * max(1.0, float(want.detach().abs().max()))
+        assert float((a1.grad - a2.grad).abs().max()) <= 1e-4 * max(1e-6, float(a2.grad.abs().max()))
+        assert float((f1.grad - f2.grad).abs().max()) <= 2e-3 * max(1e-9, float(f2.grad.abs().max()))
