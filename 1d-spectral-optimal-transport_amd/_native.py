@@ -78,6 +78,11 @@ EXPORTS = {
                                                    ctypes.c_float, _vp, _vp, _vp]),
     "sot_synth_envelopes_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                                     ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "sot_synth_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "sot_synth_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                         _vp, _vp, ctypes.c_size_t, _vp]),
+    "sot_synth_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                          _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
@@ -658,4 +663,41 @@ def synth_envelopes_backward(amp_frames, freq_frames, window, n_samples, sample_
         check(lib.sot_synth_envelopes_backward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
                                                int(n_samples), float(sample_rate), _ptr(gae), _ptr(gfe), _ptr(ga), _ptr(gf),
                                                stream_ptr(amp_frames.device)))
+    return ga, gf
+
+
+def synth_forward(amp_frames, freq_frames, window, n_samples: int, sample_rate: float, harmonic: bool, for_backward: bool = False):
+    """Frame-rate controls -> audio [batch, n_samples] (sot_synth_forward).  Returns (audio, workspace); with for_backward the
+    workspace is sized for sot_synth_backward, which then reuses the segment start phases in it."""
+    require_hip(amp_frames, freq_frames, window)
+    lib = load()
+    amp_frames, freq_frames, window = amp_frames.contiguous(), freq_frames.contiguous(), window.contiguous()
+    batch, frames, k = amp_frames.shape
+    if freq_frames.shape != ((batch, frames, 1) if harmonic else (batch, frames, k)) or window.numel() * frames != 2 * n_samples:
+        raise RuntimeError("synth_forward: control shapes / window length do not fit")
+    dev = amp_frames.device
+    audio = torch.empty(batch, n_samples, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(8, lib.sot_synth_workspace_bytes(batch, n_samples, k, int(for_backward))), dtype=torch.uint8, device=dev)
+    with _on_device(dev):
+        check(lib.sot_synth_forward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
+                                    int(n_samples), float(sample_rate), audio.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev)))
+    return audio, ws
+
+
+def synth_backward(amp_frames, freq_frames, window, n_samples, sample_rate, harmonic, grad_audio, need_amp=True, need_freq=True,
+                   forward_workspace=None):
+    require_hip(amp_frames, freq_frames, window, grad_audio)
+    lib = load()
+    amp_frames, freq_frames, window, grad_audio = amp_frames.contiguous(), freq_frames.contiguous(), window.contiguous(), grad_audio.contiguous()
+    batch, frames, k = amp_frames.shape
+    dev = amp_frames.device
+    need = lib.sot_synth_workspace_bytes(batch, n_samples, k, 1)
+    reuse = forward_workspace is not None and forward_workspace.numel() >= need
+    ws = forward_workspace if reuse else torch.empty(max(8, need), dtype=torch.uint8, device=dev)
+    ga = torch.empty_like(amp_frames) if need_amp else None
+    gf = torch.empty_like(freq_frames) if need_freq else None
+    with _on_device(dev):
+        check(lib.sot_synth_backward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
+                                     int(n_samples), float(sample_rate), grad_audio.data_ptr(), _ptr(ga), _ptr(gf), ws.data_ptr(), ws.numel(),
+                                     int(reuse), stream_ptr(dev)))
     return ga, gf

@@ -31,6 +31,55 @@ constexpr float kTwoPi = 6.283185307179586f;  // float32(2 * np.pi), as `frequen
 
 enum Mode { kTotals = 0, kForward = 1, kBackward = 2 };
 
+// frame-rate controls of the synthesiser (see the envelope section below for the arithmetic)
+struct EnvArgs {
+    const float* amp; const float* freq;     // [batch, frames, K]; freq [batch, frames, 1] when harmonic
+    const float* window;                     // [2 hop]
+    int64_t batch; int frames, K, harmonic; int64_t samples; int hop; float nyquist, scale;
+    float inv_hop, inv_K;                    // 1 / hop, 1 / K for quotient_of()
+    float* amp_env; float* freq_env;         // forward outputs [batch, samples, K]
+    const float* g_amp_env; const float* g_freq_env;   // backward inputs (either may be null)
+    float* g_amp; float* g_freq;             // backward outputs [batch, frames, K] / [batch, frames, K or 1] (either may be null)
+};
+
+// floor(t / d) for 0 <= t < 2^20 from inv = 1.0f / d: (t + 0.5) / d is at least 0.5 / d away from every integer and the two
+// float roundings move it by less than 2^-22 t / d, so truncation gives the exact quotient (checked exhaustively on the host)
+__device__ __forceinline__ int quotient_of(int t, float inv) { return (int)(((float)t + 0.5f) * inv); }
+
+// frame-rate frequency of sinusoid k in frame f of the clip whose controls start at freq_b
+__device__ __forceinline__ float frame_freq(const EnvArgs& a, const float* freq_b, int f, int k)
+{
+    return a.harmonic ? freq_b[f] * (float)(k + 1) : freq_b[f * a.K + k];
+}
+
+__device__ __forceinline__ const float* clip_freq(const EnvArgs& a, int64_t b) { return a.freq + b * a.frames * (a.harmonic ? 1 : a.K); }
+__device__ __forceinline__ const float* clip_amp(const EnvArgs& a, int64_t b) { return a.amp + b * a.frames * a.K; }
+
+__device__ __forceinline__ void linear_taps(const EnvArgs& a, int t, int& i0, int& i1, float& l0, float& l1)
+{
+    float s = fmaf(a.scale, (float)t + 0.5f, -0.5f);   // one rounding, like the contracted expression of ATen's CPU build
+    s = s < 0.0f ? 0.0f : s;
+    i0 = min((int)s, a.frames - 1);
+    i1 = min(i0 + 1, a.frames - 1);
+    l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
+// the two envelopes of sample t, sinusoid k of clip b (what synth_envelopes_forward_kernel stores)
+__device__ __forceinline__ void envelopes_at(const EnvArgs& a, const float* amp_b, const float* freq_b, int t, int k, bool want_amp,
+                                             float& f, float& am)
+{
+    int i0, i1; float l0, l1;
+    linear_taps(a, t, i0, i1, l0, l1);
+    f = fmaf(l0, frame_freq(a, freq_b, i0, k), l1 * frame_freq(a, freq_b, i1, k));
+    if (!want_amp) return;
+    const int fa = quotient_of(t, a.inv_hop), u = t - fa * a.hop, fb = min(fa + 1, a.frames - 1);
+    float A0 = amp_b[fa * a.K + k], A1 = amp_b[fb * a.K + k];
+    if (frame_freq(a, freq_b, fa, k) >= a.nyquist) A0 = 0.0f;
+    if (frame_freq(a, freq_b, fb, k) >= a.nyquist) A1 = 0.0f;
+    am = A0 * a.window[u + a.hop] + A1 * a.window[u];
+}
+
 struct OscArgs {
     const float* freq; const float* amp; int64_t batch, samples; int sinusoids; float sample_rate;
     int seg_len; int64_t nseg;                      // S and the number of segments per clip
@@ -39,6 +88,7 @@ struct OscArgs {
     float* audio;                                   // forward output [batch, samples]
     const float* grad_audio;                        // backward input  [batch, samples]
     float* grad_freq; float* grad_amp;              // backward outputs [batch, samples, sinusoids]; either may be null
+    EnvArgs ctl;                                    // CTL kernels: the envelopes are evaluated from these frame-rate controls
 };
 
 __device__ __forceinline__ float omega_of(float f, float sr) { return (f * kTwoPi) / sr; }
@@ -53,7 +103,7 @@ inline size_t lds_bytes(int S, int K, int mode)
     return b;
 }
 
-template <int MODE>
+template <int MODE, bool CTL = false>
 __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs a)
 {
     extern __shared__ double smem[];
@@ -72,9 +122,23 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
     const int64_t ebase = (b * a.samples + t_base) * K;     // first envelope element of the tile
     const int64_t wbase = (b * a.nseg + seg) * K;           // this segment's entry in the per-segment arrays
 
-    for (int e = threadIdx.x; e < tile; e += kThreads) {
-        tf[e] = e < n ? a.freq[ebase + e] : 0.0f;            // f = 0 past the clip's end: omega 0, amplitude 0
-        if (MODE != kTotals) ta[e] = e < n ? a.amp[ebase + e] : 0.0f;
+    if (CTL) {
+        // the synthesiser's form: no envelope arrays exist; every tile element is evaluated from the frame-rate controls
+        // (the same float32 operations as synth_envelopes_forward_kernel: identical values)
+        const float* amp_b = clip_amp(a.ctl, b);
+        const float* freq_b = clip_freq(a.ctl, b);
+        for (int e = threadIdx.x; e < tile; e += kThreads) {
+            const int tl = quotient_of(e, a.ctl.inv_K), k = e - tl * K;
+            float f = 0.0f, am = 0.0f;
+            if (e < n) envelopes_at(a.ctl, amp_b, freq_b, (int)t_base + tl, k, MODE != kTotals, f, am);
+            tf[e] = f;
+            if (MODE != kTotals) ta[e] = am;
+        }
+    } else {
+        for (int e = threadIdx.x; e < tile; e += kThreads) {
+            tf[e] = e < n ? a.freq[ebase + e] : 0.0f;            // f = 0 past the clip's end: omega 0, amplitude 0
+            if (MODE != kTotals) ta[e] = e < n ? a.amp[ebase + e] : 0.0f;
+        }
     }
     if (MODE == kBackward)
         for (int t = threadIdx.x; t < S; t += kThreads) tg[t] = t < rows ? a.grad_audio[b * a.samples + t_base + t] : 0.0f;
@@ -241,7 +305,10 @@ inline bool launch_segment_starts(const OscArgs& a, hipStream_t st)
 {
     if (a.nseg <= 1) return true;
     const unsigned grid = (unsigned)(a.batch * a.nseg);
-    hipLaunchKernelGGL(oscillator_tile_kernel<kTotals>, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, a.sinusoids, kTotals), st, a);
+    if (a.ctl.amp != nullptr)
+        hipLaunchKernelGGL((oscillator_tile_kernel<kTotals, true>), dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, a.sinusoids, kTotals), st, a);
+    else
+        hipLaunchKernelGGL(oscillator_tile_kernel<kTotals>, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, a.sinusoids, kTotals), st, a);
     const unsigned sgrid = (unsigned)((a.batch * a.sinusoids + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.phase0, a.batch, a.nseg, a.sinusoids, 0);
     return launched();
@@ -260,47 +327,20 @@ inline bool launch_segment_starts(const OscArgs& a, hipStream_t st)
 //                operation order of ATen's CPU kernel, found by matching its output bit for bit --  fma(1 - l, F[i0], l * F[i1]).
 // The backward hands every frame the weighted sum of the gradients of the samples it contributed to (fixed order: deterministic).
 // ---------------------------------------------------------------------------------------------
-struct EnvArgs {
-    const float* amp; const float* freq;     // [batch, frames, K]; freq [batch, frames, 1] when harmonic
-    const float* window;                     // [2 hop]
-    int64_t batch; int frames, K, harmonic; int64_t samples; int hop; float nyquist, scale;
-    float* amp_env; float* freq_env;         // forward outputs [batch, samples, K]
-    const float* g_amp_env; const float* g_freq_env;   // backward inputs (either may be null)
-    float* g_amp; float* g_freq;             // backward outputs [batch, frames, K] / [batch, frames, K or 1] (either may be null)
-};
-
-__device__ __forceinline__ float frame_freq(const EnvArgs& a, int64_t b, int f, int k)
-{
-    return a.harmonic ? a.freq[b * a.frames + f] * (float)(k + 1) : a.freq[(b * a.frames + f) * a.K + k];
-}
-
-__device__ __forceinline__ void linear_taps(const EnvArgs& a, int64_t t, int& i0, int& i1, float& l0, float& l1)
-{
-    float s = fmaf(a.scale, (float)t + 0.5f, -0.5f);   // one rounding, like the contracted expression of ATen's CPU build
-    s = s < 0.0f ? 0.0f : s;
-    i0 = min((int)s, a.frames - 1);
-    i1 = min(i0 + 1, a.frames - 1);
-    l1 = fminf(fmaxf(s - (float)i0, 0.0f), 1.0f);
-    l0 = 1.0f - l1;
-}
-
 __global__ __launch_bounds__(kThreads) void synth_envelopes_forward_kernel(const EnvArgs a)
 {
-    const int64_t total = a.batch * a.samples * a.K;
-    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
-        const int k = (int)(idx % a.K);
-        const int64_t bt = idx / a.K;
-        const int64_t b = bt / a.samples, t = bt - b * a.samples;
-        // amplitude: overlapping Hann windows over the Nyquist-masked frames
-        const int fa = (int)(t / a.hop), u = (int)(t - (int64_t)fa * a.hop), fb = min(fa + 1, a.frames - 1);
-        float A0 = a.amp[(b * a.frames + fa) * a.K + k], A1 = a.amp[(b * a.frames + fb) * a.K + k];
-        if (frame_freq(a, b, fa, k) >= a.nyquist) A0 = 0.0f;
-        if (frame_freq(a, b, fb, k) >= a.nyquist) A1 = 0.0f;
-        a.amp_env[idx] = A0 * a.window[u + a.hop] + A1 * a.window[u];
-        // frequency: linear interpolation in ATen's operation order
-        int i0, i1; float l0, l1;
-        linear_taps(a, t, i0, i1, l0, l1);
-        a.freq_env[idx] = fmaf(l0, frame_freq(a, b, i0, k), l1 * frame_freq(a, b, i1, k));
+    const int64_t b = blockIdx.y;
+    const float* amp_b = clip_amp(a, b);
+    const float* freq_b = clip_freq(a, b);
+    const int64_t per_clip = a.samples * a.K;            // < 2^29
+    float* amp_env = a.amp_env + b * per_clip;
+    float* freq_env = a.freq_env + b * per_clip;
+    for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < (unsigned)per_clip; e += gridDim.x * kThreads) {
+        const int t = (int)(e / (unsigned)a.K), k = (int)(e - (unsigned)t * (unsigned)a.K);
+        float f, am;
+        envelopes_at(a, amp_b, freq_b, t, k, true, f, am);
+        amp_env[e] = am;
+        freq_env[e] = f;
     }
 }
 
@@ -312,16 +352,17 @@ __global__ __launch_bounds__(kThreads) void synth_envelopes_backward_kernel(cons
     const int64_t b = blockIdx.x / a.frames;
     const int f = (int)(blockIdx.x - b * a.frames);
     const int K = a.K, subs = max(1, kThreads / K);
-    const int64_t tlo = max((int64_t)0, (int64_t)(f - 1) * a.hop), thi = min(a.samples, (int64_t)(f + 2) * a.hop);
-    const int64_t span = thi - tlo, per = (span + subs - 1) / subs;
+    const float* freq_b = clip_freq(a, b);
+    const int tlo = (int)max((int64_t)0, (int64_t)(f - 1) * a.hop), thi = (int)min(a.samples, (int64_t)(f + 2) * a.hop);
+    const int span = thi - tlo, per = (span + subs - 1) / subs;
     for (int item = threadIdx.x; item < subs * K; item += kThreads) {
         const int k = item % K, sub = item / K;
         double ga = 0.0, gf = 0.0;
-        const int64_t t1 = min(thi, tlo + (sub + 1) * per);
-        for (int64_t t = tlo + sub * per; t < t1; ++t) {
+        const int t1 = min(thi, tlo + (sub + 1) * per);
+        for (int t = tlo + sub * per; t < t1; ++t) {
             const int64_t e = (b * a.samples + t) * K + k;
             if (a.g_amp_env != nullptr) {
-                const int fa = (int)(t / a.hop), u = (int)(t - (int64_t)fa * a.hop), fb = min(fa + 1, a.frames - 1);
+                const int fa = quotient_of(t, a.inv_hop), u = t - fa * a.hop, fb = min(fa + 1, a.frames - 1);
                 const float g = a.g_amp_env[e];
                 if (fa == f) ga += (double)(g * a.window[u + a.hop]);
                 if (fb == f) ga += (double)(g * a.window[u]);
@@ -341,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void synth_envelopes_backward_kernel(cons
     for (int k = threadIdx.x; k < K; k += kThreads) {
         double ga = 0.0, gf = 0.0;
         for (int sub = 0; sub < subs; ++sub) { ga += red[sub * K + k]; gf += red[subs * K + sub * K + k]; }
-        if (a.g_amp != nullptr) a.g_amp[(b * a.frames + f) * K + k] = (frame_freq(a, b, f, k) >= a.nyquist) ? 0.0f : (float)ga;
+        if (a.g_amp != nullptr) a.g_amp[(b * a.frames + f) * K + k] = (frame_freq(a, freq_b, f, k) >= a.nyquist) ? 0.0f : (float)ga;
         if (a.g_freq != nullptr && !a.harmonic) a.g_freq[(b * a.frames + f) * K + k] = (float)gf;
         red[k] = gf;       // this thread's own slot of sub-range 0: safe to overwrite after it has read its column
     }
@@ -361,6 +402,7 @@ static int fill_env_args(int64_t batch, int frames, int sinusoids, int harmonic,
     if (sinusoids > kMaxSinusoids || samples > kMaxSamples || batch * (int64_t)frames > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
     a->batch = batch; a->frames = frames; a->K = sinusoids; a->harmonic = harmonic; a->samples = samples;
     a->hop = (int)(samples / frames); a->nyquist = sample_rate / 2.0f; a->scale = (float)frames / (float)samples;
+    a->inv_hop = 1.0f / (float)a->hop; a->inv_K = 1.0f / (float)sinusoids;
     return SOT_OK;
 }
 
@@ -378,10 +420,11 @@ int sot_synth_envelopes_forward(const float* amp_frames, const float* freq_frame
     if (batch == 0) return SOT_OK;
     if (!amp_frames || !freq_frames || !window || !amp_env || !freq_env) return SOT_ERR_NULL_POINTER;
     a.amp = amp_frames; a.freq = freq_frames; a.window = window; a.amp_env = amp_env; a.freq_env = freq_env;
-    const int64_t total = batch * samples * sinusoids;
-    const int64_t want = (total + kThreads - 1) / kThreads;
+    if (batch > 65535) return SOT_ERR_UNSUPPORTED_SIZE;   // one clip per blockIdx.y
+    const int64_t want = (samples * sinusoids + kThreads - 1) / kThreads;
+    const int64_t cap = 256 * 16 / batch > 0 ? 256 * 16 / batch : 1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(synth_envelopes_forward_kernel, dim3((unsigned)(want < 256 * 16 ? want : 256 * 16)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(synth_envelopes_forward_kernel, dim3((unsigned)(want < cap ? want : cap), (unsigned)batch), dim3(kThreads), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
@@ -472,6 +515,87 @@ int sot_oscillator_bank_backward(const float* freq, const float* amp, int64_t ba
         }
         hipLaunchKernelGGL(oscillator_suffix_kernel, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kTotals), st, a);
     }
+    return launched() ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+size_t sot_synth_workspace_bytes(int64_t batch, int64_t samples, int sinusoids, int backward)
+{
+    using namespace sot_osc;
+    if (batch < 1 || samples < 1 || sinusoids < 1 || samples > kMaxSamples || sinusoids > kMaxSinusoids) return 0;
+    const size_t seg = 2 * segment_array_bytes(batch, samples, sinusoids);
+    return seg + (backward ? 2 * sizeof(float) * (size_t)batch * (size_t)samples * (size_t)sinusoids : 0);
+}
+
+static int fill_synth_args(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames, int sinusoids,
+                           int harmonic, int64_t samples, float sample_rate, sot_osc::OscArgs* a)
+{
+    using namespace sot_osc;
+    if (const int rc = fill_env_args(batch, frames, sinusoids, harmonic, samples, sample_rate, &a->ctl)) return rc;
+    a->ctl.amp = amp_frames; a->ctl.freq = freq_frames; a->ctl.window = window;
+    a->batch = batch; a->samples = samples; a->sinusoids = sinusoids; a->sample_rate = sample_rate;
+    a->seg_len = pick_segment(batch, samples, sinusoids);
+    a->nseg = (samples + a->seg_len - 1) / a->seg_len;
+    return batch * a->nseg > 0x7fffffffLL ? SOT_ERR_UNSUPPORTED_SIZE : SOT_OK;
+}
+
+int sot_synth_forward(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames, int sinusoids,
+                      int harmonic, int64_t samples, float sample_rate, float* audio, void* workspace, size_t workspace_bytes, void* stream)
+{
+    using namespace sot_osc;
+    OscArgs a{};
+    if (const int rc = fill_synth_args(amp_frames, freq_frames, window, batch, frames, sinusoids, harmonic, samples, sample_rate, &a)) return rc;
+    if (batch == 0) return SOT_OK;
+    if (!amp_frames || !freq_frames || !window || !audio) return SOT_ERR_NULL_POINTER;
+    a.audio = audio;
+    if (a.nseg > 1) {
+        if (workspace == nullptr) return SOT_ERR_NULL_POINTER;
+        if (workspace_bytes < segment_array_bytes(batch, samples, sinusoids)) return SOT_ERR_WORKSPACE;
+        a.phase0 = static_cast<double*>(workspace);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (!launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
+    hipLaunchKernelGGL((oscillator_tile_kernel<kForward, true>), dim3((unsigned)(batch * a.nseg)), dim3(kThreads),
+                       lds_bytes(a.seg_len, sinusoids, kForward), st, a);
+    return launched() ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+int sot_synth_backward(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames, int sinusoids,
+                       int harmonic, int64_t samples, float sample_rate, const float* grad_audio, float* grad_amp_frames,
+                       float* grad_freq_frames, void* workspace, size_t workspace_bytes, int workspace_from_forward, void* stream)
+{
+    using namespace sot_osc;
+    OscArgs a{};
+    if (const int rc = fill_synth_args(amp_frames, freq_frames, window, batch, frames, sinusoids, harmonic, samples, sample_rate, &a)) return rc;
+    if (batch == 0 || (grad_amp_frames == nullptr && grad_freq_frames == nullptr)) return SOT_OK;
+    if (!amp_frames || !freq_frames || !window || !grad_audio || !workspace) return SOT_ERR_NULL_POINTER;
+    if (workspace_bytes < sot_synth_workspace_bytes(batch, samples, sinusoids, 1)) return SOT_ERR_WORKSPACE;
+    const size_t one = segment_array_bytes(batch, samples, sinusoids);
+    char* ws = static_cast<char*>(workspace);
+    a.phase0 = reinterpret_cast<double*>(ws);
+    a.dcarry = reinterpret_cast<double*>(ws + one);
+    float* g_amp_env = reinterpret_cast<float*>(ws + 2 * one);
+    float* g_freq_env = g_amp_env + (size_t)batch * (size_t)samples * (size_t)sinusoids;
+    a.grad_audio = grad_audio;
+    a.grad_amp = grad_amp_frames ? g_amp_env : nullptr;
+    a.grad_freq = grad_freq_frames ? g_freq_env : nullptr;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)(batch * a.nseg);
+    (void)hipGetLastError();
+    if (!workspace_from_forward && !launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
+    hipLaunchKernelGGL((oscillator_tile_kernel<kBackward, true>), dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kBackward), st, a);
+    if (a.grad_freq != nullptr) {
+        if (a.nseg > 1) {
+            const unsigned sgrid = (unsigned)((batch * sinusoids + kThreads - 1) / kThreads);
+            hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.dcarry, batch, a.nseg, sinusoids, 1);
+        }
+        hipLaunchKernelGGL(oscillator_suffix_kernel, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kTotals), st, a);
+    }
+    EnvArgs e = a.ctl;
+    e.g_amp_env = a.grad_amp; e.g_freq_env = a.grad_freq; e.g_amp = grad_amp_frames; e.g_freq = grad_freq_frames;
+    const int subs = kThreads / sinusoids > 0 ? kThreads / sinusoids : 1;
+    hipLaunchKernelGGL(synth_envelopes_backward_kernel, dim3((unsigned)(batch * frames)), dim3(kThreads),
+                       2 * sizeof(double) * (size_t)subs * sinusoids, st, e);
     return launched() ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

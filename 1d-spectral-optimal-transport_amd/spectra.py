@@ -204,6 +204,34 @@ class _SynthEnvelopes(torch.autograd.Function):
         return gf, ga, None, None, None
 
 
+FUSED_SYNTH = True   # controls -> audio without sample-rate envelopes in memory (sot_synth_*); False: envelope kernels + bank
+
+
+class _Synth(torch.autograd.Function):
+    """sot_synth_forward / _backward (include/sot_hip.h): the oscillator-bank kernels evaluating the envelopes from the
+    frame-rate controls on the fly; same audio, bit for bit, as _SynthEnvelopes followed by _OscillatorBank."""
+
+    @staticmethod
+    def forward(ctx, frequencies, amplitudes, n_samples, sample_rate, harmonic):
+        from . import _native as nat
+        frequencies, amplitudes = frequencies.contiguous(), amplitudes.contiguous()
+        window = _hann_on(amplitudes.device, n_samples // amplitudes.shape[1])
+        want_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        audio, ws = nat.synth_forward(amplitudes, frequencies, window, n_samples, sample_rate, harmonic, for_backward=want_grad)
+        ctx.save_for_backward(frequencies, amplitudes, window, ws)
+        ctx.cfg = (n_samples, sample_rate, harmonic)
+        return audio
+
+    @staticmethod
+    def backward(ctx, grad_audio):
+        from . import _native as nat
+        frequencies, amplitudes, window, ws = ctx.saved_tensors
+        n_samples, sample_rate, harmonic = ctx.cfg
+        ga, gf = nat.synth_backward(amplitudes, frequencies, window, n_samples, sample_rate, harmonic, grad_audio.float(),
+                                    need_amp=ctx.needs_input_grad[1], need_freq=ctx.needs_input_grad[0], forward_workspace=ws)
+        return gf, ga, None, None, None
+
+
 def sinusoidal_synth(amplitudes: torch.Tensor, frequencies: torch.Tensor, n_samples: int, sample_rate: int = 16000,
                      harmonic: bool = True) -> torch.Tensor:
     """The reference's `synths.Sinusoidal(amp_scale_fn=None, freq_scale_fn=None)` (synths.py:43-128): frame-rate controls
@@ -212,6 +240,8 @@ def sinusoidal_synth(amplitudes: torch.Tensor, frequencies: torch.Tensor, n_samp
     linearly -> oscillator bank (the HIP kernels behind `oscillator_bank`; differentiable w.r.t. both controls)."""
     amplitudes, frequencies = amplitudes.float(), frequencies.float()
     if amplitudes.is_cuda and _envelope_kernels_apply(amplitudes, frequencies, n_samples, harmonic):
+        if FUSED_SYNTH:
+            return _Synth.apply(frequencies, amplitudes, int(n_samples), float(sample_rate), bool(harmonic))
         freq_env, amp_env = _SynthEnvelopes.apply(frequencies, amplitudes, int(n_samples), float(sample_rate), bool(harmonic))
         return oscillator_bank(freq_env, amp_env, sample_rate)
     if harmonic:

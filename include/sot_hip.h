@@ -271,6 +271,21 @@ int sot_synth_envelopes_backward(const float *amp_frames, const float *freq_fram
                                  int sinusoids, int harmonic, int64_t samples, float sample_rate, const float *grad_amp_env,
                                  const float *grad_freq_env, float *grad_amp_frames, float *grad_freq_frames, void *stream);
 
+/* ---- The synthesiser in one piece (synths.Sinusoidal.forward, synths.py:62-128): frame-rate controls -> audio [batch, samples]
+ * without the sample-rate envelopes ever existing in memory: the oscillator-bank kernels evaluate them from the controls (the
+ * same float32 operations as sot_synth_envelopes_forward, so the audio equals sot_oscillator_bank_forward on those envelopes bit
+ * for bit).  The backward returns the gradients w.r.t. the controls (either may be NULL; grad_freq_frames [batch, frames, 1]
+ * when harmonic); workspace: sot_synth_workspace_bytes(batch, samples, sinusoids, backward) bytes (0 for invalid sizes) -- the
+ * backward's holds the two sample-rate gradient arrays between its kernels; workspace_from_forward != 0: the first bytes still
+ * hold what sot_synth_forward left there for the SAME controls.  Deterministic. */
+size_t sot_synth_workspace_bytes(int64_t batch, int64_t samples, int sinusoids, int backward);
+int sot_synth_forward(const float *amp_frames, const float *freq_frames, const float *window, int64_t batch, int frames, int sinusoids,
+                      int harmonic, int64_t samples, float sample_rate, float *audio, void *workspace, size_t workspace_bytes,
+                      void *stream);
+int sot_synth_backward(const float *amp_frames, const float *freq_frames, const float *window, int64_t batch, int frames, int sinusoids,
+                       int harmonic, int64_t samples, float sample_rate, const float *grad_audio, float *grad_amp_frames,
+                       float *grad_freq_frames, void *workspace, size_t workspace_bytes, int workspace_from_forward, void *stream);
+
 /* ---- Spectral distance of the reference's MSSLoss (losses.py:365-425 with mean_difference
  * losses.py:7-36 and safe_log utils.py:145-151) over `count` magnitudes target[i], value[i]:
  *   out[0] = mag_weight * mean(D(t - v)) + logmag_weight * mean(D(slog t - slog v)),  D = |.| (l2 == 0) or (.)^2,

@@ -237,3 +237,36 @@ def test_hip_envelopes_forward_and_backward_against_torch(batch, frames, k, samp
         assert float((audio - want).detach().abs().max()) <= 1e-4 * max(1.0, float(want.detach().abs().max()))
         assert float((a1.grad - a2.grad).abs().max()) <= 1e-4 * max(1e-6, float(a2.grad.abs().max()))
         assert float((f1.grad - f2.grad).abs().max()) <= 2e-3 * max(1e-9, float(f2.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,frames,k,samples,harmonic", [(3, 16, 8, 4096, True), (2, 7, 5, 7 * 33, False), (2, 250, 60, 1000, True), (1, 4, 300, 64, False),
+                                                              (5, 64, 8, 64 * 250, True), (1, 1, 1, 2, False), (256, 16, 8, 4096, True)])
+def test_hip_synth_in_one_piece_equals_envelopes_then_bank(batch, frames, k, samples, harmonic):
+    """sot_synth_forward / _backward (no envelope arrays) against the two-step HIP path: identical audio and gradients, bit for bit
+    (same float32 envelope values, same kernels after them)."""
+    from sot_amd import _native as nat, spectra
+    g = torch.Generator().manual_seed(batch * 77 + frames + k)
+    dev = torch.device("cuda:0")
+    amp = torch.rand(batch, frames, k, generator=g).to(dev)
+    freq = ((60 + 2500 * torch.rand(batch, frames, 1, generator=g)) if harmonic else 100 + 9000 * torch.rand(batch, frames, k, generator=g)).to(dev)
+    hann = torch.hann_window(2 * (samples // frames)).to(dev)
+    a_env, f_env = nat.synth_envelopes_forward(amp, freq, hann, samples, 16000.0, harmonic)
+    want = nat.oscillator_bank_forward(f_env, a_env, 16000.0)
+    audio, ws = nat.synth_forward(amp, freq, hann, samples, 16000.0, harmonic, for_backward=True)
+    assert torch.equal(audio, want)
+    grad_audio = torch.randn(batch, samples, generator=g).to(dev)
+    gf_env, ga_env = nat.oscillator_bank_backward(f_env, a_env, 16000.0, grad_audio)
+    wa, wf = nat.synth_envelopes_backward(amp, freq, hann, samples, 16000.0, harmonic, ga_env, gf_env)
+    for reuse in (ws, None):
+        ga, gf = nat.synth_backward(amp, freq, hann, samples, 16000.0, harmonic, grad_audio, forward_workspace=reuse)
+        assert torch.equal(ga, wa) and torch.equal(gf, wf)
+    ga, none = nat.synth_backward(amp, freq, hann, samples, 16000.0, harmonic, grad_audio, need_freq=False)
+    assert none is None and torch.equal(ga, wa)
+    # the module function takes this path, with and without gradients
+    assert spectra.FUSED_SYNTH
+    a1, f1 = amp.clone().requires_grad_(True), freq.clone().requires_grad_(True)
+    out = spectra.sinusoidal_synth(a1, f1, samples, 16000, harmonic=harmonic)
+    assert torch.equal(out.detach(), want) and torch.equal(spectra.sinusoidal_synth(amp, freq, samples, 16000, harmonic=harmonic), want)
+    (out * grad_audio).sum().backward()
+    assert torch.equal(a1.grad, wa) and torch.equal(f1.grad, wf)

@@ -35,20 +35,29 @@ def main():
         return spectra.oscillator_bank(spectra.upsample_linear(fr, samples), spectra.upsample_window(am, samples), 16000)
 
     print(f"batch {batch} frames {frames} samples {samples}")
+    print("forward, one piece        : %8.1f us" % timed(lambda: spectra.sinusoidal_synth(amp, f0, samples)))
+    spectra.FUSED_SYNTH = False
     print("forward, envelope kernels : %8.1f us" % timed(lambda: spectra.sinusoidal_synth(amp, f0, samples)))
+    spectra.FUSED_SYNTH = True
     print("forward, torch envelopes  : %8.1f us" % timed(lambda: torch_envelopes(amp, f0)))
     ar, fr = amp.clone().requires_grad_(True), f0.clone().requires_grad_(True)
 
     def step(fn):
         ar.grad = fr.grad = None
         fn(ar, fr).square().mean().backward()
+    print("fwd+bwd, one piece        : %8.1f us" % timed(lambda: step(lambda a, f: spectra.sinusoidal_synth(a, f, samples))))
+    spectra.FUSED_SYNTH = False
     print("fwd+bwd, envelope kernels : %8.1f us" % timed(lambda: step(lambda a, f: spectra.sinusoidal_synth(a, f, samples))))
+    spectra.FUSED_SYNTH = True
     print("fwd+bwd, torch envelopes  : %8.1f us" % timed(lambda: step(torch_envelopes)))
     from sot_amd import _native as nat
     hann = torch.hann_window(2 * samples // frames).to(dev)
     print("envelope forward kernel   : %8.1f us" % timed(lambda: nat.synth_envelopes_forward(amp, f0, hann, samples, 16000.0, True)))
     g = torch.randn(batch, samples, 8, device=dev)
     print("envelope backward kernel  : %8.1f us" % timed(lambda: nat.synth_envelopes_backward(amp, f0, hann, samples, 16000.0, True, g, g)))
+    print("synth forward (C ABI)     : %8.1f us" % timed(lambda: nat.synth_forward(amp, f0, hann, samples, 16000.0, True)))
+    ga = torch.randn(batch, samples, device=dev)
+    print("synth backward (C ABI)    : %8.1f us" % timed(lambda: nat.synth_backward(amp, f0, hann, samples, 16000.0, True, ga)))
     fe, ae = nat.synth_envelopes_forward(amp, f0, hann, samples, 16000.0, True)
     print("oscillator bank forward   : %8.1f us" % timed(lambda: nat.oscillator_bank_forward(fe, ae, 16000.0)))
 
