@@ -78,7 +78,7 @@ EXPORTS = {
                                                    ctypes.c_float, _vp, _vp, _vp]),
     "sot_synth_envelopes_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                                     ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
-    "sot_synth_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "sot_synth_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sot_synth_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                          _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_synth_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -677,7 +677,7 @@ def synth_forward(amp_frames, freq_frames, window, n_samples: int, sample_rate: 
         raise RuntimeError("synth_forward: control shapes / window length do not fit")
     dev = amp_frames.device
     audio = torch.empty(batch, n_samples, dtype=torch.float32, device=dev)
-    ws = torch.empty(max(8, lib.sot_synth_workspace_bytes(batch, n_samples, k, int(for_backward))), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(8, lib.sot_synth_workspace_bytes(batch, frames, n_samples, k, int(for_backward))), dtype=torch.uint8, device=dev)
     with _on_device(dev):
         check(lib.sot_synth_forward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
                                     int(n_samples), float(sample_rate), audio.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(dev)))
@@ -691,7 +691,7 @@ def synth_backward(amp_frames, freq_frames, window, n_samples, sample_rate, harm
     amp_frames, freq_frames, window, grad_audio = amp_frames.contiguous(), freq_frames.contiguous(), window.contiguous(), grad_audio.contiguous()
     batch, frames, k = amp_frames.shape
     dev = amp_frames.device
-    need = lib.sot_synth_workspace_bytes(batch, n_samples, k, 1)
+    need = lib.sot_synth_workspace_bytes(batch, frames, n_samples, k, 1)
     reuse = forward_workspace is not None and forward_workspace.numel() >= need
     ws = forward_workspace if reuse else torch.empty(max(8, need), dtype=torch.uint8, device=dev)
     ga = torch.empty_like(amp_frames) if need_amp else None

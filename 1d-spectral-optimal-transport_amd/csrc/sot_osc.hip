@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <mutex>
 
 #include "../../include/sot_hip.h"
 
@@ -29,7 +30,7 @@ constexpr int kMaxSinusoids = kTileElems / kRun;
 constexpr int64_t kMaxSamples = 1 << 20;
 constexpr float kTwoPi = 6.283185307179586f;  // float32(2 * np.pi), as `frequency_envelopes * (2.0 * np.pi)` rounds it
 
-enum Mode { kTotals = 0, kForward = 1, kBackward = 2 };
+enum Mode { kTotals = 0, kForward = 1, kBackward = 2, kBackwardFrames = 3 };   // 3: backward reduced to the frame-rate controls in the tile
 
 // frame-rate controls of the synthesiser (see the envelope section below for the arithmetic)
 struct EnvArgs {
@@ -89,6 +90,9 @@ struct OscArgs {
     const float* grad_audio;                        // backward input  [batch, samples]
     float* grad_freq; float* grad_amp;              // backward outputs [batch, samples, sinusoids]; either may be null
     EnvArgs ctl;                                    // CTL kernels: the envelopes are evaluated from these frame-rate controls
+    // kBackwardFrames: cumulative linear-tap weights and Hann-window weights [frames, 3 hop], per-segment partial sums
+    // [batch, nseg, nslot, sinusoids] x 2
+    const double* wtab; const float* atab; double* part_amp; double* part_freq; int nslot;
 };
 
 __device__ __forceinline__ float omega_of(float f, float sr) { return (f * kTwoPi) / sr; }
@@ -103,6 +107,16 @@ inline size_t lds_bytes(int S, int K, int mode)
     return b;
 }
 
+// frame slots a segment of S samples can touch: the frames whose 3-hop support [(f - 1) hop, (f + 2) hop) meets the segment
+inline int frame_slots(int S, int hop) { return (S + hop - 1) / hop + 3; }
+
+// kBackwardFrames: the backward tile + two arrays of partial sums (one entry per (frame slot, sinusoid, sub-range))
+inline size_t lds_bytes_frames(int S, int K, int hop)
+{
+    const size_t pairs = (size_t)frame_slots(S, hop) * K;
+    return lds_bytes(S, K, kBackward) + 8 + 2 * sizeof(double) * (pairs > (size_t)kThreads ? pairs : (size_t)kThreads);
+}
+
 template <int MODE, bool CTL = false>
 __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs a)
 {
@@ -110,7 +124,8 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
     const int K = a.sinusoids, S = a.seg_len, slots = S / kRun, items = slots * K, tile = S * K;
     double* ls = smem;
     double* ls2 = ls + items;
-    float* tf = reinterpret_cast<float*>(ls + (MODE == kBackward ? 2 : 1) * items);
+    constexpr bool BWD = MODE == kBackward || MODE == kBackwardFrames;
+    float* tf = reinterpret_cast<float*>(ls + (BWD ? 2 : 1) * items);
     float* ta = tf + tile;
     float* tg = ta + tile;
     const float sr = a.sample_rate, nyq = sr / 2.0f;
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
             if (MODE != kTotals) ta[e] = e < n ? a.amp[ebase + e] : 0.0f;
         }
     }
-    if (MODE == kBackward)
+    if (BWD)
         for (int t = threadIdx.x; t < S; t += kThreads) tg[t] = t < rows ? a.grad_audio[b * a.samples + t_base + t] : 0.0f;
     __syncthreads();
 
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
                 dlocal += (double)dphi;
             }
         }
-        if (MODE == kBackward) ls2[i] = dlocal;
+        if (BWD) ls2[i] = dlocal;
     }
     __syncthreads();
 
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
             for (int off = tps >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);
             if (sub == 0 && t < rows) dst[t] = s;
         }
-    } else {
+    } else if (MODE == kBackward) {
         for (int e = threadIdx.x; e < n; e += kThreads) {
             if (a.grad_amp) a.grad_amp[ebase + e] = ta[e];
             if (a.grad_freq) a.grad_freq[ebase + e] = tf[e];  // dphi for now; the suffix kernel turns it into the gradient
@@ -218,6 +233,72 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
                 for (int slot = 0; slot < slots; ++slot) s += ls2[slot * K + k];
                 a.dcarry[wbase + k] = s;
             }
+    } else {
+        // The synthesiser's backward: nothing at sample rate leaves the tile.  The gradient of a frame-rate control is a
+        // weighted sum over the samples of its 3-hop support:
+        //   amplitude: sum_t (g sin)_t wamp_f(t)                               (the two Hann-window halves),
+        //   frequency: sum_t l_f(t) sum_{t' >= t} dphi_t'  =  sum_t' dphi_t' W_f(t'),   W_f(t') = sum_{t <= t'} l_f(t)
+        // (order of summation exchanged: W_f is the cumulative tap weight a.wtab holds; it stays at its last value behind the
+        // support, where whole segments enter through their dphi totals -- synth_frames_reduce_kernel).  Here: the part of both
+        // sums that lies in this tile, for every frame whose support meets it; fixed order.
+        const EnvArgs& e = a.ctl;
+        const bool want_amp = a.part_amp != nullptr, want_freq = a.part_freq != nullptr;
+        if (want_freq)
+            for (int k = threadIdx.x; k < K; k += kThreads) {
+                double s = 0.0;
+                for (int slot = 0; slot < slots; ++slot) s += ls2[slot * K + k];
+                a.dcarry[wbase + k] = s;
+            }
+        double* pa_l = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(tg + S + 1) & ~(uintptr_t)7);
+        const int hop = e.hop, tb = (int)t_base, T = (int)a.samples;
+        const int f_lo = max(0, quotient_of(tb, e.inv_hop) - 1);
+        const int f_hi = min(e.frames - 1, quotient_of(tb + rows - 1, e.inv_hop) + 1);
+        const int P = (f_hi - f_lo + 1) * K;                        // (frame slot, sinusoid) pairs; <= a.nslot * K
+        const int subs = P >= kThreads ? 1 : kThreads / P;          // sub-ranges of the tile's samples per pair
+        const int chunk = (rows + subs - 1) / subs;
+        double* pf_l = pa_l + (P > kThreads ? P : kThreads);
+        for (int item = threadIdx.x; item < P * subs; item += kThreads) {
+            const int sub = item / P, pr = item - sub * P, sl = pr / K, k = pr - sl * K, f = f_lo + sl;
+            const int ts = max(0, (f - 1) * hop), te = min(T, (f + 2) * hop);
+            const int lo = max(tb + sub * chunk, ts), hi = min(tb + min(rows, (sub + 1) * chunk), want_freq ? T : te);
+            const double* wt = a.wtab + (int64_t)f * 3 * hop;
+            const float* at = a.atab + (int64_t)f * 3 * hop;
+            double sa = 0.0, sf = 0.0;
+            // (8 table loads in flight per thread: the tables come from L2, one load at a time would cost its full latency per sample)
+            if (want_amp) {
+                const int hia = min(hi, te);
+                int t = lo;
+                for (; t + 8 <= hia; t += 8) {
+                    float w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = at[t + j - ts];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sa += (double)(ta[(t + j - tb) * K + k] * w[j]);
+                }
+                for (; t < hia; ++t) sa += (double)(ta[(t - tb) * K + k] * at[t - ts]);
+            }
+            if (want_freq) {
+                int t = lo;
+                for (; t + 8 <= hi; t += 8) {
+                    double w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = wt[min(t + j - ts, 3 * hop - 1)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sf += (double)tf[(t + j - tb) * K + k] * w[j];
+                }
+                for (; t < hi; ++t) sf += (double)tf[(t - tb) * K + k] * wt[min(t - ts, 3 * hop - 1)];
+            }
+            pa_l[item] = sa; pf_l[item] = sf;
+        }
+        __syncthreads();
+        for (int pr = threadIdx.x; pr < P; pr += kThreads) {
+            double sa = 0.0, sf = 0.0;
+            for (int sub = 0; sub < subs; ++sub) { sa += pa_l[sub * P + pr]; sf += pf_l[sub * P + pr]; }
+            const int sl = pr / K, k = pr - sl * K;
+            const int64_t o = ((b * a.nseg + seg) * a.nslot + sl) * K + k;
+            if (want_amp) a.part_amp[o] = sa;
+            if (want_freq) a.part_freq[o] = sf;
+        }
     }
 }
 
@@ -395,6 +476,83 @@ __global__ __launch_bounds__(kThreads) void synth_envelopes_backward_kernel(cons
     }
 }
 
+// The weights sample t = ts(f) + j puts on frame f, for the 3 hop samples from ts(f) = max(0, (f - 1) hop) on (the same for every
+// clip and sinusoid; zero past the clip's end): atab [frames, 3 hop] floats -- the Hann-window weight of the amplitude upsampling
+// (both halves added where the held last frame makes them meet); wtab [frames, 3 hop] doubles -- the CUMULATIVE linear-
+// interpolation weight W_f(j) = sum_{j' <= j} l_f(ts + j').  One workgroup per frame.
+__global__ __launch_bounds__(kThreads) void synth_tap_table_kernel(const EnvArgs a, double* wtab, float* atab)
+{
+    __shared__ double sums[kThreads];
+    const int f = blockIdx.x, n = 3 * a.hop, ts = max(0, (f - 1) * a.hop), T = (int)a.samples;
+    const int chunk = (n + kThreads - 1) / kThreads, j0 = min(n, (int)threadIdx.x * chunk), j1 = min(n, j0 + chunk);
+    auto weight = [&](int t) -> double {
+        if (t >= T) return 0.0;
+        int i0, i1; float l0, l1;
+        linear_taps(a, t, i0, i1, l0, l1);
+        return (double)((i0 == f ? l0 : 0.0f) + (i1 == f ? l1 : 0.0f));
+    };
+    double s = 0.0;
+    for (int j = j0; j < j1; ++j) s += weight(ts + j);
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int i = 0; i < kThreads; ++i) { const double v = sums[i]; sums[i] = run; run += v; }
+    }
+    __syncthreads();
+    double run = sums[threadIdx.x];
+    for (int j = j0; j < j1; ++j) {
+        const int t = ts + j;
+        run += weight(t);
+        wtab[(int64_t)f * n + j] = run;
+        float w = 0.0f;
+        if (t < T) {
+            const int fa = quotient_of(t, a.inv_hop), u = t - fa * a.hop, fb = min(fa + 1, a.frames - 1);
+            w = (fa == f ? a.window[u + a.hop] : 0.0f) + (fb == f ? a.window[u] : 0.0f);
+        }
+        atab[(int64_t)f * n + j] = w;
+    }
+}
+
+// gradients of the frame-rate controls from the per-segment partial sums of oscillator_tile_kernel<kBackwardFrames>: one workgroup
+// per (clip, frame), one thread per sinusoid; segments are added in ascending order.
+__global__ __launch_bounds__(64) void synth_frames_reduce_kernel(const OscArgs a, float* g_amp, float* g_freq)
+{
+    extern __shared__ double fsum[];     // [K]: harmonic only
+    const EnvArgs& e = a.ctl;
+    const int64_t b = blockIdx.x / e.frames;
+    const int f = (int)(blockIdx.x - b * e.frames);
+    const int K = e.K, hop = e.hop, S = a.seg_len, T = (int)a.samples;
+    const float* freq_b = clip_freq(e, b);
+    const int ts = max(0, (f - 1) * hop), te = min(T, (f + 2) * hop);
+    const int seg_a = ts / S, seg_b = (te - 1) / S;
+    const double wtot = a.part_freq != nullptr ? a.wtab[(int64_t)f * 3 * hop + 3 * hop - 1] : 0.0;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        double sa = 0.0, sf = 0.0;
+        for (int seg = seg_a; seg <= seg_b; ++seg) {
+            const int sl = f - max(0, quotient_of(seg * S, e.inv_hop) - 1);
+            const int64_t o = ((b * a.nseg + seg) * a.nslot + sl) * K + k;
+            if (a.part_amp != nullptr) sa += a.part_amp[o];
+            if (a.part_freq != nullptr) sf += a.part_freq[o];
+        }
+        if (g_amp != nullptr) g_amp[(b * e.frames + f) * K + k] = (frame_freq(e, freq_b, f, k) >= e.nyquist) ? 0.0f : (float)sa;
+        if (g_freq != nullptr) {
+            if (a.nseg > 1) sf += wtot * a.dcarry[(b * a.nseg + seg_b) * K + k];   // all later segments (after the reverse scan)
+            sf = sf / (double)a.sample_rate * (double)kTwoPi;                        // d omega / d f
+            if (!e.harmonic) g_freq[(b * e.frames + f) * K + k] = (float)sf;
+            else fsum[k] = sf;
+        }
+    }
+    if (g_freq != nullptr && e.harmonic) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;   // d / d f0 = sum_k (k + 1) d / d f_k, in ascending k
+            for (int k = 0; k < K; ++k) s += (double)(k + 1) * fsum[k];
+            g_freq[b * e.frames + f] = (float)s;
+        }
+    }
+}
+
 static int fill_env_args(int64_t batch, int frames, int sinusoids, int harmonic, int64_t samples, float sample_rate, EnvArgs* a)
 {
     if (batch < 0 || frames < 1 || sinusoids < 1 || samples < 1 || !(sample_rate > 0.0f)) return SOT_ERR_BAD_SHAPE;
@@ -518,12 +676,23 @@ int sot_oscillator_bank_backward(const float* freq, const float* amp, int64_t ba
     return launched() ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
-size_t sot_synth_workspace_bytes(int64_t batch, int64_t samples, int sinusoids, int backward)
+// backward workspace: [segment start phases][segment dphi totals][wtab: frames x 3 hop doubles][partial sums x 2][atab: frames x 3 hop floats]
+static size_t synth_partial_entries(int64_t batch, int frames, int64_t samples, int sinusoids)
 {
     using namespace sot_osc;
-    if (batch < 1 || samples < 1 || sinusoids < 1 || samples > kMaxSamples || sinusoids > kMaxSinusoids) return 0;
+    const int S = pick_segment(batch, samples, sinusoids);
+    const int64_t nseg = (samples + S - 1) / S;
+    return (size_t)batch * (size_t)nseg * (size_t)frame_slots(S, (int)(samples / frames)) * (size_t)sinusoids;
+}
+
+size_t sot_synth_workspace_bytes(int64_t batch, int frames, int64_t samples, int sinusoids, int backward)
+{
+    using namespace sot_osc;
+    if (batch < 1 || frames < 1 || samples < 1 || sinusoids < 1 || samples > kMaxSamples || sinusoids > kMaxSinusoids) return 0;
+    if (frames >= samples || samples % frames != 0) return 0;
     const size_t seg = 2 * segment_array_bytes(batch, samples, sinusoids);
-    return seg + (backward ? 2 * sizeof(float) * (size_t)batch * (size_t)samples * (size_t)sinusoids : 0);
+    if (!backward) return seg;
+    return seg + sizeof(double) * (3 * (size_t)samples + 2 * synth_partial_entries(batch, frames, samples, sinusoids)) + sizeof(float) * 3 * (size_t)samples;
 }
 
 static int fill_synth_args(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames, int sinusoids,
@@ -569,33 +738,40 @@ int sot_synth_backward(const float* amp_frames, const float* freq_frames, const 
     if (const int rc = fill_synth_args(amp_frames, freq_frames, window, batch, frames, sinusoids, harmonic, samples, sample_rate, &a)) return rc;
     if (batch == 0 || (grad_amp_frames == nullptr && grad_freq_frames == nullptr)) return SOT_OK;
     if (!amp_frames || !freq_frames || !window || !grad_audio || !workspace) return SOT_ERR_NULL_POINTER;
-    if (workspace_bytes < sot_synth_workspace_bytes(batch, samples, sinusoids, 1)) return SOT_ERR_WORKSPACE;
+    if (workspace_bytes < sot_synth_workspace_bytes(batch, frames, samples, sinusoids, 1)) return SOT_ERR_WORKSPACE;
     const size_t one = segment_array_bytes(batch, samples, sinusoids);
+    const size_t entries = synth_partial_entries(batch, frames, samples, sinusoids);
     char* ws = static_cast<char*>(workspace);
     a.phase0 = reinterpret_cast<double*>(ws);
     a.dcarry = reinterpret_cast<double*>(ws + one);
-    float* g_amp_env = reinterpret_cast<float*>(ws + 2 * one);
-    float* g_freq_env = g_amp_env + (size_t)batch * (size_t)samples * (size_t)sinusoids;
+    double* wtab = reinterpret_cast<double*>(ws + 2 * one);
+    double* parts = wtab + 3 * (size_t)samples;
+    a.wtab = wtab;
+    float* atab = reinterpret_cast<float*>(parts + 2 * entries);
+    a.atab = atab;
+    a.part_amp = grad_amp_frames ? parts : nullptr;
+    a.part_freq = grad_freq_frames ? parts + entries : nullptr;
+    a.nslot = frame_slots(a.seg_len, a.ctl.hop);
     a.grad_audio = grad_audio;
-    a.grad_amp = grad_amp_frames ? g_amp_env : nullptr;
-    a.grad_freq = grad_freq_frames ? g_freq_env : nullptr;
+    const size_t lds = lds_bytes_frames(a.seg_len, sinusoids, a.ctl.hop);
+    if (lds > 160 * 1024) return SOT_ERR_UNSUPPORTED_SIZE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const unsigned grid = (unsigned)(batch * a.nseg);
     (void)hipGetLastError();
     if (!workspace_from_forward && !launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
-    hipLaunchKernelGGL((oscillator_tile_kernel<kBackward, true>), dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kBackward), st, a);
-    if (a.grad_freq != nullptr) {
-        if (a.nseg > 1) {
-            const unsigned sgrid = (unsigned)((batch * sinusoids + kThreads - 1) / kThreads);
-            hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.dcarry, batch, a.nseg, sinusoids, 1);
-        }
-        hipLaunchKernelGGL(oscillator_suffix_kernel, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kTotals), st, a);
+    hipLaunchKernelGGL(synth_tap_table_kernel, dim3((unsigned)frames), dim3(kThreads), 0, st, a.ctl, wtab, atab);
+    auto kern = oscillator_tile_kernel<kBackwardFrames, true>;
+    if (lds > 64 * 1024) {
+        static std::once_flag once;
+        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     }
-    EnvArgs e = a.ctl;
-    e.g_amp_env = a.grad_amp; e.g_freq_env = a.grad_freq; e.g_amp = grad_amp_frames; e.g_freq = grad_freq_frames;
-    const int subs = kThreads / sinusoids > 0 ? kThreads / sinusoids : 1;
-    hipLaunchKernelGGL(synth_envelopes_backward_kernel, dim3((unsigned)(batch * frames)), dim3(kThreads),
-                       2 * sizeof(double) * (size_t)subs * sinusoids, st, e);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
+    if (a.part_freq != nullptr && a.nseg > 1) {
+        const unsigned sgrid = (unsigned)((batch * sinusoids + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.dcarry, batch, a.nseg, sinusoids, 1);
+    }
+    hipLaunchKernelGGL(synth_frames_reduce_kernel, dim3((unsigned)(batch * frames)), dim3(64), sizeof(double) * (size_t)sinusoids, st, a,
+                       grad_amp_frames, grad_freq_frames);
     return launched() ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

@@ -275,10 +275,11 @@ int sot_synth_envelopes_backward(const float *amp_frames, const float *freq_fram
  * without the sample-rate envelopes ever existing in memory: the oscillator-bank kernels evaluate them from the controls (the
  * same float32 operations as sot_synth_envelopes_forward, so the audio equals sot_oscillator_bank_forward on those envelopes bit
  * for bit).  The backward returns the gradients w.r.t. the controls (either may be NULL; grad_freq_frames [batch, frames, 1]
- * when harmonic); workspace: sot_synth_workspace_bytes(batch, samples, sinusoids, backward) bytes (0 for invalid sizes) -- the
- * backward's holds the two sample-rate gradient arrays between its kernels; workspace_from_forward != 0: the first bytes still
- * hold what sot_synth_forward left there for the SAME controls.  Deterministic. */
-size_t sot_synth_workspace_bytes(int64_t batch, int64_t samples, int sinusoids, int backward);
+ * when harmonic) without sample-rate gradient arrays either: the tile kernel reduces its samples to per-frame partial sums (the
+ * frequency gradient through cumulative tap weights, see csrc/sot_osc.hip), a last kernel adds the segments up.
+ * workspace: sot_synth_workspace_bytes(batch, frames, samples, sinusoids, backward) bytes (0 for invalid sizes);
+ * workspace_from_forward != 0: its first bytes still hold what sot_synth_forward left there for the SAME controls.  Deterministic. */
+size_t sot_synth_workspace_bytes(int64_t batch, int frames, int64_t samples, int sinusoids, int backward);
 int sot_synth_forward(const float *amp_frames, const float *freq_frames, const float *window, int64_t batch, int frames, int sinusoids,
                       int harmonic, int64_t samples, float sample_rate, float *audio, void *workspace, size_t workspace_bytes,
                       void *stream);

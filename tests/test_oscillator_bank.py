@@ -243,8 +243,8 @@ def test_hip_envelopes_forward_and_backward_against_torch(batch, frames, k, samp
 @pytest.mark.parametrize("batch,frames,k,samples,harmonic", [(3, 16, 8, 4096, True), (2, 7, 5, 7 * 33, False), (2, 250, 60, 1000, True), (1, 4, 300, 64, False),
                                                               (5, 64, 8, 64 * 250, True), (1, 1, 1, 2, False), (256, 16, 8, 4096, True)])
 def test_hip_synth_in_one_piece_equals_envelopes_then_bank(batch, frames, k, samples, harmonic):
-    """sot_synth_forward / _backward (no envelope arrays) against the two-step HIP path: identical audio and gradients, bit for bit
-    (same float32 envelope values, same kernels after them)."""
+    """sot_synth_forward / _backward (no sample-rate arrays) against the two-step HIP path: identical audio, bit for bit (same float32
+    envelope values, same kernel after them); gradients to 2e-6 of their largest entry."""
     from sot_amd import _native as nat, spectra
     g = torch.Generator().manual_seed(batch * 77 + frames + k)
     dev = torch.device("cuda:0")
@@ -258,15 +258,22 @@ def test_hip_synth_in_one_piece_equals_envelopes_then_bank(batch, frames, k, sam
     grad_audio = torch.randn(batch, samples, generator=g).to(dev)
     gf_env, ga_env = nat.oscillator_bank_backward(f_env, a_env, 16000.0, grad_audio)
     wa, wf = nat.synth_envelopes_backward(amp, freq, hann, samples, 16000.0, harmonic, ga_env, gf_env)
+    def close(got, want, tol):   # the one-piece backward adds the same terms up in another order (fp64 accumulators either way)
+        return float((got - want).abs().max()) <= tol * max(1e-30, float(want.abs().max()))
+    first = None
     for reuse in (ws, None):
         ga, gf = nat.synth_backward(amp, freq, hann, samples, 16000.0, harmonic, grad_audio, forward_workspace=reuse)
-        assert torch.equal(ga, wa) and torch.equal(gf, wf)
+        assert close(ga, wa, 2e-6) and close(gf, wf, 2e-6), (float((ga - wa).abs().max()), float((gf - wf).abs().max()), float(wf.abs().max()))
+        first = first or (ga, gf)
+        assert torch.equal(ga, first[0]) and torch.equal(gf, first[1])        # deterministic
     ga, none = nat.synth_backward(amp, freq, hann, samples, 16000.0, harmonic, grad_audio, need_freq=False)
-    assert none is None and torch.equal(ga, wa)
+    assert none is None and torch.equal(ga, first[0])
+    none, gf = nat.synth_backward(amp, freq, hann, samples, 16000.0, harmonic, grad_audio, need_amp=False)
+    assert none is None and torch.equal(gf, first[1])
     # the module function takes this path, with and without gradients
     assert spectra.FUSED_SYNTH
     a1, f1 = amp.clone().requires_grad_(True), freq.clone().requires_grad_(True)
     out = spectra.sinusoidal_synth(a1, f1, samples, 16000, harmonic=harmonic)
     assert torch.equal(out.detach(), want) and torch.equal(spectra.sinusoidal_synth(amp, freq, samples, 16000, harmonic=harmonic), want)
     (out * grad_audio).sum().backward()
-    assert torch.equal(a1.grad, wa) and torch.equal(f1.grad, wf)
+    assert torch.equal(a1.grad, first[0]) and torch.equal(f1.grad, first[1])
