@@ -232,6 +232,32 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     # bytes the slice must move: both clips' audio in, the estimate's audio gradient out (spectra stay on chip in the ideal)
     out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<128, 9, 2, ..., 1025, false> + stft backward",
                                                3 * 256 * 4096 * 4, steps_per_s=1e3 / ms5, rows=4096, bins=1025)
+
+    # (5) the synthesiser in front of it: 256 clips x 16 frames x 8 partials of frame-rate controls -> 4096
+    #     samples (sot_synth_forward / _backward: no sample-rate array in HBM), alone and with the config-5 slice behind it
+    amp_frames = torch.rand(256, 16, 8, device=dev, generator=gen).requires_grad_(True)
+    f0_frames = (40 + 1900 * torch.rand(256, 16, 1, device=dev, generator=gen)).requires_grad_(True)
+    ctl_bytes = 4 * (256 * 16 * 9) * 2 + 4 * 256 * 4096 * 2      # controls in, their gradients out, audio out and its gradient in
+    with torch.no_grad():
+        ms_sf = timed(lambda i: spectra.sinusoidal_synth(amp_frames, f0_frames, 4096, 16000, harmonic=True), n)
+    out["synth_forward_256clips"] = entry(ms_sf, "oscillator_tile_kernel<0, true> + scan + oscillator_tile_kernel<1, true>", 4 * 256 * (16 * 9 + 4096))
+    grad_audio = torch.randn(256, 4096, device=dev, generator=gen)
+
+    def synth_step(i):
+        amp_frames.grad = f0_frames.grad = None
+        spectra.sinusoidal_synth(amp_frames, f0_frames, 4096, 16000, harmonic=True).backward(grad_audio)
+
+    ms_sb = timed(synth_step, n)
+    out["synth_forward_backward_256clips"] = entry(ms_sb, "synth forward + tap tables + oscillator_tile_kernel<3, true> + scan + frames reduce", ctl_bytes)
+
+    def synth_train_step(i):
+        amp_frames.grad = f0_frames.grad = None
+        audio = spectra.sinusoidal_synth(amp_frames, f0_frames, 4096, 16000, harmonic=True)
+        spectra.training_step_slice(mod5, target, audio).backward()
+
+    ms_st = timed(synth_train_step, n)
+    out["config5_train_step_with_synth_256clips"] = entry(ms_st, "synth + stft pair + sot training form + stft backward + synth backward", ctl_bytes,
+                                                          steps_per_s=1e3 / ms_st)
     return out
 
 
