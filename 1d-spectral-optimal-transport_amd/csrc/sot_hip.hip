@@ -1008,6 +1008,21 @@ struct GridCache {
     struct Entry { size_t lds; int grid; bool attr; } e[kMaxDevices] = {};
 };
 
+// Grid of a persistent kernel whose workgroups stride over `want` row groups, at most `cap` of them resident.  SOT_BALANCED_GRID = 1
+// gives every workgroup the same number of row groups (ceil(want / rounds) workgroups) instead of `cap` workgroups of which some run
+// one round more.  Measured (8192 x 2048): merge-free and merge forward unchanged (30.0 / 45.4 us), training form 86.2 instead of
+// 81.5 us (745 instead of 768 workgroups leave some CUs with two resident workgroups instead of three for the whole launch): off.
+#ifndef SOT_BALANCED_GRID
+#define SOT_BALANCED_GRID 0
+#endif
+static inline int balanced_grid(int64_t want, int cap)
+{
+    if (want <= cap) return (int)want;
+    if (!SOT_BALANCED_GRID) return cap;
+    const int64_t rounds = (want + cap - 1) / cap;
+    return (int)((want + rounds - 1) / rounds);
+}
+
 template <typename Kernel>
 static inline int cached_resident_grid(GridCache& gc, Kernel kern, int block, size_t lds)
 {
@@ -1145,7 +1160,7 @@ static hipError_t launch_forward(const FwdArgs& a, size_t lds, int64_t want, int
     lds += extra_lds;
     static GridCache cache;  // per instantiation (function-local static: thread-safe initialisation)
     const int grid_cap = cached_resident_grid(cache, kern, block, lds);
-    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    const int grid = balanced_grid(want, grid_cap);
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
     return hipGetLastError();
@@ -1243,7 +1258,7 @@ static hipError_t launch_backward(const BwdArgs& b, size_t lds, int64_t want, in
     auto kern = sot_backward_kernel<G, CPT, ROWPOS, PM, LIM, VEC>;
     static GridCache cache;  // per instantiation (function-local static: thread-safe initialisation)
     const int grid_cap = cached_resident_grid(cache, kern, block, lds);
-    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    const int grid = balanced_grid(want, grid_cap);
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
     return hipGetLastError();
@@ -1536,7 +1551,7 @@ static hipError_t launch_forward_csr(const FwdArgs& a, size_t lds, int64_t want,
     auto kern = sot_forward_kernel<G, CPT, true, false, PM, LIM, false, true>;
     static GridCache cache;  // per instantiation (function-local static: thread-safe initialisation)
     const int grid_cap = cached_resident_grid(cache, kern, block, lds);
-    const int grid = (int)(want < grid_cap ? want : grid_cap);
+    const int grid = balanced_grid(want, grid_cap);
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
     return hipGetLastError();

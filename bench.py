@@ -72,7 +72,7 @@ FULL_ROW_GEOMETRY = {512: (64, 8, 4, 0), 1024: (128, 8, 2, 0), 2048: (256, 8, 1,
 
 
 def forward_kernel_name(n, mode, backward=False, same_grid=True):
-    """Name of the dominant kernel as rocprofv3 lists it (template arguments G, CPT, ROWS, PM, LIM, SQ, NX[, WANT_X])."""
+    """Name of the dominant kernel as rocprofv3 lists it (template arguments G, CPT, ROWS, PM, LIM, SQ, NX[, WANT_X, SLIM])."""
     c = MODES[mode]
     pm, lim, sq = int(c.get("p", 1)), bool(c.get("limit_quantile_range", False)), bool(c.get("square_dist", False))
     geo = FULL_ROW_GEOMETRY.get(n)
@@ -82,8 +82,10 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True):
     g, cpt, rows, nx = geo
     if pm == 1 and not lim and not backward and same_grid:   # p = 1 on one grid: the merge-free kernel (sot_area_full_kernel)
         return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, {nx}>"
-    if backward:
-        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false>"
+    if backward:   # the y-only (training) kernels; 2048-bin rows run two per workgroup in the layout without U gradient slots
+        if n == 2048:
+            return f"sot_backward_full_kernel<{g}, {cpt}, 2, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true>"
+        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false>"
     return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
 
 
@@ -230,7 +232,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
 
     ms5 = timed(train_step, n)
     # bytes the slice must move: both clips' audio in, the estimate's audio gradient out (spectra stay on chip in the ideal)
-    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<128, 9, 2, ..., 1025, false> + stft backward",
+    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<128, 9, 2, ..., 1025, false, false> + stft backward",
                                                3 * 256 * 4096 * 4, steps_per_s=1e3 / ms5, rows=4096, bins=1025)
 
     # (5) the synthesiser in front of it: 256 clips x 16 frames x 8 partials of frame-rate controls -> 4096
