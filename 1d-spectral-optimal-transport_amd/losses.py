@@ -214,15 +214,54 @@ def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, requ
     return rows if out_dtype is None else rows.to(out_dtype)
 
 
+def _csr_to_padded(weights, positions, offsets, width):
+    """CSR entries -> [rows, width] weights (zeros behind each row's entries: zero-weight points are inert) and positions (the
+    row's last position repeated), plus the mask of real entries (row-major = CSR order)."""
+    starts, ends = offsets[:-1, None], offsets[1:, None]
+    idx = starts + torch.arange(width, device=offsets.device)[None, :]
+    valid = idx < ends
+    idx = torch.minimum(idx, (ends - 1).clamp_min(0)).clamp_(0, max(weights.numel() - 1, 0))
+    return torch.where(valid, weights[idx], torch.zeros((), device=weights.device)), positions[idx], valid
+
+
+class _CsrRowLoss(torch.autograd.Function):
+    """Row losses of the CSR form (sot_w1d_forward_csr).  Backward: the rows are padded with zero-weight points to
+    [rows, max_n] / [rows, max_m] with per-row positions and go through the dense backward kernel (the same function of the kept
+    weights, hence the same gradient); the gradients of the kept points are gathered back into CSR order."""
+
+    @staticmethod
+    def forward(ctx, xw, xp, xoff, yw, yp, yoff, max_n, max_m, p, flags):
+        rows = nat.forward_rows_csr(xw, xp, xoff, yw, yp, yoff, max_n, max_m, p, flags)
+        ctx.save_for_backward(xw, xp, xoff, yw, yp, yoff)
+        ctx.cfg = (max_n, max_m, p, flags)
+        return rows
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        xw, xp, xoff, yw, yp, yoff = ctx.saved_tensors
+        max_n, max_m, p, flags = ctx.cfg
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[4]:
+            raise NotImplementedError("gradients w.r.t. support positions are not implemented (no reference call site uses them)")
+        xd, xpd, xvalid = _csr_to_padded(xw, xp, xoff, max_n)
+        yd, ypd, yvalid = _csr_to_padded(yw, yp, yoff, max_m)
+        gx, gy = nat.backward_rows(xd, yd, xpd.contiguous(), ypd.contiguous(), p, flags, grad_rows.float(),
+                                   need_gx=ctx.needs_input_grad[0], need_gy=ctx.needs_input_grad[3])
+        return (gx[xvalid] if gx is not None else None, None, None, gy[yvalid] if gy is not None else None, None, None,
+                None, None, None, None)
+
+
 def wasserstein_1d_csr(x_weights, x_positions, x_offsets, y_weights, y_positions, y_offsets, max_n, max_m, p=1,
                        square_dist=False, dont_normalize=False, limit_quantile_range=False, require_sort=True,
                        prenormalized=False):
     """Per-row SOT loss for RAGGED supports in CSR form (no reference counterpart: the reference is fed zero-masked
     dense rows, which give the same value because zero-weight points are inert -- BASELINE config 4).
     Row r owns entries [offsets[r], offsets[r+1]); normalisation etc. follow Wasserstein1D's keyword arguments.
-    Returns the [rows] tensor of W_p^p (forward only)."""
+    Returns the [rows] tensor of W_p^p; differentiable w.r.t. the weights (see _CsrRowLoss)."""
     assert p >= 1, f"The OT loss is only valid for p>=1, {p} was given"
     flags = _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized)
+    if torch.is_grad_enabled() and (x_weights.requires_grad or y_weights.requires_grad):
+        return _CsrRowLoss.apply(x_weights, x_positions, x_offsets, y_weights, y_positions, y_offsets, int(max_n), int(max_m),
+                                 float(p), flags)
     return nat.forward_rows_csr(x_weights, x_positions, x_offsets, y_weights, y_positions, y_offsets, max_n, max_m,
                                 float(p), flags)
 

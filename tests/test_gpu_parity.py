@@ -1011,3 +1011,55 @@ def test_p1_same_grid_dispatch_conditions():
     w = float(np.mean(so.forward(x.numpy(), y.numpy(), np.linspace(0, 1, N, dtype=np.float32), np.linspace(0, 1, N, dtype=np.float32), p=1.0,
                                  flags=8).astype(np.float64)))
     assert abs(m - w) <= 1e-5 * abs(w)
+
+
+@pytest.mark.parametrize("mode", ["p1", "nocut", "cutoff"])
+def test_csr_backward_matches_oracle_on_the_ragged_rows(mode):
+    """Gradients of the CSR form w.r.t. the kept weights (missing #5): against the oracle's backward evaluated on
+    the truly ragged rows, and -- where no knife edge interferes -- against the masked-dense module's gradient at the kept points."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import gen_inputs
+    from oracle.make_golden import MODES
+    from sot_amd.losses import wasserstein_1d_csr
+    native()
+    dev = device()
+    B, N = 96, 257
+    x, y = gen_inputs("peaky", B, N, N, 77)
+    g = torch.Generator().manual_seed(77)
+    tau = 10 ** (-3 + 2.7 * torch.rand(B, 1, generator=g))
+    kx, ky = x >= tau * x.amax(1, keepdim=True), y >= tau * y.amax(1, keepdim=True)
+    pos = torch.linspace(0, 1, N)
+    ctor = MODES[mode]
+    p, flags = ctor_to_flags(ctor)
+    xw, xp, xo = _to_csr(x, pos, kx)
+    yw, yp, yo = _to_csr(y, pos, ky)
+    max_n, max_m = int(kx.sum(1).max()), int(ky.sum(1).max())
+    kw = dict(p=ctor.get("p", 1), square_dist=ctor.get("square_dist", False), dont_normalize=ctor.get("dont_normalize", False),
+              limit_quantile_range=ctor.get("limit_quantile_range", False))
+    xwd, ywd = xw.to(dev).requires_grad_(True), yw.to(dev).requires_grad_(True)
+    upstream = torch.rand(B, generator=g)
+    rows = wasserstein_1d_csr(xwd, xp.to(dev), xo.to(dev), ywd, yp.to(dev), yo.to(dev), max_n, max_m, **kw)
+    (rows * upstream.to(dev)).sum().backward()
+    gx, gy = xwd.grad.cpu().numpy(), ywd.grad.cpu().numpy()
+    assert gx.shape == (int(xo[-1]),) and gy.shape == (int(yo[-1]),) and np.isfinite(gx).all() and np.isfinite(gy).all()
+    checked = 0
+    for r in range(0, B, 6):
+        xr, yr = x[r][kx[r]][None].numpy(), y[r][ky[r]][None].numpy()
+        wx, wy = so.backward(xr, yr, pos[kx[r]].numpy(), pos[ky[r]].numpy(), upstream[r:r + 1].numpy(), p=p, flags=flags)
+        a, b = gx[int(xo[r]):int(xo[r + 1])], gy[int(yo[r]):int(yo[r + 1])]
+        scale = max(np.abs(wx).max(), np.abs(wy).max(), 1e-30)
+        if ctor.get("limit_quantile_range", False):
+            # the padded rows' mass is summed over other operands than the ragged rows' (torch.sum order): rows on the cutoff's
+            # knife edge may differ (SURVEY B.1); the bulk must agree
+            checked += int(np.abs(a - wx[0]).max() <= 2e-4 * scale and np.abs(b - wy[0]).max() <= 2e-4 * scale)
+        else:
+            assert np.abs(a - wx[0]).max() <= 2e-5 * scale and np.abs(b - wy[0]).max() <= 2e-5 * scale, r
+            checked += 1
+    assert checked >= 10
+    # only one side needs a gradient; none at all -> the plain forward
+    yw2 = yw.to(dev).requires_grad_(True)
+    wasserstein_1d_csr(xw.to(dev), xp.to(dev), xo.to(dev), yw2, yp.to(dev), yo.to(dev), max_n, max_m, **kw).sum().backward()
+    assert yw2.grad.shape == yw.shape
+    with torch.no_grad():
+        again = wasserstein_1d_csr(xw.to(dev), xp.to(dev), xo.to(dev), yw2, yp.to(dev), yo.to(dev), max_n, max_m, **kw)
+    assert torch.equal(again, rows.detach())
