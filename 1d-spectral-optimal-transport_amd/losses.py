@@ -58,6 +58,38 @@ def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, pren
             | (FLAG_PRENORMALIZED if prenormalized else 0))
 
 
+def _position_grads(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, need_y):
+    """d sum_r grad_rows[r] * loss_r / d positions (losses.py:287-313: the positions enter through torch.sort and
+    take_along_dim, both differentiable).  No reference call site asks for it, so there is no kernel of its own:
+    the quantile kernel (sot_w1d_quantiles) supplies the merged levels and both inverse CDFs, and
+        d loss / d xs[i] = sum over the merged levels k whose x-rank is i of  delta_k * p |uq_k - vq_k|^(p-1) sign(uq_k - vq_k)
+    (minus that for ys) is scattered with torch ops (atomic adds: the one gradient of this package whose last bits may vary)."""
+    uq, vq, levels, cdf_x, cdf_y = nat.quantiles(x, y, xpos, ypos, p, flags, plan)
+    rows, n = x.shape
+    m = y.shape[1]
+    delta = torch.diff(levels, dim=1, prepend=torch.zeros(rows, 1, device=x.device))
+    if flags & nat.FLAG_LIMIT_Q:
+        delta = torch.where(levels > 1, torch.zeros_like(delta), delta)
+    d = uq - vq
+    slope = torch.sign(d) if p == 1 else p * d.abs().pow(p - 1) * torch.sign(d)
+    w = delta * slope * grad_rows.reshape(-1, 1)
+    out = []
+    for need, pos, cdf, width, sgn in ((need_x, xpos, cdf_x, n, 1.0), (need_y, ypos, cdf_y, m, -1.0)):
+        if not need:
+            out.append(None)
+            continue
+        rank = torch.searchsorted(cdf, levels).clamp_(max=width - 1)          # quantile_function, losses.py:214-220
+        g_sorted = torch.zeros(rows, width, device=x.device).scatter_add_(1, rank, sgn * w)
+        pos2 = pos if pos.ndim == 2 else pos.unsqueeze(0)
+        if flags & nat.FLAG_REQUIRE_SORT:                                       # back through torch.sort (losses.py:286-288)
+            order = torch.sort(pos2, dim=1)[1].expand(rows, width)
+            g = torch.zeros_like(g_sorted).scatter_(1, order, g_sorted)
+        else:
+            g = g_sorted
+        out.append(g.sum(0) if pos.ndim == 1 else g)
+    return out
+
+
 class _RowLoss(torch.autograd.Function):
     """rows[B] = W_p^p per spectrum pair; backward = closed-form HIP kernel."""
 
@@ -71,12 +103,14 @@ class _RowLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_rows):
         x, y, xpos, ypos = ctx.saved_tensors
+        gx = gy = gxp = gyp = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, grad_rows.float(),
+                                       need_gx=ctx.needs_input_grad[0], need_gy=ctx.needs_input_grad[1], plan=ctx.plan)
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            raise NotImplementedError("gradients w.r.t. support positions are not implemented "
-                                      "(no reference call site uses them)")
-        gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, grad_rows.float(),
-                                   need_gx=ctx.needs_input_grad[0], need_gy=ctx.needs_input_grad[1], plan=ctx.plan)
-        return gx, gy, None, None, None, None, None
+            gxp, gyp = _position_grads(x, y, xpos, ypos, ctx.p, ctx.flags, ctx.plan, grad_rows.float(), ctx.needs_input_grad[2],
+                                       ctx.needs_input_grad[3])
+        return gx, gy, gxp, gyp, None, None, None
 
 
 EARLY_GRADIENT = True   # module switch for the loss-and-gradient form below (tests compare both forms)
@@ -104,15 +138,18 @@ class _FusedMeanLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, y, xpos, ypos = ctx.saved_tensors
+        gxp = gyp = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            raise NotImplementedError("gradients w.r.t. support positions are not implemented "
-                                      "(no reference call site uses them)")
+            gxp, gyp = _position_grads(x, y, xpos, ypos, ctx.p, ctx.flags, ctx.plan, (g.float() / x.shape[0]).expand(x.shape[0]),
+                                       ctx.needs_input_grad[2], ctx.needs_input_grad[3])
         if ctx.early_gy is not None:   # consumed once: a second backward through a retained graph recomputes below
             gy, ctx.early_gy = ctx.early_gy, None
-            return None, nat.scale_inplace(gy, g.float().contiguous()), None, None, None, None, None
-        gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, g.float(), need_gx=ctx.needs_input_grad[0],
-                                   need_gy=ctx.needs_input_grad[1], plan=ctx.plan, grad_scale=1.0 / x.shape[0])
-        return gx, gy, None, None, None, None, None
+            return None, nat.scale_inplace(gy, g.float().contiguous()), gxp, gyp, None, None, None
+        gx = gy = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, g.float(), need_gx=ctx.needs_input_grad[0],
+                                       need_gy=ctx.needs_input_grad[1], plan=ctx.plan, grad_scale=1.0 / x.shape[0])
+        return gx, gy, gxp, gyp, None, None, None
 
 
 class _RowMean(torch.autograd.Function):
@@ -317,7 +354,7 @@ class Wasserstein1D(torch.nn.Module):
         """Flat [rows] tensor of W_p^p per spectrum pair (after the optional hinge, before the mean):
         what losses.py:186-205 holds before its reshape/mean.  Used by the row-sharded multi-GPU path."""
         x, y, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
-        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (x, y, x_pos_, y_pos_)):
             loss = _RowLoss.apply(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
         else:
             loss = nat.forward_rows(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
@@ -343,7 +380,7 @@ class Wasserstein1D(torch.nn.Module):
         if dims is None and not self.hinge:
             # default reduction: forward and the mean over every row (losses.py:211) in one native call
             x2, y2, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
-            if torch.is_grad_enabled() and (x2.requires_grad or y2.requires_grad):
+            if torch.is_grad_enabled() and any(t.requires_grad for t in (x2, y2, x_pos_, y_pos_)):
                 return _FusedMeanLoss.apply(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
             return nat.loss_fused(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)[0]
         loss = self.row_losses(x, y, x_pos, y_pos, **kwargs)

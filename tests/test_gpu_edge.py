@@ -69,12 +69,11 @@ def test_module_plumbing():
     # empty batch: mean of zero rows is NaN in the reference too (torch.mean of an empty tensor)
     e = m(x[:0][:, None, :], y[:0][:, None, :], dims=[1])
     assert e.shape == (0,)
-    # requires_grad on positions is rejected loudly at backward time
+    # positions that require a gradient get one (test_position_gradients_match_the_reference_autograd)
     xp = torch.linspace(0, 1, 64, device=dev, requires_grad=True)
     yy = y.clone().requires_grad_(True)
-    loss = Wasserstein1D(p=1).to(dev)(x, yy, x_pos=xp, y_pos=xp.detach().clone())
-    with pytest.raises(NotImplementedError):
-        loss.backward()
+    Wasserstein1D(p=1).to(dev)(x, yy, x_pos=xp, y_pos=xp.detach().clone()).backward()
+    assert xp.grad is not None and xp.grad.shape == (64,) and yy.grad is not None
     # half precision is refused rather than silently upcast
     with pytest.raises(TypeError):
         m(x.half(), y.half())
@@ -125,3 +124,49 @@ def test_float64_inputs_are_accepted_like_the_reference():
     assert float(out) == float(ref) and torch.equal(y.grad.float(), y32.grad)
     rows = wasserstein_1d(pos.expand(9, 300), pos.expand(9, 300), x / x.sum(1, keepdim=True), y.detach() / y.detach().sum(1, keepdim=True))
     assert rows.dtype == torch.float64 and rows.shape == (9,)
+
+
+@pytest.mark.parametrize("case", ["shared_sorted_p1", "shared_unsorted_p2_cutoff", "rows_unsorted_p2", "rows_p3_nm", "positions_only_mean"])
+def test_position_gradients_match_the_reference_autograd(case):
+    """Gradients w.r.t. the support positions (losses.py:287-313 is differentiable in u_values / v_values through torch.sort and
+    take_along_dim; VERDICT round 1, missing #6) against autograd of the op-for-op restatement of the reference on the CPU."""
+    from gpu_util import device, native
+    from oracle import torch_restatement as tr
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    g = torch.Generator().manual_seed(300 + len(case))   # a fixed seed per case
+    B, n, m = 12, 67, 67
+    kw, shared, unsorted = dict(p=1), True, False
+    if case == "shared_unsorted_p2_cutoff":
+        kw, unsorted = dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True), True
+    elif case == "rows_unsorted_p2":
+        kw, shared, unsorted = dict(p=2), False, True
+    elif case == "rows_p3_nm":
+        kw, shared, m = dict(p=3), False, 41
+    x, y = torch.rand(B, n, generator=g) + 0.05, torch.rand(B, m, generator=g) + 0.05
+    def positions(width):
+        pos = torch.rand(B if not shared else 1, width, generator=g)
+        pos = pos if unsorted else torch.sort(pos, dim=1)[0]
+        return pos[0].clone() if shared else pos
+    xp, yp = positions(n), positions(m)
+    up = torch.rand(B, generator=g)
+    ctor = {k: v for k, v in kw.items() if k != "p"}
+    # reference (restatement) on the CPU
+    xr, yr, xpr, ypr = (t.clone().requires_grad_(True) for t in (x, y, xp, yp))
+    if case == "positions_only_mean":
+        tr.sot_loss(x, y, xpr, ypr, **kw).backward()
+    else:
+        (tr.sot_loss(xr, yr, xpr, ypr, reduce=False, **kw) * up).sum().backward()
+    # HIP path
+    xd, yd, xpd, ypd = (t.to(dev).requires_grad_(True) for t in (x, y, xp, yp))
+    mod = Wasserstein1D(p=kw["p"], **ctor).to(dev)
+    if case == "positions_only_mean":      # only the positions need a gradient, default reduction (the fused-mean node)
+        mod(x.to(dev), y.to(dev), x_pos=xpd, y_pos=ypd).backward()
+    else:
+        (mod.row_losses(xd, yd, xpd, ypd) * up.to(dev)).sum().backward()
+        for got, want in ((xd.grad, xr.grad), (yd.grad, yr.grad)):
+            assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    for got, want in ((xpd.grad, xpr.grad), (ypd.grad, ypr.grad)):
+        assert got.shape == want.shape
+        assert float((got.cpu() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-6), case
