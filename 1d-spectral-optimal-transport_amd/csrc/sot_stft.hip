@@ -32,6 +32,13 @@ constexpr int kMaxFft = 2048;
 
 #include "sot_stft_tables.inc"      // kPassTw, kWn (csrc/gen/make_stft_tables.py)
 
+#ifndef SOT_STFT_RAW_SQRT
+#define SOT_STFT_RAW_SQRT 0   /* 1: v_sqrt_f32 alone -- 14 % fewer VALU instructions, the same 24.7 us, and past the 2e-6 pin against float64 */
+#endif
+#ifndef SOT_STFT_PERSISTENT_WAVES
+#define SOT_STFT_PERSISTENT_WAVES 6   /* waves per SIMD the persistent forward kernel is compiled for: 6 = 76 VGPRs, no spills; 8 =
+                                         64 VGPRs with 10 spilled, measured slower (26.4 vs 21.9 us) */
+#endif
 #ifndef SOT_STFT_WAVE_FRAMES
 #define SOT_STFT_WAVE_FRAMES 1
 #endif
@@ -159,16 +166,17 @@ __device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, 
     using G = Geo<LOGM>;
     const float2* win = reinterpret_cast<const float2*>(a.window);   // 8-byte aligned (checked by the host)
     const bool inside = active && t0 + G::n <= a.samples;            // the whole frame lies inside the clip
+    const float* const s0 = src + t0;                                // frame start: 32-bit offsets from here on
+    const int left = (int)min((int64_t)G::n, a.samples - t0);        // samples of the frame that exist
 #pragma unroll
     for (int i = lid; i < G::m; i += G::tpf) {
-        const int64_t t = t0 + 2 * i;
         const float2 w = win[i];
         float v0, v1;
         if (inside) {
-            v0 = src[t] * w.x; v1 = src[t + 1] * w.y;
+            v0 = s0[2 * i] * w.x; v1 = s0[2 * i + 1] * w.y;
         } else {                                                      // end padding: zeros (utils.py:252-275)
-            v0 = (active && t < a.samples) ? src[t] * w.x : 0.0f;
-            v1 = (active && t + 1 < a.samples) ? src[t + 1] * w.y : 0.0f;
+            v0 = (active && 2 * i < left) ? s0[2 * i] * w.x : 0.0f;
+            v1 = (active && 2 * i + 1 < left) ? s0[2 * i + 1] * w.y : 0.0f;
         }
         z[zi(bitrev(i, LOGM))] = (v2f){v0, v1};
     }
@@ -181,7 +189,11 @@ __device__ __forceinline__ float magnitude(v2f x)
     const float s = fmaf(x.x, x.x, x.y * x.y);
     const bool plain = (s > 1e-30f && s < 1e30f) || (x.x == 0.0f && x.y == 0.0f);
     if (__builtin_expect(__ballot(!plain) != 0ull, 0)) return hypotf(x.x, x.y);
+#if SOT_STFT_RAW_SQRT
+    return __builtin_amdgcn_sqrtf(s);   // v_sqrt_f32 (1 ulp) without the range scaling and the two refinement steps of sqrtf: s is normal here
+#else
     return sqrtf(s);
+#endif
 }
 
 // spectrum bins k and m-k of the real frame from the packed transform (see Geo)
@@ -193,6 +205,19 @@ __device__ __forceinline__ void unpack_pair(const v2f* z, const v2f* wn, int k, 
     const v2f ze = 0.5f * (zk + cconj(zm));
     const v2f zo = 0.5f * mul_mi(zk - cconj(zm));          // -i/2 (Z_k - conj(Z_{m-k}))
     const v2f wz = cmul(wn[k], zo);
+    xk = ze + wz;
+    xm = cconj(ze - wz);
+}
+
+// the same with the bin's twiddle W_n^k passed by value
+template <int LOGM>
+__device__ __forceinline__ void unpack_pair_w(const v2f* z, v2f w, int k, v2f& xk, v2f& xm)
+{
+    constexpr int m = 1 << LOGM;
+    const v2f zk = z[zi(k)], zm = z[zi((m - k) & (m - 1))];
+    const v2f ze = 0.5f * (zk + cconj(zm));
+    const v2f zo = 0.5f * mul_mi(zk - cconj(zm));
+    const v2f wz = cmul(w, zo);
     xk = ze + wz;
     xm = cconj(ze - wz);
 }
@@ -231,6 +256,83 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same transform with PERSISTENT workgroups (SOT_STFT_PERSISTENT): a workgroup loads the twiddle tables and its threads' window
+// taps once, then walks over frame groups g = blockIdx.x, blockIdx.x + gridDim.x, ...; the audio of the NEXT frame is fetched into
+// registers before the passes of the current one start, so its latency (and the tables') is paid once per workgroup instead of once
+// per frame.  Results are identical to stft_mag_forward_kernel's (the same operations on the same values).
+// (LDS: z [slots][zi(m)] | pass twiddles [m]; the unpacking twiddles W_n^k of a thread's bins sit in registers: 16.6 KB at n_fft 2048,
+// eight workgroups per CU, which the 64-VGPR budget of amdgpu_waves_per_eu(8) matches.)
+template <int LOGM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SOT_STFT_PERSISTENT_WAVES, 8))) void stft_mag_forward_persistent_kernel(const StftArgs a)
+{
+    using G = Geo<LOGM>;
+    constexpr int PER = G::m / G::tpf;                       // packed points per thread and frame
+    constexpr int PERK = (G::m / 2 + G::tpf) / G::tpf;       // bin pairs (k, m - k), k <= m/2, per thread and frame
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int slot = threadIdx.x / G::tpf, lid = threadIdx.x - slot * G::tpf;
+    v2f* const zall = reinterpret_cast<v2f*>(smem_f);
+    v2f* const z = zall + slot * G::zpoints;
+    v2f* const tw = zall + G::slots * G::zpoints;
+    v2f wnr[PERK];
+#pragma unroll
+    for (int j = 0; j < PERK; ++j) {
+        const int k = min(lid + j * G::tpf, G::m / 2);
+        const float2 t = kWn[k << (10 - LOGM)];
+        wnr[j] = (v2f){t.x, t.y};
+    }
+    const float scale = 1.0f / sqrtf((float)G::n);
+    const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;
+    const unsigned ngroups = (total + G::slots - 1) / G::slots;
+    const float2* win = reinterpret_cast<const float2*>(a.window);
+    float2 w[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) w[j] = win[lid + j * G::tpf];
+
+    float2 cur[PER];
+    auto fetch = [&](unsigned g) {   // raw samples 2i, 2i+1 of frame g*slots+slot for i = lid + j tpf; zeros outside the clip / for an idle slot
+        const unsigned fr = g * G::slots + slot;
+        const bool active = fr < total;
+        const unsigned b = active ? fr / frames : 0u, f = active ? fr - b * frames : 0u;
+        const float* src = (a.audio_b != nullptr && (int64_t)b >= a.split) ? a.audio_b + ((int64_t)b - a.split) * a.row_stride_b
+                                                                          : a.audio + (int64_t)b * a.row_stride;
+        const int64_t t0 = (int64_t)f * a.hop;
+        const float* const s0 = src + t0;
+        const int left = active ? (int)min((int64_t)G::n, a.samples - t0) : 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = lid + j * G::tpf;
+            cur[j].x = (2 * i < left) ? s0[2 * i] : 0.0f;
+            cur[j].y = (2 * i + 1 < left) ? s0[2 * i + 1] : 0.0f;
+        }
+    };
+    unsigned g = blockIdx.x;
+    if (g < ngroups) fetch(g);
+    for (int i = threadIdx.x; i < G::m - 2; i += kThreads) { const float2 t = kPassTw[i]; tw[i] = (v2f){t.x, t.y}; }   // load_tables() without W_n
+    if constexpr (G::wave_sync) __syncthreads();
+    for (; g < ngroups; g += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j)   // the products of load_frame(): sample * tap (zero * tap = 0 for the padding)
+            z[zi(bitrev(lid + j * G::tpf, LOGM))] = (v2f){cur[j].x * w[j].x, cur[j].y * w[j].y};
+        const unsigned fr = g * G::slots + slot;
+        if (g + gridDim.x < ngroups) fetch(g + gridDim.x);   // in flight during the passes below
+        fft_inplace<LOGM, false>(z, tw, lid);
+        if (fr < total) {
+            float* dst = a.mag + (int64_t)fr * G::nb;
+#pragma unroll
+            for (int j = 0; j < PERK; ++j) {
+                const int k = lid + j * G::tpf;
+                if (k <= G::m / 2) {
+                    v2f xk, xm;
+                    unpack_pair_w<LOGM>(z, wnr[j], k, xk, xm);
+                    dst[k] = magnitude(xk) * scale;
+                    dst[G::m - k] = magnitude(xm) * scale;
+                }
+            }
+        }
+        slot_sync<G::wave_sync>();   // the spectrum has been read before the next frame overwrites it
+    }
+}
+
 // n_fft = 2048, one WAVEFRONT per frame (SOT_STFT_WAVE_KERNEL): the 1024-point complex transform of the packed frame as five
 // radix-4 decimation-in-frequency stages on 16 points per lane.  With the index written in base 4, i = (d4 d3 d2 d1 d0), a lane
 // keeps two digits in its 16 registers and the other three are its lane number: stages 1-2 (digits d4, d3) on
@@ -609,6 +711,52 @@ static void launch_slots(void (*kernel)(const StftArgs), int64_t work, size_t ex
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, a);
 }
 
+#ifndef SOT_STFT_PERSISTENT
+#define SOT_STFT_PERSISTENT 1
+#endif
+static int cu_count()
+{
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (cus[dev] == 0) {   // idempotent per device
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 256; }
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+// the persistent forward kernel on as many workgroups as stay resident (LDS / 2048 threads per CU)
+template <int LOGM>
+static void launch_forward_persistent(int64_t work, hipStream_t st, const StftArgs& a)
+{
+    using G = Geo<LOGM>;
+    const size_t lds = ((size_t)G::slots * G::zpoints + G::m) * sizeof(float2);
+    static int per_cu_cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+    if (per_cu_cache[dev] == 0) {   // idempotent per device
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, stft_mag_forward_persistent_kernel<LOGM>, kThreads, lds) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 4;
+        }
+        per_cu_cache[dev] = n;
+    }
+    const int64_t groups = (work + G::slots - 1) / G::slots, cap = (int64_t)cu_count() * per_cu_cache[dev];
+    hipLaunchKernelGGL(stft_mag_forward_persistent_kernel<LOGM>, dim3((unsigned)(groups < cap ? groups : cap)), dim3(kThreads), lds, st, a);
+}
+
+// Measured (tools/ab_stft.py, 256 clips x 4096 samples): n_fft 2048 forward 25.2 -> 21.9 us, forward of a pair 42.4 -> 38.1 us; n_fft 512
+// 10.2 -> 10.8 / 16.7 -> 17.8 us -- the small transforms already share a workgroup's tables among 4-16 frame slots, so only n_fft 2048
+// (one frame per workgroup) takes the persistent form.
+static void launch_forward(int64_t work, hipStream_t st, const StftArgs& a)
+{
+    if (SOT_STFT_PERSISTENT && a.logm == 10) { launch_forward_persistent<10>(work, st, a); return; }
+    SOT_STFT_LAUNCH(stft_mag_forward_kernel, work, 0, st, a);
+}
+
 // OFF by default.  Measured (MI355X, 256 clips x 16 frames, tools/ab_stft.py): forward 24.2 us against 24.7 us for the slot
 // kernel, forward of a pair 52.5 against 42.3 us.  The kernel is correct (tests/test_stft_producer.py passes with it) and does
 // a frame in ~1000 instructions per lane without a workgroup barrier, but at 16-32 frames per CU there is no steady state to
@@ -657,7 +805,7 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
     a.mag = mag;
     (void)hipGetLastError();
     if (!launch_forward_wave(a, batch * a.frames, reinterpret_cast<hipStream_t>(stream)))
-        SOT_STFT_LAUNCH(stft_mag_forward_kernel, batch * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
+        launch_forward(batch * a.frames, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -675,7 +823,7 @@ int sot_stft_mag_forward_pair(const float* audio_a, int64_t row_stride_a, const 
     a.mag = mag;
     (void)hipGetLastError();
     if (!launch_forward_wave(a, 2 * batch_each * a.frames, reinterpret_cast<hipStream_t>(stream)))
-        SOT_STFT_LAUNCH(stft_mag_forward_kernel, 2 * batch_each * a.frames, 0, reinterpret_cast<hipStream_t>(stream), a);
+        launch_forward(2 * batch_each * a.frames, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
