@@ -66,7 +66,20 @@ __device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }   // a
 // LDS index of element i of a transform buffer: one point of padding after every 32.  The bit-reversed load (lane
 // stride m/2, m/4, ...) and the stride-4 accesses of the first pass would otherwise pile 32 lanes onto two banks
 // (SQ_LDS_BANK_CONFLICT 72 % -> 37 % of the LDS cycles of the forward kernel).
-__host__ __device__ constexpr int zi(int i) { return i + (i >> 5); }
+#ifndef SOT_STFT_PAD
+#define SOT_STFT_PAD 0   /* diagnostic: other paddings of the transform buffer.  tools/ab_stft.py, n_fft 2048 forward / backward:
+                            0 (one point per 32) 22.4 / 53.0 us; 1 (per 16) 23.3 / 54.2; 2 (per 32 and per 256) 22.6 / 54.0;
+                            3 (per 16 and per 256) 22.3 / 53.5; 4 (per 8) 23.6 / 54.8; 5 (none) 29.3 / 65.7 */
+#endif
+__host__ __device__ constexpr int zi(int i)
+{
+    return SOT_STFT_PAD == 0 ? i + (i >> 5)
+         : SOT_STFT_PAD == 1 ? i + (i >> 4)
+         : SOT_STFT_PAD == 2 ? i + (i >> 5) + (i >> 8)
+         : SOT_STFT_PAD == 3 ? i + (i >> 4) + (i >> 8)
+         : SOT_STFT_PAD == 4 ? i + (i >> 3)
+         : i;
+}
 
 // Frame geometry for n_fft = 2^(LOGM+1).  The frames are REAL, so each one is transformed by a complex FFT of HALF its
 // length m = n_fft/2 on the packed signal z[i] = v[2i] + i v[2i+1]:   with Ze = (Z_k + conj(Z_{m-k})) / 2,
@@ -86,7 +99,7 @@ struct Geo {
     static constexpr int tpf = (SOT_STFT_WAVE_FRAMES == 2 && tpf_full > 64) ? 64 : tpf_full;
     static constexpr bool wave_sync = (SOT_STFT_WAVE_FRAMES != 0) && tpf <= 64;
     static constexpr int slots = kThreads / tpf;
-    static constexpr int zpoints = zi(m);
+    static constexpr int zpoints = zi(m - 1) + 2;
     static constexpr int table_points = m + m / 2 + 2;
     static constexpr size_t lds_points = (size_t)slots * zpoints + table_points;
 };
