@@ -29,7 +29,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 3                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 4                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -82,7 +82,9 @@ EXPORTS = {
     "sot_synth_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                          _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_synth_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
-                                          _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
+                                          _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
+    "sot_synth_tap_table_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int64]),
+    "sot_synth_tap_tables": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
@@ -684,8 +686,19 @@ def synth_forward(amp_frames, freq_frames, window, n_samples: int, sample_rate: 
     return audio, ws
 
 
+def synth_tap_tables(window, frames: int, n_samples: int):
+    """The weight tables of sot_synth_backward for (window, frames, n_samples), to be kept by the caller (sot_synth_tap_tables)."""
+    require_hip(window)
+    lib = load()
+    window = window.contiguous()
+    tables = torch.empty(max(8, lib.sot_synth_tap_table_bytes(int(frames), int(n_samples))), dtype=torch.uint8, device=window.device)
+    with _on_device(window.device):
+        check(lib.sot_synth_tap_tables(window.data_ptr(), int(frames), int(n_samples), tables.data_ptr(), stream_ptr(window.device)))
+    return tables
+
+
 def synth_backward(amp_frames, freq_frames, window, n_samples, sample_rate, harmonic, grad_audio, need_amp=True, need_freq=True,
-                   forward_workspace=None):
+                   forward_workspace=None, tap_tables=None):
     require_hip(amp_frames, freq_frames, window, grad_audio)
     lib = load()
     amp_frames, freq_frames, window, grad_audio = amp_frames.contiguous(), freq_frames.contiguous(), window.contiguous(), grad_audio.contiguous()
@@ -698,6 +711,6 @@ def synth_backward(amp_frames, freq_frames, window, n_samples, sample_rate, harm
     gf = torch.empty_like(freq_frames) if need_freq else None
     with _on_device(dev):
         check(lib.sot_synth_backward(amp_frames.data_ptr(), freq_frames.data_ptr(), window.data_ptr(), batch, frames, k, int(bool(harmonic)),
-                                     int(n_samples), float(sample_rate), grad_audio.data_ptr(), _ptr(ga), _ptr(gf), ws.data_ptr(), ws.numel(),
-                                     int(reuse), stream_ptr(dev)))
+                                     int(n_samples), float(sample_rate), grad_audio.data_ptr(), _ptr(ga), _ptr(gf), _ptr(tap_tables), ws.data_ptr(),
+                                     ws.numel(), int(reuse), stream_ptr(dev)))
     return ga, gf

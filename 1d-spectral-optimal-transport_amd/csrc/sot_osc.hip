@@ -89,6 +89,7 @@ struct OscArgs {
     float* audio;                                   // forward output [batch, samples]
     const float* grad_audio;                        // backward input  [batch, samples]
     float* grad_freq; float* grad_amp;              // backward outputs [batch, samples, sinusoids]; either may be null
+    int scanned;                                    // phase0 / dcarry hold scanned values (oscillator_scan_kernel ran) rather than raw totals
     EnvArgs ctl;                                    // CTL kernels: the envelopes are evaluated from these frame-rate controls
     // kBackwardFrames: cumulative linear-tap weights and Hann-window weights [frames, 3 hop], per-segment partial sums
     // [batch, nseg, nslot, sinusoids] x 2
@@ -96,6 +97,32 @@ struct OscArgs {
 };
 
 __device__ __forceinline__ float omega_of(float f, float sr) { return (f * kTwoPi) / sr; }
+
+// Clips of at most kFusedScanSegments segments would skip the two scan launches: a tile adds up the totals of the segments before it
+// (after it, for the reverse direction) itself, in the order oscillator_scan_kernel uses -- the same doubles, bit for bit.  Measured
+// with 64 (256 clips x 8 segments): the tile kernels lose more (forward 45.3 -> 50.5 us, backward 74.5 -> 79.2 us) than the 4.7 us
+// scan launches they replace: 0 = always scan.
+constexpr int64_t kFusedScanSegments = 0;
+
+__device__ __forceinline__ double sum_before(const double* totals, int64_t b, int64_t nseg, int64_t seg, int K, int k, int scanned)
+{
+    if (nseg <= 1) return 0.0;
+    const double* p = totals + b * nseg * K + k;
+    if (scanned) return p[seg * K];
+    double acc = 0.0;
+    for (int64_t s = 0; s < seg; ++s) acc += p[s * K];
+    return acc;
+}
+
+__device__ __forceinline__ double sum_after(const double* totals, int64_t b, int64_t nseg, int64_t seg, int K, int k, int scanned)
+{
+    if (nseg <= 1) return 0.0;
+    const double* p = totals + b * nseg * K + k;
+    if (scanned) return p[seg * K];
+    double acc = 0.0;
+    for (int64_t s = nseg - 1; s > seg; --s) acc += p[s * K];
+    return acc;
+}
 
 // LDS: ls[slots*K] doubles | ls2[slots*K] doubles (backward) | tf[S*K] | ta[S*K] | tg[S]
 inline size_t lds_bytes(int S, int K, int mode)
@@ -179,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
 
     for (int i = threadIdx.x; i < items; i += kThreads) {
         const int slot = i / K, k = i - slot * K, base = slot * kRun * K + k;
-        double run = a.nseg > 1 ? a.phase0[wbase + k] : 0.0;
+        double run = sum_before(a.phase0, b, a.nseg, seg, K, k, a.scanned);
         for (int s = 0; s < slot; ++s) run += ls[s * K + k];
         double dlocal = 0.0;
 #pragma unroll
@@ -330,7 +357,6 @@ __global__ __launch_bounds__(kThreads) void oscillator_suffix_kernel(const OscAr
     const int rows = (int)((a.samples - t_base) < S ? (a.samples - t_base) : S);
     const int n = rows * K;
     float* g = a.grad_freq + (b * a.samples + t_base) * K;
-    const int64_t wbase = (b * a.nseg + seg) * K;
 
     for (int e = threadIdx.x; e < tile; e += kThreads) tf[e] = e < n ? g[e] : 0.0f;
     __syncthreads();
@@ -344,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void oscillator_suffix_kernel(const OscAr
     __syncthreads();
     for (int i = threadIdx.x; i < items; i += kThreads) {
         const int slot = i / K, k = i - slot * K, base = slot * kRun * K + k;
-        double after = a.nseg > 1 ? a.dcarry[wbase + k] : 0.0;
+        double after = sum_after(a.dcarry, b, a.nseg, seg, K, k, a.scanned);
         for (int s = slots - 1; s > slot; --s) after += ls[s * K + k];
 #pragma unroll
         for (int j = kRun - 1; j >= 0; --j) {
@@ -390,8 +416,10 @@ inline bool launch_segment_starts(const OscArgs& a, hipStream_t st)
         hipLaunchKernelGGL((oscillator_tile_kernel<kTotals, true>), dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, a.sinusoids, kTotals), st, a);
     else
         hipLaunchKernelGGL(oscillator_tile_kernel<kTotals>, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, a.sinusoids, kTotals), st, a);
-    const unsigned sgrid = (unsigned)((a.batch * a.sinusoids + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.phase0, a.batch, a.nseg, a.sinusoids, 0);
+    if (a.scanned) {
+        const unsigned sgrid = (unsigned)((a.batch * a.sinusoids + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.phase0, a.batch, a.nseg, a.sinusoids, 0);
+    }
     return launched();
 }
 
@@ -537,7 +565,7 @@ __global__ __launch_bounds__(64) void synth_frames_reduce_kernel(const OscArgs a
         }
         if (g_amp != nullptr) g_amp[(b * e.frames + f) * K + k] = (frame_freq(e, freq_b, f, k) >= e.nyquist) ? 0.0f : (float)sa;
         if (g_freq != nullptr) {
-            if (a.nseg > 1) sf += wtot * a.dcarry[(b * a.nseg + seg_b) * K + k];   // all later segments (after the reverse scan)
+            sf += wtot * sum_after(a.dcarry, b, a.nseg, seg_b, K, k, a.scanned);       // all later segments
             sf = sf / (double)a.sample_rate * (double)kTwoPi;                        // d omega / d f
             if (!e.harmonic) g_freq[(b * e.frames + f) * K + k] = (float)sf;
             else fsum[k] = sf;
@@ -627,6 +655,7 @@ int sot_oscillator_bank_forward(const float* freq, const float* amp, int64_t bat
     a.freq = freq; a.amp = amp; a.batch = batch; a.samples = samples; a.sinusoids = sinusoids; a.sample_rate = sample_rate; a.audio = audio;
     a.seg_len = pick_segment(batch, samples, sinusoids);
     a.nseg = (samples + a.seg_len - 1) / a.seg_len;
+    a.scanned = a.nseg > kFusedScanSegments;
     if (batch * a.nseg > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
     if (a.nseg > 1) {
         if (workspace == nullptr) return SOT_ERR_NULL_POINTER;
@@ -654,6 +683,7 @@ int sot_oscillator_bank_backward(const float* freq, const float* amp, int64_t ba
     a.grad_audio = grad_audio; a.grad_freq = grad_freq; a.grad_amp = grad_amp;
     a.seg_len = pick_segment(batch, samples, sinusoids);
     a.nseg = (samples + a.seg_len - 1) / a.seg_len;
+    a.scanned = a.nseg > kFusedScanSegments;
     if (batch * a.nseg > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
     const size_t one = segment_array_bytes(batch, samples, sinusoids);
     if (workspace == nullptr) return SOT_ERR_NULL_POINTER;
@@ -667,7 +697,7 @@ int sot_oscillator_bank_backward(const float* freq, const float* amp, int64_t ba
     if (!workspace_from_forward && !launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
     hipLaunchKernelGGL(oscillator_tile_kernel<kBackward>, dim3(grid), dim3(kThreads), lds_bytes(a.seg_len, sinusoids, kBackward), st, a);
     if (grad_freq != nullptr) {
-        if (a.nseg > 1) {
+        if (a.nseg > 1 && a.scanned) {
             const unsigned sgrid = (unsigned)((batch * sinusoids + kThreads - 1) / kThreads);
             hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.dcarry, batch, a.nseg, sinusoids, 1);
         }
@@ -704,6 +734,7 @@ static int fill_synth_args(const float* amp_frames, const float* freq_frames, co
     a->batch = batch; a->samples = samples; a->sinusoids = sinusoids; a->sample_rate = sample_rate;
     a->seg_len = pick_segment(batch, samples, sinusoids);
     a->nseg = (samples + a->seg_len - 1) / a->seg_len;
+    a->scanned = a->nseg > kFusedScanSegments;
     return batch * a->nseg > 0x7fffffffLL ? SOT_ERR_UNSUPPORTED_SIZE : SOT_OK;
 }
 
@@ -729,9 +760,30 @@ int sot_synth_forward(const float* amp_frames, const float* freq_frames, const f
     return launched() ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
+size_t sot_synth_tap_table_bytes(int frames, int64_t samples)
+{
+    if (frames < 1 || samples < 1 || samples > sot_osc::kMaxSamples || frames >= samples || samples % frames != 0) return 0;
+    return (sizeof(double) + sizeof(float)) * 3 * (size_t)samples;
+}
+
+int sot_synth_tap_tables(const float* window, int frames, int64_t samples, void* tables, void* stream)
+{
+    using namespace sot_osc;
+    EnvArgs e{};
+    if (const int rc = fill_env_args(1, frames, 1, 0, samples, 2.0f, &e)) return rc;
+    if (!window || !tables) return SOT_ERR_NULL_POINTER;
+    e.window = window;
+    double* wtab = static_cast<double*>(tables);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(synth_tap_table_kernel, dim3((unsigned)frames), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), e, wtab,
+                       reinterpret_cast<float*>(wtab + 3 * (size_t)samples));
+    return launched() ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
 int sot_synth_backward(const float* amp_frames, const float* freq_frames, const float* window, int64_t batch, int frames, int sinusoids,
                        int harmonic, int64_t samples, float sample_rate, const float* grad_audio, float* grad_amp_frames,
-                       float* grad_freq_frames, void* workspace, size_t workspace_bytes, int workspace_from_forward, void* stream)
+                       float* grad_freq_frames, const void* tap_tables, void* workspace, size_t workspace_bytes, int workspace_from_forward,
+                       void* stream)
 {
     using namespace sot_osc;
     OscArgs a{};
@@ -746,9 +798,14 @@ int sot_synth_backward(const float* amp_frames, const float* freq_frames, const 
     a.dcarry = reinterpret_cast<double*>(ws + one);
     double* wtab = reinterpret_cast<double*>(ws + 2 * one);
     double* parts = wtab + 3 * (size_t)samples;
-    a.wtab = wtab;
     float* atab = reinterpret_cast<float*>(parts + 2 * entries);
-    a.atab = atab;
+    if (tap_tables != nullptr) {   // the caller's tables (sot_synth_tap_tables for the same window, frames and samples)
+        a.wtab = static_cast<const double*>(tap_tables);
+        a.atab = reinterpret_cast<const float*>(a.wtab + 3 * (size_t)samples);
+    } else {
+        a.wtab = wtab;
+        a.atab = atab;
+    }
     a.part_amp = grad_amp_frames ? parts : nullptr;
     a.part_freq = grad_freq_frames ? parts + entries : nullptr;
     a.nslot = frame_slots(a.seg_len, a.ctl.hop);
@@ -759,14 +816,14 @@ int sot_synth_backward(const float* amp_frames, const float* freq_frames, const 
     const unsigned grid = (unsigned)(batch * a.nseg);
     (void)hipGetLastError();
     if (!workspace_from_forward && !launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
-    hipLaunchKernelGGL(synth_tap_table_kernel, dim3((unsigned)frames), dim3(kThreads), 0, st, a.ctl, wtab, atab);
+    if (tap_tables == nullptr) hipLaunchKernelGGL(synth_tap_table_kernel, dim3((unsigned)frames), dim3(kThreads), 0, st, a.ctl, wtab, atab);
     auto kern = oscillator_tile_kernel<kBackwardFrames, true>;
     if (lds > 64 * 1024) {
         static std::once_flag once;
         std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
-    if (a.part_freq != nullptr && a.nseg > 1) {
+    if (a.part_freq != nullptr && a.nseg > 1 && a.scanned) {
         const unsigned sgrid = (unsigned)((batch * sinusoids + kThreads - 1) / kThreads);
         hipLaunchKernelGGL(oscillator_scan_kernel, dim3(sgrid), dim3(kThreads), 0, st, a.dcarry, batch, a.nseg, sinusoids, 1);
     }

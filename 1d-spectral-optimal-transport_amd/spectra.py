@@ -169,6 +169,18 @@ def _hann_on(device, hop: int) -> torch.Tensor:
     return _HANN[key]
 
 
+_TAPS = {}
+
+
+def _tap_tables_on(window: torch.Tensor, frames: int, n_samples: int) -> torch.Tensor:
+    """The synthesiser backward's weight tables for this frame / sample count (they depend on nothing else), built once per device."""
+    from . import _native as nat
+    key = (str(window.device), frames, n_samples)
+    if key not in _TAPS:
+        _TAPS[key] = nat.synth_tap_tables(window, frames, n_samples)
+    return _TAPS[key]
+
+
 def _envelope_kernels_apply(amplitudes, frequencies, n_samples, harmonic) -> bool:
     if amplitudes.ndim != 3 or frequencies.ndim != 3:
         return False
@@ -228,7 +240,8 @@ class _Synth(torch.autograd.Function):
         frequencies, amplitudes, window, ws = ctx.saved_tensors
         n_samples, sample_rate, harmonic = ctx.cfg
         ga, gf = nat.synth_backward(amplitudes, frequencies, window, n_samples, sample_rate, harmonic, grad_audio.float(),
-                                    need_amp=ctx.needs_input_grad[1], need_freq=ctx.needs_input_grad[0], forward_workspace=ws)
+                                    need_amp=ctx.needs_input_grad[1], need_freq=ctx.needs_input_grad[0], forward_workspace=ws,
+                                    tap_tables=_tap_tables_on(window, amplitudes.shape[1], n_samples))
         return gf, ga, None, None, None
 
 
