@@ -82,10 +82,13 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True):
     g, cpt, rows, nx = geo
     if pm == 1 and not lim and not backward and same_grid:   # p = 1 on one grid: the merge-free kernel (sot_area_full_kernel)
         return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, {nx}>"
-    if backward:   # the y-only (training) kernels; 2048-bin rows run two per workgroup in the layout without U gradient slots
+    if backward:   # the y-only (training) kernels <..., WANT_X, SLIM, MINB>: 2048-bin rows run two per workgroup in the layout without
+        # U gradient slots, 1025- and 513-bin rows in that layout compiled for four workgroups per CU
         if n == 2048:
-            return f"sot_backward_full_kernel<{g}, {cpt}, 2, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true>"
-        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false>"
+            return f"sot_backward_full_kernel<{g}, {cpt}, 2, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
+        if n in (1025, 513):
+            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 4>"
+        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false, 1>"
     return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
 
 
@@ -232,7 +235,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
 
     ms5 = timed(train_step, n)
     # bytes the slice must move: both clips' audio in, the estimate's audio gradient out (spectra stay on chip in the ideal)
-    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<128, 9, 2, ..., 1025, false, false> + stft backward",
+    out["config5_train_step_256clips"] = entry(ms5, "stft_mag_forward_pair + sot_backward_full_kernel<128, 9, 2, ..., 1025, false, true, 4> + stft backward",
                                                3 * 256 * 4096 * 4, steps_per_s=1e3 / ms5, rows=4096, bins=1025)
 
     # (5) the synthesiser in front of it: 256 clips x 16 frames x 8 partials of frame-rate controls -> 4096
@@ -260,6 +263,28 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     ms_st = timed(synth_train_step, n)
     out["config5_train_step_with_synth_256clips"] = entry(ms_st, "synth + stft pair + sot training form + stft backward + synth backward", ctl_bytes,
                                                           steps_per_s=1e3 / ms_st)
+
+    # (6) the multi-kernel steps above are launched from Python one kernel at a time: on a loaded host they measure the host.  The same
+    #     steps replayed from ONE HIP graph (what a training loop that captures its step does) show the GPU time.
+    def replayed(step_fn):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step_fn(0)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step_fn(0)
+        return timed(lambda i: graph.replay(), n)
+
+    for key, fn, kern, nbytes in (("config5_train_step_256clips", train_step, "the same kernels, one HIP graph", 3 * 256 * 4096 * 4),
+                                  ("synth_forward_backward_256clips", synth_step, "the same kernels, one HIP graph", ctl_bytes),
+                                  ("config5_train_step_with_synth_256clips", synth_train_step, "the same kernels, one HIP graph", ctl_bytes)):
+        try:
+            out[key + "_graph_replay"] = entry(replayed(fn), kern, nbytes)
+        except Exception as exc:  # noqa: BLE001 -- a capture that fails must not take the bench line with it
+            out[key + "_graph_replay"] = {"error": repr(exc)[:200]}
     return out
 
 

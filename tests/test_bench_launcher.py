@@ -53,8 +53,8 @@ def test_kernel_name_follows_shape_and_mode():
     assert b.forward_kernel_name(2048, "p1") == "sot_area_full_kernel<256, 8, 1, false, 0>"          # p = 1, one grid: merge-free
     assert b.forward_kernel_name(2048, "p1", same_grid=False) == "sot_forward_full_kernel<256, 8, 1, 1, false, false, 0>"
     assert b.forward_kernel_name(1025, "cutoff") == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
-    assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<128, 9, 2, 2, true, true, 1025, false, false>"
-    assert b.forward_kernel_name(2048, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 2, 2, true, true, 0, false, true>"
+    assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<128, 9, 2, 2, true, true, 1025, false, true, 4>"
+    assert b.forward_kernel_name(2048, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 2, 2, true, true, 0, false, true, 1>"
     assert "generic" in b.forward_kernel_name(3000, "p1")
 
 
