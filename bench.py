@@ -88,6 +88,8 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True):
             return f"sot_backward_full_kernel<{g}, {cpt}, 2, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
         if n in (1025, 513):
             return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 4>"
+        if n in (1024, 2049):
+            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
         return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false, 1>"
     return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
 
