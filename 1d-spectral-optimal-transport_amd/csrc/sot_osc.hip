@@ -824,9 +824,17 @@ int sot_synth_backward(const float* amp_frames, const float* freq_frames, const 
     if (!workspace_from_forward && !launch_segment_starts(a, st)) return SOT_ERR_LAUNCH;
     if (tap_tables == nullptr) hipLaunchKernelGGL(synth_tap_table_kernel, dim3((unsigned)frames), dim3(kThreads), 0, st, a.ctl, wtab, atab);
     auto kern = oscillator_tile_kernel<kBackwardFrames, true>;
-    if (lds > 64 * 1024) {
-        static std::once_flag once;
-        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (lds > 64 * 1024) {   // opt this kernel in to the full LDS once per DEVICE (the attribute is per device; setting it twice is harmless)
+        static std::mutex mu;
+        static bool done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = -1; }
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || !done[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                (void)hipGetLastError();
+            if (dev >= 0) done[dev] = true;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, a);
     if (a.part_freq != nullptr && a.nseg > 1 && a.scanned) {

@@ -19,6 +19,7 @@
 // gradient once.  (4 frames per group: 2.75 x, but half the workgroups; the same time at n_fft 2048, 20 % slower over
 // the six scales of MSSLoss.)
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <math.h>
 
@@ -729,15 +730,15 @@ static void launch_slots(void (*kernel)(const StftArgs), int64_t work, size_t ex
 #endif
 static int cu_count()
 {
-    static int cus[64] = {};
+    static std::atomic<int> cus[64];   // zero-initialised; per device, written with the same value by whoever gets there first
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
-    if (cus[dev] == 0) {   // idempotent per device
-        int v = 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 256; }
-        cus[dev] = v;
+        cus[dev].store(v, std::memory_order_relaxed);
     }
-    return cus[dev];
+    return v;
 }
 
 // the persistent forward kernel on as many workgroups as stay resident (LDS / 2048 threads per CU)
@@ -746,18 +747,18 @@ static void launch_forward_persistent(int64_t work, hipStream_t st, const StftAr
 {
     using G = Geo<LOGM>;
     const size_t lds = ((size_t)G::slots * G::zpoints + G::m) * sizeof(float2);
-    static int per_cu_cache[64] = {};
+    static std::atomic<int> per_cu_cache[64];   // per device, as in cu_count()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
-    if (per_cu_cache[dev] == 0) {   // idempotent per device
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, stft_mag_forward_persistent_kernel<LOGM>, kThreads, lds) != hipSuccess || n < 1) {
+    int per_cu = per_cu_cache[dev].load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stft_mag_forward_persistent_kernel<LOGM>, kThreads, lds) != hipSuccess || per_cu < 1) {
             (void)hipGetLastError();
-            n = 4;
+            per_cu = 4;
         }
-        per_cu_cache[dev] = n;
+        per_cu_cache[dev].store(per_cu, std::memory_order_relaxed);
     }
-    const int64_t groups = (work + G::slots - 1) / G::slots, cap = (int64_t)cu_count() * per_cu_cache[dev];
+    const int64_t groups = (work + G::slots - 1) / G::slots, cap = (int64_t)cu_count() * per_cu;
     hipLaunchKernelGGL(stft_mag_forward_persistent_kernel<LOGM>, dim3((unsigned)(groups < cap ? groups : cap)), dim3(kThreads), lds, st, a);
 }
 
