@@ -509,8 +509,14 @@ __device__ __forceinline__ int lower_rank(const float* A, int len, float q)
 // Row pipeline: the NEXT row's weights are fetched into registers while the current row is being
 // processed in LDS, so HBM latency overlaps the scan/merge work of the same workgroup.
 // ---------------------------------------------------------------------------------------------
+// Register cap (waves per SIMD) of the one-wave-per-row CSR kernel: 146 VGPRs = three waves per SIMD without it; compiled for four
+// (128 VGPRs) config 4's 8192 ragged rows take 30.8 instead of 33.0 us (five: 42.4, six: 56.5 -- spills).  The dense generic kernels
+// keep their registers: the same cap on 8192 x 1000 costs 46 -> 58 us (12 elements per thread spill).
+#ifndef SOT_CSR_MIN_WAVES
+#define SOT_CSR_MIN_WAVES 4
+#endif
 template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, bool CSR = false, int SQM = 2>
-__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_forward_kernel(const FwdArgs a)
+__global__ __launch_bounds__((G < 256 ? 256 : G), ((CSR && G == 64) ? SOT_CSR_MIN_WAVES : 1)) void sot_forward_kernel(const FwdArgs a)
 {
     static_assert(!CSR || (ROWPOS && !VEC && !QUANT), "the CSR form has per-row positions and unaligned rows");
     constexpr int BLOCK = (G < 256 ? 256 : G);
