@@ -584,16 +584,19 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
 
 __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftArgs a)
 {
-    const int64_t total = a.batch * a.samples;
-    const int64_t gstep = (int64_t)kFramesPerGroup * a.hop;   // samples between the starts of consecutive groups
-    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
-        const int64_t b = idx / a.samples, t = idx - b * a.samples;
-        int64_t g_lo = (t - a.span + gstep) / gstep;           // first group whose span [g * gstep, g * gstep + span) holds t
-        if (t - a.span + 1 <= 0) g_lo = 0;
-        const int64_t g_hi = min(t / gstep, a.groups - 1);
+    // one clip per blockIdx.y; 32-bit arithmetic inside the clip (samples < 2^31 is checked by the host)
+    const int64_t b = blockIdx.y;
+    const int samples = (int)a.samples, span = a.span, groups = (int)a.groups;
+    const int gstep = kFramesPerGroup * a.hop;                  // samples between the starts of consecutive groups
+    const float* part = a.partial + b * (int64_t)groups * span;
+    float* out = a.grad_audio + b * a.samples;
+    for (int t = blockIdx.x * kThreads + threadIdx.x; t < samples; t += gridDim.x * kThreads) {
+        int g_lo = (t - span + gstep) / gstep;                  // first group whose span [g * gstep, g * gstep + span) holds t
+        if (t - span + 1 <= 0) g_lo = 0;
+        const int g_hi = min(t / gstep, groups - 1);
         float sum = 0.0f;
-        for (int64_t g = g_lo; g <= g_hi; ++g) sum += a.partial[(b * a.groups + g) * a.span + (t - g * gstep)];
-        a.grad_audio[idx] = a.accumulate ? a.grad_audio[idx] + sum : sum;
+        for (int g = g_lo; g <= g_hi; ++g) sum += part[(int64_t)g * span + (t - g * gstep)];
+        out[t] = a.accumulate ? out[t] + sum : sum;
     }
 }
 
@@ -863,6 +866,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
     const int64_t span = n_fft + (int64_t)hop * (kFramesPerGroup - 1);
     if (span > 8192) return SOT_ERR_UNSUPPORTED_SIZE;   // the groups' gradients live in LDS
+    if (samples > 0x7fffffffLL || batch > 65535) return SOT_ERR_UNSUPPORTED_SIZE;   // overlap-add kernel: one clip per blockIdx.y, 32-bit sample indices
     a.grad_mag = grad_mag; a.grad_scale = grad_scale; a.grad_audio = grad_audio; a.accumulate = accumulate;
     a.partial = reinterpret_cast<float*>(workspace);
     a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
@@ -871,9 +875,8 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     (void)hipGetLastError();
     SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
-    const int64_t total = batch * samples;
-    const int grid2 = (int)((total + kThreads - 1) / kThreads < 256 * 32 ? (total + kThreads - 1) / kThreads : 256 * 32);
-    hipLaunchKernelGGL(stft_overlap_add_kernel, dim3(grid2), dim3(kThreads), 0, st, a);
+    const int64_t per_clip = (samples + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(stft_overlap_add_kernel, dim3((unsigned)(per_clip < 64 ? per_clip : 64), (unsigned)batch), dim3(kThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
