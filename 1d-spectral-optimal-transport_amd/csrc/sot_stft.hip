@@ -584,19 +584,20 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
 
 __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftArgs a)
 {
-    // one clip per blockIdx.y; 32-bit arithmetic inside the clip (samples < 2^31 is checked by the host)
-    const int64_t b = blockIdx.y;
+    // clips over blockIdx.y; 32-bit arithmetic inside a clip (samples < 2^31 is checked by the host)
     const int samples = (int)a.samples, span = a.span, groups = (int)a.groups;
     const int gstep = kFramesPerGroup * a.hop;                  // samples between the starts of consecutive groups
-    const float* part = a.partial + b * (int64_t)groups * span;
-    float* out = a.grad_audio + b * a.samples;
-    for (int t = blockIdx.x * kThreads + threadIdx.x; t < samples; t += gridDim.x * kThreads) {
-        int g_lo = (t - span + gstep) / gstep;                  // first group whose span [g * gstep, g * gstep + span) holds t
-        if (t - span + 1 <= 0) g_lo = 0;
-        const int g_hi = min(t / gstep, groups - 1);
-        float sum = 0.0f;
-        for (int g = g_lo; g <= g_hi; ++g) sum += part[(int64_t)g * span + (t - g * gstep)];
-        out[t] = a.accumulate ? out[t] + sum : sum;
+    for (int64_t b = blockIdx.y; b < a.batch; b += gridDim.y) {
+        const float* part = a.partial + b * (int64_t)groups * span;
+        float* out = a.grad_audio + b * a.samples;
+        for (int t = blockIdx.x * kThreads + threadIdx.x; t < samples; t += gridDim.x * kThreads) {
+            int g_lo = (t - span + gstep) / gstep;              // first group whose span [g * gstep, g * gstep + span) holds t
+            if (t - span + 1 <= 0) g_lo = 0;
+            const int g_hi = min(t / gstep, groups - 1);
+            float sum = 0.0f;
+            for (int g = g_lo; g <= g_hi; ++g) sum += part[(int64_t)g * span + (t - g * gstep)];
+            out[t] = a.accumulate ? out[t] + sum : sum;
+        }
     }
 }
 
@@ -866,7 +867,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
     const int64_t span = n_fft + (int64_t)hop * (kFramesPerGroup - 1);
     if (span > 8192) return SOT_ERR_UNSUPPORTED_SIZE;   // the groups' gradients live in LDS
-    if (samples > 0x7fffffffLL || batch > 65535) return SOT_ERR_UNSUPPORTED_SIZE;   // overlap-add kernel: one clip per blockIdx.y, 32-bit sample indices
+    if (samples > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;   // overlap-add kernel: 32-bit sample indices inside a clip
     a.grad_mag = grad_mag; a.grad_scale = grad_scale; a.grad_audio = grad_audio; a.accumulate = accumulate;
     a.partial = reinterpret_cast<float*>(workspace);
     a.groups = (a.frames + kFramesPerGroup - 1) / kFramesPerGroup;
@@ -876,7 +877,7 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
     const int64_t per_clip = (samples + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(stft_overlap_add_kernel, dim3((unsigned)(per_clip < 64 ? per_clip : 64), (unsigned)batch), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(stft_overlap_add_kernel, dim3((unsigned)(per_clip < 64 ? per_clip : 64), (unsigned)(batch < 65535 ? batch : 65535)), dim3(kThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
