@@ -444,18 +444,19 @@ inline bool launch_segment_starts(const OscArgs& a, hipStream_t st)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void synth_envelopes_forward_kernel(const EnvArgs a)
 {
-    const int64_t b = blockIdx.y;
-    const float* amp_b = clip_amp(a, b);
-    const float* freq_b = clip_freq(a, b);
     const int64_t per_clip = a.samples * a.K;            // < 2^29
-    float* amp_env = a.amp_env + b * per_clip;
-    float* freq_env = a.freq_env + b * per_clip;
-    for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < (unsigned)per_clip; e += gridDim.x * kThreads) {
-        const int t = (int)(e / (unsigned)a.K), k = (int)(e - (unsigned)t * (unsigned)a.K);
-        float f, am;
-        envelopes_at(a, amp_b, freq_b, t, k, true, f, am);
-        amp_env[e] = am;
-        freq_env[e] = f;
+    for (int64_t b = blockIdx.y; b < a.batch; b += gridDim.y) {
+        const float* amp_b = clip_amp(a, b);
+        const float* freq_b = clip_freq(a, b);
+        float* amp_env = a.amp_env + b * per_clip;
+        float* freq_env = a.freq_env + b * per_clip;
+        for (unsigned e = blockIdx.x * kThreads + threadIdx.x; e < (unsigned)per_clip; e += gridDim.x * kThreads) {
+            const int t = (int)(e / (unsigned)a.K), k = (int)(e - (unsigned)t * (unsigned)a.K);
+            float f, am;
+            envelopes_at(a, amp_b, freq_b, t, k, true, f, am);
+            amp_env[e] = am;
+            freq_env[e] = f;
+        }
     }
 }
 
@@ -612,11 +613,10 @@ int sot_synth_envelopes_forward(const float* amp_frames, const float* freq_frame
     if (batch == 0) return SOT_OK;
     if (!amp_frames || !freq_frames || !window || !amp_env || !freq_env) return SOT_ERR_NULL_POINTER;
     a.amp = amp_frames; a.freq = freq_frames; a.window = window; a.amp_env = amp_env; a.freq_env = freq_env;
-    if (batch > 65535) return SOT_ERR_UNSUPPORTED_SIZE;   // one clip per blockIdx.y
     const int64_t want = (samples * sinusoids + kThreads - 1) / kThreads;
     const int64_t cap = 256 * 16 / batch > 0 ? 256 * 16 / batch : 1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(synth_envelopes_forward_kernel, dim3((unsigned)(want < cap ? want : cap), (unsigned)batch), dim3(kThreads), 0,
+    hipLaunchKernelGGL(synth_envelopes_forward_kernel, dim3((unsigned)(want < cap ? want : cap), (unsigned)(batch < 65535 ? batch : 65535)), dim3(kThreads), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
