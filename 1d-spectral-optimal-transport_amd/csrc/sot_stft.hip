@@ -196,6 +196,29 @@ __device__ __forceinline__ void load_frame(const StftArgs& a, const float* src, 
     }
 }
 
+// the same with the thread's window taps (points lid + j tpf) already in registers
+template <int LOGM>
+__device__ __forceinline__ void load_frame_w(const StftArgs& a, const float* src, int64_t t0, v2f* z, bool active, int lid,
+                                             const float2 (&w)[Geo<LOGM>::m / Geo<LOGM>::tpf])
+{
+    using G = Geo<LOGM>;
+    const bool inside = active && t0 + G::n <= a.samples;
+    const float* const s0 = src + t0;
+    const int left = (int)min((int64_t)G::n, a.samples - t0);
+#pragma unroll
+    for (int j = 0; j < G::m / G::tpf; ++j) {
+        const int i = lid + j * G::tpf;
+        float v0, v1;
+        if (inside) {
+            v0 = s0[2 * i] * w[j].x; v1 = s0[2 * i + 1] * w[j].y;
+        } else {
+            v0 = (active && 2 * i < left) ? s0[2 * i] * w[j].x : 0.0f;
+            v1 = (active && 2 * i + 1 < left) ? s0[2 * i + 1] * w[j].y : 0.0f;
+        }
+        z[zi(bitrev(i, LOGM))] = (v2f){v0, v1};
+    }
+}
+
 // |x| as torch's abs(complex) gives it (hypot): sqrt(re^2 + im^2) wherever the squares stay normal (a correctly rounded
 // sqrt of a sum that is good to 1 ulp); the scaled hypotf when any lane of the wave holds a tiny or huge value
 __device__ __forceinline__ float magnitude(v2f x)
@@ -516,6 +539,10 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
     const float scale = 1.0f / sqrtf((float)G::n);
     const float up = a.grad_scale ? *a.grad_scale : 1.0f;
     const unsigned total = (unsigned)(a.batch * a.groups), groups = (unsigned)a.groups;
+    constexpr int PER = m / G::tpf;
+    float2 wt[PER];   // this thread's window taps: used twice per frame (analysis and synthesis side)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) wt[j] = win[lid + j * G::tpf];
     load_tables<LOGM>(tw, wn);
     if constexpr (G::wave_sync) __syncthreads();
     const unsigned w = blockIdx.x * G::slots + slot;
@@ -523,16 +550,40 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
     const unsigned b = active ? w / groups : 0u, grp = active ? w - b * groups : 0u;
     const float* src = a.audio + (int64_t)b * a.row_stride;
     const int64_t f_begin = (int64_t)grp * kFramesPerGroup;
+    float2 cur[PER];   // raw samples of the frame about to be transformed (fetched while the frame before it is processed)
+    auto fetch_audio = [&](int64_t f) {
+        const int64_t t0 = f * a.hop;
+        const float* const s0 = src + t0;
+        const int left = (active && f < a.frames) ? (int)min((int64_t)G::n, a.samples - t0) : 0;   // zeros past the clip (utils.py:252-275)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = lid + j * G::tpf;
+            cur[j].x = (2 * i < left) ? s0[2 * i] : 0.0f;
+            cur[j].y = (2 * i + 1 < left) ? s0[2 * i + 1] : 0.0f;
+        }
+    };
+    fetch_audio(f_begin);
     for (int t = lid; t < a.span; t += G::tpf) acc[t] = 0.0f;
     for (int fi = 0; fi < kFramesPerGroup; ++fi) {
         const int64_t f = f_begin + fi;
         const bool has = active && f < a.frames;   // idle slots / missing frames run the same passes on zeros
-        const int64_t t0 = f * a.hop;
         slot_sync<G::wave_sync>();
-        load_frame<LOGM>(a, src, t0, z, has, lid);
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            z[zi(bitrev(lid + j * G::tpf, LOGM))] = (v2f){cur[j].x * wt[j].x, cur[j].y * wt[j].y};
+        if (fi + 1 < kFramesPerGroup) fetch_audio(f + 1);
+        // this frame's upstream gradients: requested before the transform, consumed after it
+        const float* g = a.grad_mag + ((int64_t)b * a.frames + (has ? f : 0)) * G::nb;
+        float gup_k[kPairIters], gup_m[kPairIters];
+#pragma unroll
+        for (int r = 0; r < kPairIters; ++r) {
+            const int k = lid + r * G::tpf;
+            const bool use = has && k <= m / 2;
+            gup_k[r] = use ? g[k] : 0.0f;
+            gup_m[r] = use ? g[m - k] : 0.0f;
+        }
         fft_inplace<LOGM, false>(z, tw, lid);
         // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
-        const float* g = a.grad_mag + ((int64_t)b * a.frames + (has ? f : 0)) * G::nb;
         v2f gk[kPairIters], gm[kPairIters];
 #pragma unroll
         for (int r = 0; r < kPairIters; ++r) {
@@ -542,8 +593,8 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
                 v2f xk, xm;
                 unpack_pair<LOGM>(z, wn, k, xk, xm);
                 const float mk = magnitude(xk), mm = magnitude(xm);
-                const float ck = mk > 0.0f ? (g[k] * up) / mk : 0.0f;          // torch: sgn(0) = 0
-                const float cm = mm > 0.0f ? (g[m - k] * up) / mm : 0.0f;
+                const float ck = mk > 0.0f ? (gup_k[r] * up) / mk : 0.0f;      // torch: sgn(0) = 0
+                const float cm = mm > 0.0f ? (gup_m[r] * up) / mm : 0.0f;
                 v2f hk = (0.5f * ck) * xk, hm = (0.5f * cm) * xm;
                 if (k == 0) { hk = (v2f){ck * xk.x, 0.0f}; hm = (v2f){cm * xm.x, 0.0f}; }   // H_0, H_m are real
                 const v2f sk = hk + cconj(hm);      // H_k + conj(H_{m-k})
@@ -567,11 +618,11 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
         if (has) {
             const int off = fi * a.hop;
 #pragma unroll
-            for (int i = lid; i < m; i += G::tpf) {
+            for (int j = 0; j < PER; ++j) {
+                const int i = lid + j * G::tpf;
                 const v2f v = z[zi(i)];
-                const float2 wv = win[i];
-                acc[off + 2 * i] += wv.x * v.x * scale;
-                acc[off + 2 * i + 1] += wv.y * v.y * scale;
+                acc[off + 2 * i] += wt[j].x * v.x * scale;
+                acc[off + 2 * i + 1] += wt[j].y * v.y * scale;
             }
         }
     }
