@@ -399,6 +399,7 @@ def main():
     lanes = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     ring = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(4)]   # local / global fp64 sums (N > 1)
     rowbuf = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(4)]  # row losses; slot i % 4 stays on one lane
+    meanbuf = [torch.empty((), dtype=torch.float32, device=dev) for _ in range(4)]
     inv_global_rows = 1.0 / float(world * B)   # weak scaling: every rank owns exactly B rows
 
     def step(i, profile=None):
@@ -412,10 +413,11 @@ def main():
                 torch.cuda.set_stream(cur)
             if profile is not None:
                 nat.profile_next_launch(profile)   # start / stop events attached to the next row-kernel dispatch
-            # same kernels as Wasserstein1D.forward (sot_w1d_loss: the row kernel, then the fixed-order mean kernel)
-            rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
             if not dist_on:
-                return nat.reduce_mean(rows)
+                # the FFI call Wasserstein1D.forward makes (sot_w1d_loss: the row kernel, then the fixed-order mean kernel), into
+                # preallocated outputs
+                return nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, row_out=rowbuf[slot], mean_out=meanbuf[slot])[0]
+            rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
             # N > 1: local kernels -> ONE all-reduce(SUM) of the fp64 partial sum over RCCL -> global mean
             import torch.distributed as dist
             nat.reduce_mean(rows, sum_out=ring[slot])
