@@ -29,7 +29,7 @@ namespace sot_stft {
 
 constexpr int kThreads = 256;
 constexpr int kFramesPerGroup = 2;  // backward: one frame slot per group of consecutive frames of a clip
-constexpr int kMaxFft = 2048;
+constexpr int kMaxFft = 4096;
 
 #include "sot_stft_tables.inc"      // kPassTw, kWn (csrc/gen/make_stft_tables.py)
 
@@ -86,7 +86,7 @@ __host__ __device__ constexpr int zi(int i)
 // length m = n_fft/2 on the packed signal z[i] = v[2i] + i v[2i+1]:   with Ze = (Z_k + conj(Z_{m-k})) / 2,
 // Zo = -i/2 (Z_k - conj(Z_{m-k})), W = exp(-2 pi i k / n):   X_k = Ze + W Zo,   X_{m-k} = conj(Ze - W Zo)   (k <= m/2).
 // One frame SLOT is m/4 threads (one radix-4 butterfly each per pass; at least 16); small transforms share a workgroup:
-// n_fft = 64 / 128 -> 16 frames per workgroup, 256 -> 8, 512 -> 4, 1024 -> 2, 2048 -> 1.
+// n_fft = 64 / 128 -> 16 frames per workgroup, 256 -> 8, 512 -> 4, 1024 -> 2, 2048 and 4096 -> 1 (4096: two butterflies per thread).
 // LDS: z [slots][zi(m)] | per-pass FFT twiddles [m] | W_n^k [m/2 + 2]  (| backward: overlap-add buffers [slots][span]).
 template <int LOGM>
 struct Geo {
@@ -96,7 +96,7 @@ struct Geo {
     // forward 10.7 -> 10.3 us, backward 30.2 -> 28.7 us for 8192 frames.  (Shrinking the slots of n_fft 1024 / 2048 to one
     // wavefront -- 2 / 4 butterflies per thread and pass, SOT_STFT_WAVE_FRAMES=2 -- was measured slower: n_fft 2048 forward
     // 24.6 -> 29.4 us, backward 53 -> 104 us.)
-    static constexpr int tpf_full = (m / 4 > 16) ? m / 4 : 16;
+    static constexpr int tpf_full = (m / 4 > 16) ? (m / 4 > kThreads ? kThreads : m / 4) : 16;   // n_fft 4096: two butterflies per thread and pass
     static constexpr int tpf = (SOT_STFT_WAVE_FRAMES == 2 && tpf_full > 64) ? 64 : tpf_full;
     static constexpr bool wave_sync = (SOT_STFT_WAVE_FRAMES != 0) && tpf <= 64;
     static constexpr int slots = kThreads / tpf;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void load_tables(v2f* tw, v2f* wn)
 {
     using G = Geo<LOGM>;
     for (int i = threadIdx.x; i < G::m - 2; i += kThreads) { const float2 t = kPassTw[i]; tw[i] = (v2f){t.x, t.y}; }
-    for (int k = threadIdx.x; k <= G::m / 2; k += kThreads) { const float2 t = kWn[k << (10 - LOGM)]; wn[k] = (v2f){t.x, t.y}; }
+    for (int k = threadIdx.x; k <= G::m / 2; k += kThreads) { const float2 t = kWn[k << (11 - LOGM)]; wn[k] = (v2f){t.x, t.y}; }
 }
 
 // In-place decimation-in-time FFT of m = 2^LOGM points held in LDS (element i at z[zi(i)]) in BIT-REVERSED order on
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SOT_ST
 #pragma unroll
     for (int j = 0; j < PERK; ++j) {
         const int k = min(lid + j * G::tpf, G::m / 2);
-        const float2 t = kWn[k << (10 - LOGM)];
+        const float2 t = kWn[k << (11 - LOGM)];
         wnr[j] = (v2f){t.x, t.y};
     }
     const float scale = 1.0f / sqrtf((float)G::n);
@@ -469,13 +469,13 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
     v2f* const zl = wn + 520 + wave * kWaveBuf;
     // W_1024^{256 a + b} = W_2048^{2 b} (-i)^a  (exact quarter turns of the committed table)
     for (int j = threadIdx.x; j < 1024; j += kThreads) {
-        const float2 t = kWn[2 * (j & 255)];
+        const float2 t = kWn[4 * (j & 255)];
         v2f w = (v2f){t.x, t.y};
         const int qa = j >> 8;
         if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w; else if (qa == 3) w = mul_i(w);
         tw[j] = w;
     }
-    for (int k = threadIdx.x; k <= 512; k += kThreads) { const float2 t = kWn[k]; wn[k] = (v2f){t.x, t.y}; }
+    for (int k = threadIdx.x; k <= 512; k += kThreads) { const float2 t = kWn[2 * k]; wn[k] = (v2f){t.x, t.y}; }
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)n);
     const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;
@@ -744,7 +744,7 @@ static int fill_args(const float* audio, int64_t batch, int64_t samples, int64_t
 {
     if (batch < 0 || samples < 1 || hop < 1 || row_stride < samples) return SOT_ERR_BAD_SHAPE;
     const int logn = ilog2_exact(n_fft);
-    if (logn < 6 || n_fft > kMaxFft) return SOT_ERR_UNSUPPORTED_SIZE;  // 64 ... 2048, powers of two
+    if (logn < 6 || n_fft > kMaxFft) return SOT_ERR_UNSUPPORTED_SIZE;  // 64 ... 4096, powers of two
     if (batch > 0 && (audio == nullptr || window == nullptr)) return SOT_ERR_NULL_POINTER;
     if (reinterpret_cast<uintptr_t>(window) % 8 != 0) return SOT_ERR_BAD_SHAPE;   // the kernels read the window two taps at a time
     a->audio = audio; a->batch = batch; a->samples = samples; a->row_stride = row_stride;
@@ -763,7 +763,8 @@ static int fill_args(const float* audio, int64_t batch, int64_t samples, int64_t
             case 7: launch_slots<7>(KERNEL<7>, work, extra_lds_per_slot, st, a); break;                                       \
             case 8: launch_slots<8>(KERNEL<8>, work, extra_lds_per_slot, st, a); break;                                       \
             case 9: launch_slots<9>(KERNEL<9>, work, extra_lds_per_slot, st, a); break;                                       \
-            default: launch_slots<10>(KERNEL<10>, work, extra_lds_per_slot, st, a); break;                                    \
+            case 10: launch_slots<10>(KERNEL<10>, work, extra_lds_per_slot, st, a); break;                                    \
+            default: launch_slots<11>(KERNEL<11>, work, extra_lds_per_slot, st, a); break;                                    \
         }                                                                                                                     \
     } while (0)
 

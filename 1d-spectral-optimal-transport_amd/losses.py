@@ -460,7 +460,7 @@ class MSSLoss(torch.nn.Module):
         if audio.is_cuda and not native_ok:
             warn_once(("mss", dims is not None, self.fft_sizes),
                       "MSSLoss: this call runs the torch composition instead of the HIP kernels (`dims` given, FFT sizes outside "
-                      "64..2048, shapes that differ, or both weights zero)")
+                      "64..4096, shapes that differ, or both weights zero)")
         if native_ok:
             return _MultiScaleSpectral.apply(target_audio.float(), audio.float(), self.fft_sizes, float(self.mag_weight),
                                              float(self.logmag_weight), kind == "L2")

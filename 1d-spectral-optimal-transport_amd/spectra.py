@@ -65,8 +65,8 @@ class _StftMagnitude(torch.autograd.Function):
 
 
 def hip_stft_supported(n_fft: int, hop: int, samples: int) -> bool:
-    """Sizes the HIP kernels cover: n_fft a power of two in [64, 2048] (a group of 4 frames must fit LDS in the backward)."""
-    return 64 <= n_fft <= 2048 and (n_fft & (n_fft - 1)) == 0 and samples >= 1 and 1 <= hop and n_fft + 3 * hop <= 8192
+    """Sizes the HIP kernels cover: n_fft a power of two in [64, 4096] (a group of frames must fit LDS in the backward)."""
+    return 64 <= n_fft <= 4096 and (n_fft & (n_fft - 1)) == 0 and samples >= 1 and 1 <= hop and n_fft + 3 * hop <= 8192
 
 
 def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop") -> torch.Tensor:
@@ -78,7 +78,7 @@ def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, windo
     if audio.is_cuda:   # not silent: a GPU tensor that leaves the HIP path says so, once per size
         from .losses import warn_once
         warn_once(("stft", int(n_fft), int(hop), audio.ndim), f"stft_magnitude: n_fft={n_fft}, hop={hop}, audio.ndim={audio.ndim} is outside what "
-                  "the HIP STFT kernels take (2-D audio, n_fft a power of two in [64, 2048]); running torch.stft (rocFFT) instead")
+                  "the HIP STFT kernels take (2-D audio, n_fft a power of two in [64, 4096]); running torch.stft (rocFFT) instead")
     return stft_magnitude_torch(audio, n_fft, hop, window)
 
 

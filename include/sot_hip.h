@@ -215,7 +215,7 @@ int sot_segmented_sort(const float *keys, int64_t B, int32_t n, int64_t row_stri
  * frames = ceil(samples / hop) frames of n_fft samples starting every `hop` samples (zeros past the end of the clip),
  * multiplied by `window` [n_fft], one-sided DFT, |.| / sqrt(n_fft) (torch.stft(center=False, normalized=True)).
  * audio [batch, samples] (row stride in elements), mag / grad_mag [batch, frames, n_fft/2 + 1] contiguous (frames-major:
- * each row is a spectrum for sot_w1d_*), grad_audio [batch, samples] contiguous.  n_fft: a power of two in [64, 2048].
+ * each row is a spectrum for sot_w1d_*), grad_audio [batch, samples] contiguous.  n_fft: a power of two in [64, 4096].
  * Enqueue-only, no allocation: the backward takes a caller-owned scratch buffer of sot_stft_backward_workspace_bytes(). */
 int64_t sot_stft_frames(int64_t samples, int hop);
 int sot_stft_mag_forward(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,

@@ -37,7 +37,7 @@ def test_cpu_tensors_use_the_torch_transform():
     fx = _fx()
     got = spectra.stft_magnitude(torch.as_tensor(fx["c_audio_x"]), 1024, 256)
     assert np.abs(got.numpy() - fx["c_spec_x"]).max() <= 2e-6 * np.abs(fx["c_spec_x"]).max()
-    assert spectra.hip_stft_supported(2048, 256, 4096) and not spectra.hip_stft_supported(4096, 256, 4096)
+    assert spectra.hip_stft_supported(2048, 256, 4096) and spectra.hip_stft_supported(4096, 1024, 4096) and not spectra.hip_stft_supported(8192, 2048, 9000)
     assert not spectra.hip_stft_supported(1000, 250, 4096) and spectra.hip_stft_supported(2048, 256, 16000)
 
 
@@ -166,9 +166,11 @@ def test_wasserstein_with_transform_rejects_other_transforms():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_fft,hop,samples,batch", [(2048, 256, 16000, 3), (256, 64, 777, 5), (1024, 512, 5000, 2), (64, 16, 100, 4)])
+@pytest.mark.parametrize("n_fft,hop,samples,batch", [(2048, 256, 16000, 3), (256, 64, 777, 5), (1024, 512, 5000, 2), (64, 16, 100, 4),
+                                                      (4096, 1024, 20000, 3), (4096, 512, 3000, 2)])
 def test_hip_stft_other_sizes_against_torch(n_fft, hop, samples, batch):
-    """Long clips (many frame groups), odd lengths, hop = n_fft/2: forward and (magnitude-weighted) backward vs torch.stft."""
+    """Long clips (many frame groups), odd lengths, hop = n_fft/2, n_fft 4096 (the producer of the 2049-bin rows; clips shorter than
+    one frame): forward and (magnitude-weighted) backward vs torch.stft, forward also vs the float64 restatement."""
     from gpu_util import device, native
     from sot_amd import spectra
     native()
@@ -178,6 +180,11 @@ def test_hip_stft_other_sizes_against_torch(n_fft, hop, samples, batch):
     got = spectra.stft_magnitude(audio, n_fft, hop, "hann")
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    if n_fft == 4096:
+        from oracle import sot_oracle as so
+        from scipy.signal import get_window
+        ref64 = so.stft_magnitude_np(audio.cpu().numpy(), get_window("hann", n_fft).astype(np.float32), n_fft, hop)
+        assert np.abs(got.cpu().numpy() - ref64).max() <= 2e-6 * np.abs(ref64).max()
     up = torch.randn(ref.shape, device=device(), generator=g) * ref
     a1 = audio.clone().requires_grad_(True); (spectra.stft_magnitude(a1, n_fft, hop, "hann") * up).sum().backward()
     a2 = audio.clone().requires_grad_(True); (spectra.stft_magnitude_torch(a2, n_fft, hop, "hann") * up).sum().backward()
@@ -211,8 +218,8 @@ def test_hip_stft_errors_and_fallback():
         nat.stft_mag_forward(a, torch.ones(1000, device=device()), 1000, 250)          # not a power of two
     with pytest.raises(RuntimeError):
         nat.stft_mag_forward(a.cpu(), torch.ones(2048), 2048, 256)                    # no CPU path in the native layer
-    out = spectra.stft_magnitude(a, 4096, 1024)                                        # unsupported size -> torch transform
-    assert tuple(out.shape) == (2, 4, 2049)
+    out = spectra.stft_magnitude(torch.rand(2, 9000, device=device()), 8192, 2048)   # unsupported size -> torch transform
+    assert tuple(out.shape) == (2, 5, 4097)
     assert nat.stft_mag_forward(a[:0], torch.ones(2048, device=device()), 2048, 256).shape == (0, 16, 1025)
 
 
@@ -397,3 +404,32 @@ def test_hip_gradients_are_as_close_to_float64_as_the_reference_float32():
         ours, ref = _err(got, f64[k]), _err(fx[k], f64[k])
         for o, r, what, floor in zip(ours, ref, ("max", "median", "rms"), (1.5e-5, 1e-6, 1e-6)):
             assert o <= 1.5 * r + floor, (k, what, o, r, "\n" + "\n".join(report))
+
+
+@pytest.mark.gpu
+def test_chain_with_n_fft_4096_runs_the_2049_bin_kernels():
+    """n_fft 4096 -> 2049-bin rows: HIP STFT + the compile-time 2049-bin SOT kernels + both backwards, against the composition of
+    torch.stft with the same module (the spectra agree to ~3e-7 of their peak; the cutoff mode's knife edge sets the loss tolerance)."""
+    from gpu_util import device, module_for
+    from oracle.make_golden import MODES
+    from sot_amd import spectra
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(11)
+    ax = spectra.harmonic_batch(3, n_samples=16384, generator=g, device=dev)
+    ay = spectra.harmonic_batch(3, n_samples=16384, generator=g, device=dev)
+    # (p = 1 gradients jump where two CDF levels swap order, so last-bit differences of the two transforms' spectra move single
+    #  entries by ~1e-2 of the largest one: the maximum is loose, the rms error shows the bulk)
+    for mode, tol_loss, tol_grad in (("p1", 2e-6, 5e-2), ("cutoff", 2e-4, 5e-2)):
+        mod = module_for(MODES[mode])
+        a1 = ay.clone().requires_grad_(True)
+        loss = spectra.training_step_slice(mod, ax, a1, n_fft=4096, hop=1024)
+        loss.backward()
+        a2 = ay.clone().requires_grad_(True)
+        sx, sy = spectra.stft_magnitude_torch(ax, 4096, 1024, "flattop"), spectra.stft_magnitude_torch(a2, 4096, 1024, "flattop")
+        pos = spectra.unit_frequencies(4096, 16000, dev)
+        want = mod(sx, sy, x_pos=pos, y_pos=pos.clone())
+        want.backward()
+        assert sx.shape[-1] == 2049
+        assert abs(float(loss.detach()) - float(want.detach())) <= tol_loss * abs(float(want.detach())), mode
+        assert float((a1.grad - a2.grad).abs().max()) <= tol_grad * float(a2.grad.abs().max()), mode
+        assert float((a1.grad - a2.grad).norm()) <= 5e-2 * float(a2.grad.norm()), mode   # observed: p1 1.9e-2 (see above)
