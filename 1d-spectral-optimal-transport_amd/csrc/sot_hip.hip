@@ -282,14 +282,34 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
     // row group of the workgroup); rows whose positions are already sorted skip it altogether
     const int npx = next_pow2(nmax), npy = next_pow2(mmax);
     int unsorted = 0;
+    // The thread's CPT slots (elements t + k G) are fetched with a compile-time trip count: all loads of a row are in flight together
+    // (a runtime loop waits for each element before it requests the next: sixteen L2 round trips per row at 8 elements per thread).
+    float vx[CPT], vy[CPT], wx1[CPT], wy1[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int e = t + k * G;
+        vx[k] = (e < n) ? xp[e] : INFINITY;
+        vy[k] = (e < m) ? yp[e] : INFINITY;
+        wx1[k] = (c.do_sort && e + 1 < n) ? xp[e + 1] : INFINITY;   // right neighbours for the sortedness test
+        wy1[k] = (c.do_sort && e + 1 < m) ? yp[e + 1] : INFINITY;
+    }
     if (c.do_sort) {
-        for (int e = t; e < npx; e += G) { c.PX[e] = (e < n) ? xp[e] : INFINITY; IX[e] = (e < n) ? e : INT_MAX; }
-        for (int e = t; e < npy; e += G) { c.PY[e] = (e < m) ? yp[e] : INFINITY; IY[e] = (e < m) ? e : INT_MAX; }
-        for (int e = t; e + 1 < n; e += G) unsorted |= (xp[e] > xp[e + 1]);
-        for (int e = t; e + 1 < m; e += G) unsorted |= (yp[e] > yp[e + 1]);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t + k * G;
+            if (e < npx) { c.PX[e] = vx[k]; IX[e] = (e < n) ? e : INT_MAX; }
+            if (e < npy) { c.PY[e] = vy[k]; IY[e] = (e < m) ? e : INT_MAX; }
+            unsorted |= (vx[k] > wx1[k]) | (vy[k] > wy1[k]);        // +inf on the right of the last element: never "unsorted"
+        }
+        for (int e = t + CPT * G; e < npx; e += G) { c.PX[e] = INFINITY; IX[e] = INT_MAX; }   // padding of the sort network past the slots
+        for (int e = t + CPT * G; e < npy; e += G) { c.PY[e] = INFINITY; IY[e] = INT_MAX; }
     } else {
-        for (int e = t; e < n; e += G) c.PX[e] = xp[e];
-        for (int e = t; e < m; e += G) c.PY[e] = yp[e];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t + k * G;
+            if (e < n) c.PX[e] = vx[k];
+            if (e < m) c.PY[e] = vy[k];
+        }
     }
     const bool need_sort = row_any<G / kWave>(unsorted != 0);  // also the barrier after the loads
     if (need_sort) {
