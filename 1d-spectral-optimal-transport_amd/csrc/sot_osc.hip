@@ -172,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
         // (the same float32 operations as synth_envelopes_forward_kernel: identical values)
         const float* amp_b = clip_amp(a.ctl, b);
         const float* freq_b = clip_freq(a.ctl, b);
+#pragma unroll 4   // (runtime trip count: unrolled so that the loads of four elements are in flight together)
         for (int e = threadIdx.x; e < tile; e += kThreads) {
             const int tl = quotient_of(e, a.ctl.inv_K), k = e - tl * K;
             float f = 0.0f, am = 0.0f;
@@ -180,9 +181,21 @@ __global__ __launch_bounds__(kThreads) void oscillator_tile_kernel(const OscArgs
             if (MODE != kTotals) ta[e] = am;
         }
     } else {
-        for (int e = threadIdx.x; e < tile; e += kThreads) {
-            tf[e] = e < n ? a.freq[ebase + e] : 0.0f;            // f = 0 past the clip's end: omega 0, amplitude 0
-            if (MODE != kTotals) ta[e] = e < n ? a.amp[ebase + e] : 0.0f;
+        // all loads of up to eight elements per thread first, then the LDS stores (a plain loop with this runtime trip count waits for
+        // every element before it requests the next)
+        for (int e0 = threadIdx.x; e0 < tile; e0 += 8 * kThreads) {
+            float f[8], am[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + j * kThreads;
+                f[j] = e < n ? a.freq[ebase + e] : 0.0f;        // f = 0 past the clip's end: omega 0, amplitude 0
+                am[j] = (MODE != kTotals && e < n) ? a.amp[ebase + e] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + j * kThreads;
+                if (e < tile) { tf[e] = f[j]; if (MODE != kTotals) ta[e] = am[j]; }
+            }
         }
     }
     if (BWD)
@@ -361,7 +374,13 @@ __global__ __launch_bounds__(kThreads) void oscillator_suffix_kernel(const OscAr
     const int n = rows * K;
     float* g = a.grad_freq + (b * a.samples + t_base) * K;
 
-    for (int e = threadIdx.x; e < tile; e += kThreads) tf[e] = e < n ? g[e] : 0.0f;
+    for (int e0 = threadIdx.x; e0 < tile; e0 += 8 * kThreads) {   // loads first, as in the tile kernel
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int e = e0 + j * kThreads; v[j] = e < n ? g[e] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int e = e0 + j * kThreads; if (e < tile) tf[e] = v[j]; }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < items; i += kThreads) {
         const int slot = i / K, k = i - slot * K, base = slot * kRun * K + k;
