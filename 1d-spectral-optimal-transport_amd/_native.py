@@ -18,6 +18,7 @@ FLAG_SQUARE = 1
 FLAG_DONT_NORMALIZE = 2
 FLAG_LIMIT_Q = 4
 FLAG_REQUIRE_SORT = 8
+FLAG_PRENORMALIZED = 16    # weights are used as given (the functional form wasserstein_1d)
 FLAG_NO_SPECIALIZE = 32  # diagnostic: generic forward kernel only (include/sot_hip.h)
 FLAG_SAME_GRID = 64      # both measures live on one grid: the p = 1 forward runs the merge-free kernel (include/sot_hip.h)
 FLAG_NO_AREA = 128       # diagnostic: ignore FLAG_SAME_GRID
@@ -203,7 +204,10 @@ def make_problem(x, y, xpos, ypos, p, flags, plan=None) -> SotProblem:
     pr.B, pr.n, pr.m = B, n, m
     pr.x_row_stride = x.stride(0) if B > 1 else n
     pr.y_row_stride = y.stride(0) if B > 1 else m
-    pr.p, pr.flags = float(p), int(flags) | (FLAG_SAME_GRID if (plan is not None and plan.same_grid) else 0)
+    pr.p, pr.flags = float(p), int(flags)
+    # only the p = 1 forward without cutoff has a use for the same-grid answer (and may pay one synchronisation per plan for it)
+    if plan is not None and p == 1 and not (flags & (FLAG_LIMIT_Q | FLAG_NO_AREA | FLAG_PRENORMALIZED)) and plan.same_grid():
+        pr.flags |= FLAG_SAME_GRID
     if plan is not None:
         pr.xpos, pr.ypos = plan.xpos_sorted.data_ptr(), plan.ypos_sorted.data_ptr()
         pr.xperm, pr.yperm = plan.xperm.data_ptr(), plan.yperm.data_ptr()
@@ -231,6 +235,7 @@ class PositionPlan:
         self.yperm = torch.empty(m, dtype=torch.int32, device=dev)
         self.ident = torch.empty(2, dtype=torch.int32, device=dev)
         xp, yp = xpos.contiguous(), ypos.contiguous()
+        self._same_tensor = n == m and xpos.data_ptr() == ypos.data_ptr()
         with _on_device(dev):
             self.stream = stream_ptr(dev)
             check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
@@ -239,18 +244,24 @@ class PositionPlan:
             # the plan is cached and may be consumed from other streams: they wait on this event (see use_plan)
             self.ready = torch.cuda.Event()
             self.ready.record(torch.cuda.current_stream(dev))
-        # Do both measures live on ONE grid (every reference call site: y_pos = x_pos.clone(), the fixed_x buffer)?  Then
-        # the p = 1 forward has a merge-free form (SOT_FLAG_SAME_GRID).  Decided once per plan: trivially for one tensor
-        # passed twice, by a device comparison (one host synchronisation per PLAN, not per call) otherwise -- skipped, i.e.
-        # answered "no", while a stream capture is in progress.
-        if n != m:
-            self.same_grid = False
-        elif xpos.data_ptr() == ypos.data_ptr():
-            self.same_grid = True
-        elif torch.cuda.is_current_stream_capturing():
-            self.same_grid = False
-        else:
-            self.same_grid = bool(torch.equal(self.xpos_sorted, self.ypos_sorted))
+        self._same_grid = None   # decided lazily, see same_grid()
+
+    def same_grid(self) -> bool:
+        """Do both measures live on ONE grid (every reference call site: y_pos = x_pos.clone(), the fixed_x buffer)?  Then the
+        p = 1 forward without cutoff has a merge-free form (SOT_FLAG_SAME_GRID).  Only such a call asks (make_problem), so the
+        paper's p = 2 training step never pays for the answer.  Trivial for one tensor passed twice; otherwise ONE device
+        comparison per plan, i.e. one host synchronisation the first time a p = 1 call uses the plan -- answered "no" (and not
+        remembered) while a stream capture is in progress."""
+        if self._same_grid is None:
+            if self.xpos_sorted.numel() != self.ypos_sorted.numel():
+                self._same_grid = False
+            elif self._same_tensor:
+                self._same_grid = True
+            elif torch.cuda.is_current_stream_capturing():
+                return False
+            else:
+                self._same_grid = bool(torch.equal(self.xpos_sorted, self.ypos_sorted))
+        return self._same_grid
 
     def use_on_current_stream(self, device):
         """Order the current stream after the kernel that produced this plan (no-op on the producing stream)."""

@@ -7,8 +7,10 @@ Same names, argument meaning and error behaviour as the reference's ``losses`` m
 (utils.py:135-142), so ``trainer.py:220/228``, ``metrics.py:148`` and the YAML
 ``class_path: losses.Wasserstein1D`` keep working unchanged.
 
-All arithmetic on the path runs in the hand-written HIP library (csrc/, C ABI in
-include/sot_hip.h); this file only reshapes, marshals pointers and wires autograd.
+All arithmetic on float32 HIP-device tensors runs in the hand-written HIP library (csrc/, C ABI in
+include/sot_hip.h); this file only reshapes, marshals pointers and wires autograd.  Tensors outside the library's domain
+-- CPU tensors, float64 -- take the reference's own route, torch ops (_torch_path.py), because the reference is device- and
+dtype-agnostic (losses.py:129-211) and `accelerator: cpu` has to keep working.
 """
 from __future__ import annotations
 
@@ -17,11 +19,12 @@ import warnings
 import torch
 
 from . import _native as nat
+from . import _torch_path as tp
 
 __all__ = ["Wasserstein1D", "Wasserstein1DWithTransform", "wasserstein_1d", "wasserstein_1d_csr", "quantile_function", "MixOfLosses",
            "MSSLoss", "safe_divide"]
 
-FLAG_PRENORMALIZED = 16  # weights are used as given (the functional form wasserstein_1d)
+FLAG_PRENORMALIZED = nat.FLAG_PRENORMALIZED
 
 
 def safe_divide(numerator, denominator, eps=1e-7):
@@ -41,15 +44,20 @@ def warn_once(key, message):
         warnings.warn(message, stacklevel=3)
 
 
-def _as_float32(*tensors):
-    """The kernels compute in float32 (include/sot_hip.h).  float64 inputs -- which the reference tolerates (SURVEY 8b;
-    utils.py:135-142 promotes) -- are converted on the way in, and the caller converts the result back to float64: same
-    interface, float32 arithmetic (said once, in a warning)."""
-    if not any(t is not None and t.dtype == torch.float64 for t in tensors):
-        return tensors, None   # float32 passes through; half / bfloat16 are refused by the binding (TypeError), not upcast
-    warn_once("float64", "sot_amd computes in float32: float64 inputs are converted to float32 and the result back to float64 "
-                         "(the reference would have computed in float64)")
-    return tuple(t.float() if (t is not None and t.dtype == torch.float64) else t for t in tensors), torch.float64
+def _hip_domain(*tensors) -> bool:
+    """True when the HIP library takes these tensors: all of them float32 on a HIP device.  CPU tensors (any floating dtype) and
+    float64 tensors (any device) go to the torch-op composition instead -- float64 is then float64 arithmetic, as in the
+    reference; a float64 GPU tensor says so once.  half / bfloat16 GPU tensors are refused (TypeError), not upcast."""
+    ts = [t for t in tensors if t is not None]
+    if all(t.is_cuda and t.dtype == torch.float32 for t in ts):
+        return True
+    for t in ts:
+        if t.is_cuda and t.dtype in (torch.float16, torch.bfloat16):
+            raise TypeError(f"sot_amd computes in float32; got {t.dtype} (convert with .float())")
+    if any(t.is_cuda for t in ts):
+        warn_once("not-hip-f32", "sot_amd: tensors that are not all float32 on the GPU (float64, or CPU and GPU mixed) run the torch-op "
+                                 "composition in their own dtype, like the reference; the HIP kernels take float32 GPU tensors")
+    return False
 
 
 def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized=False):
@@ -236,19 +244,20 @@ def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, requ
         u_weights = torch.full(u_values.shape, 1.0 / n, device=u_values.device, dtype=u_values.dtype)
     if v_weights is None:
         v_weights = torch.full(v_values.shape, 1.0 / m, device=v_values.device, dtype=v_values.dtype)
+    if not _hip_domain(u_values, v_values, u_weights, v_weights):
+        return tp.transport_rows(u_values, v_values, u_weights, v_weights, p=p, require_sort=require_sort,
+                                 return_quantiles=return_quantiles, limit_quantile_range=limit_quantile_range)
+
     # stride-0 expanded positions (losses.py:167-170) are passed down as one shared row
     def shared_row(t):
         return t[0] if (t.ndim == 2 and t.shape[0] > 1 and t.stride(0) == 0) else t
     upos, vpos = shared_row(u_values), shared_row(v_values)
-    (u_weights, v_weights, upos, vpos), out_dtype = _as_float32(u_weights, v_weights, upos, vpos)
     x, y, upos, vpos = _prepare(u_weights, v_weights, upos, vpos)
     flags = _flags(False, False, limit_quantile_range, require_sort, prenormalized=True)
     plan = _functional_plans.get(upos, vpos) if (require_sort and upos.ndim == 1) else None
     if return_quantiles:
-        out = nat.quantiles(x, y, upos, vpos, p, flags, plan)
-        return out if out_dtype is None else tuple(t.to(out_dtype) for t in out)
-    rows = _RowLoss.apply(x, y, upos, vpos, float(p), flags, plan)
-    return rows if out_dtype is None else rows.to(out_dtype)
+        return nat.quantiles(x, y, upos, vpos, p, flags, plan)
+    return _RowLoss.apply(x, y, upos, vpos, float(p), flags, plan)
 
 
 def _csr_to_padded(weights, positions, offsets, width):
@@ -321,17 +330,16 @@ class Wasserstein1D(torch.nn.Module):
         else:
             self.register_buffer("fixed_x", None)
         self._plans = _PlanCache()
-        self._out_dtype = None
 
-    def _marshal(self, x, y, x_pos, y_pos, kwargs):
+    def _positions(self, x_pos, y_pos):
         if (x_pos is None or y_pos is None) and self.fixed_x is None:
             raise ValueError("If fixed_x is not provided, x_pos and y_pos must be provided")
         assert self.p >= 1, f"The OT loss is only valid for p>=1, {self.p} was given"  # losses.py:271
+        return (self.fixed_x if x_pos is None else x_pos), (self.fixed_x if y_pos is None else y_pos)
 
-        x_pos_ = self.fixed_x if x_pos is None else x_pos
-        y_pos_ = self.fixed_x if y_pos is None else y_pos
-        (x, y, x_pos_, y_pos_), self._out_dtype = _as_float32(x, y, x_pos_, y_pos_)
-
+    def _marshal(self, x, y, x_pos, y_pos, kwargs):
+        """float32 GPU tensors -> what the native calls take: 2-D rows, positions, flag word, position plan."""
+        x_pos_, y_pos_ = self._positions(x_pos, y_pos)
         original_shape = x.shape[:-1]
         if x.ndim == 3:
             x = x.reshape(-1, x.shape[-1])
@@ -350,9 +358,22 @@ class Wasserstein1D(torch.nn.Module):
         plan = self._plans.get(x_pos_, y_pos_) if (self.require_sort and x_pos_.ndim == 1) else None
         return x, y, x_pos_, y_pos_, flags, plan, original_shape
 
+    def _torch_forward(self, x, y, x_pos_, y_pos_, kwargs, rows_only=False):
+        """CPU / float64 tensors: the torch-op composition (_torch_path.py), same keyword handling as the HIP route."""
+        return tp.module_forward(
+            x, y, x_pos_, y_pos_, p=self.p, square_dist=self.square_dist,
+            dont_normalize=bool(kwargs.get("dont_normalize", False) or self.dont_normalize),
+            limit_quantile_range=bool(kwargs.get("limit_quantile_range", False) or self.limit_quantile_range),
+            require_sort=self.require_sort, hinge_on=bool(self.hinge), hinge_value=kwargs.get("hinge", 0.0),
+            dims=(0 if rows_only else kwargs.get("dims", None)), return_quantiles=(not rows_only) and kwargs.get("return_quantiles", False),
+            rows_only=rows_only)
+
     def row_losses(self, x, y, x_pos=None, y_pos=None, **kwargs):
         """Flat [rows] tensor of W_p^p per spectrum pair (after the optional hinge, before the mean):
         what losses.py:186-205 holds before its reshape/mean.  Used by the row-sharded multi-GPU path."""
+        x_pos_, y_pos_ = self._positions(x_pos, y_pos)
+        if not _hip_domain(x, y, x_pos_, y_pos_):
+            return self._torch_forward(x, y, x_pos_, y_pos_, kwargs, rows_only=True)
         x, y, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (x, y, x_pos_, y_pos_)):
             loss = _RowLoss.apply(x, y, x_pos_, y_pos_, float(self.p), flags, plan)
@@ -363,13 +384,9 @@ class Wasserstein1D(torch.nn.Module):
         return loss
 
     def forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
-        out = self._forward(x, y, x_pos, y_pos, **kwargs)
-        dt = self._out_dtype   # set by _marshal: the promoted input dtype when it is not float32
-        if dt is None:
-            return out
-        return [t.to(dt) for t in out] if isinstance(out, list) else out.to(dt)
-
-    def _forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
+        x_pos_, y_pos_ = self._positions(x_pos, y_pos)
+        if not _hip_domain(x, y, x_pos_, y_pos_):
+            return self._torch_forward(x, y, x_pos_, y_pos_, kwargs)
         if kwargs.get("return_quantiles", False):
             x2, y2, x_pos_, y_pos_, flags, plan, original_shape = self._marshal(x, y, x_pos, y_pos, kwargs)
             out = nat.quantiles(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)

@@ -120,3 +120,38 @@ def test_parameter_gradients_under_ddp_need_ddp_average():
         np.testing.assert_allclose(grad, single, rtol=1e-5)            # averaged by DDP, scaled back by ddp_average
     for rank, grad in _run(_ddp_worker, (feats, False)):
         np.testing.assert_allclose(grad * 2, single, rtol=1e-5)        # without it: world_size times too small
+
+
+def _module_worker(rank, world, port, x_np, y_np, dims, q):
+    """sharded_sot_loss end to end on CPU tensors: module -> per-row losses (the package's torch-op route) -> reduction."""
+    _init(rank, world, port)
+    from sot_amd.distributed import shard_rows, sharded_sot_loss
+    from sot_amd.losses import Wasserstein1D
+    a, b = shard_rows(x_np.shape[0], rank, world)
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    pos = torch.linspace(0, 1, x_np.shape[-1])
+    yl = torch.tensor(y_np[a:b], requires_grad=True)
+    out = sharded_sot_loss(mod, torch.tensor(x_np[a:b]), yl, x_pos=pos, y_pos=pos.clone(), dims=dims)
+    w = torch.arange(1, out.numel() + 1, dtype=torch.float32).reshape(out.shape)
+    (out * w).sum().backward()
+    q.put((rank, out.detach().numpy().copy(), yl.grad.numpy().copy(), (a, b)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims", [None, [1]])
+def test_sharded_module_equals_single_process_module_world2(dims):
+    """The N > 1 path from the module down: two ranks with uneven row blocks of a [5, 3, 64] batch give the loss and
+    the input gradients of one process on the whole batch."""
+    from sot_amd.losses import Wasserstein1D
+    g = torch.Generator().manual_seed(11)
+    x, y = torch.rand(5, 3, 64, generator=g) ** 4, torch.rand(5, 3, 64, generator=g) ** 4
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    pos = torch.linspace(0, 1, 64)
+    yf = y.clone().requires_grad_(True)
+    want = mod(x, yf, x_pos=pos, y_pos=pos.clone(), dims=dims)
+    w = torch.arange(1, want.numel() + 1, dtype=torch.float32).reshape(want.shape)
+    (want * w).sum().backward()
+    for rank, got, grad, (a, b) in _run(_module_worker, (x.numpy(), y.numpy(), dims)):
+        np.testing.assert_allclose(got, want.detach().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(grad, yf.grad.numpy()[a:b], rtol=2e-5, atol=1e-9)

@@ -101,8 +101,9 @@ def test_gradients_only_where_requested():
 
 @pytest.mark.gpu
 def test_float64_inputs_are_accepted_like_the_reference():
-    """inputs may be float64 (the reference promotes, utils.py:135-142).  Here they are computed in float32 and the
-    result -- value and gradient -- comes back in float64, with one warning."""
+    """inputs may be float64 (the reference promotes, utils.py:135-142) and are then computed IN float64: float64 GPU
+    tensors take the package's torch-op route (one warning), value and gradient come back in float64 and agree with the HIP
+    float32 evaluation to float32 accuracy; float64 CPU tensors give the same float64 numbers (ATen CPU vs GPU: ~1e-12)."""
     import warnings
     from sot_amd.losses import Wasserstein1D, wasserstein_1d
     native()
@@ -112,18 +113,25 @@ def test_float64_inputs_are_accepted_like_the_reference():
     y = torch.rand(9, 300, device=dev, generator=g, dtype=torch.float64).requires_grad_(True)
     pos = torch.linspace(0, 1, 300, device=dev, dtype=torch.float64)
     mod = Wasserstein1D(p=2, square_dist=True).to(dev)
-    with warnings.catch_warnings(record=True) as caught:
+    with warnings.catch_warnings(record=True):
         warnings.simplefilter("always")
         out = mod(x, y, x_pos=pos, y_pos=pos.clone())
-    assert out.dtype == torch.float64
+    assert out.dtype == torch.float64 and out.is_cuda
     out.backward()
     assert y.grad is not None and y.grad.dtype == torch.float64 and torch.isfinite(y.grad).all()
     y32 = y.detach().float().requires_grad_(True)
-    ref = mod(x.float(), y32, x_pos=pos.float(), y_pos=pos.float().clone())
+    ref = mod(x.float(), y32, x_pos=pos.float(), y_pos=pos.float().clone())   # the HIP kernels
     ref.backward()
-    assert float(out) == float(ref) and torch.equal(y.grad.float(), y32.grad)
+    assert abs(float(out) - float(ref)) <= 2e-5 * abs(float(out))
+    assert float((y.grad.float() - y32.grad).abs().max()) <= 2e-3 * float(y32.grad.abs().max())
+    yc = y.detach().cpu().requires_grad_(True)
+    cpu = mod.cpu()(x.cpu(), yc, x_pos=pos.cpu(), y_pos=pos.cpu().clone())
+    mod.to(dev)
+    assert abs(float(cpu) - float(out)) <= 1e-10 * abs(float(out))
     rows = wasserstein_1d(pos.expand(9, 300), pos.expand(9, 300), x / x.sum(1, keepdim=True), y.detach() / y.detach().sum(1, keepdim=True))
     assert rows.dtype == torch.float64 and rows.shape == (9,)
+    rows_m = mod.row_losses(x, y.detach(), x_pos=pos, y_pos=pos)
+    assert rows_m.dtype == torch.float64 and rows_m.shape == (9,)
 
 
 @pytest.mark.parametrize("case", ["shared_sorted_p1", "shared_unsorted_p2_cutoff", "rows_unsorted_p2", "rows_p3_nm", "positions_only_mean"])

@@ -963,7 +963,7 @@ def test_p1_same_grid_merge_free_kernel(N, B, flags):
         xd, yd, pd = x.to(dev), y.to(dev), pos.to(dev)
         pd2 = pd.clone()
         plan = nat.PositionPlan(pd, pd2)
-        assert plan.same_grid
+        assert plan.same_grid()
         f = flags | nat.FLAG_REQUIRE_SORT
         area = nat.forward_rows(xd, yd, pd, pd2, 1.0, f, plan).cpu().numpy().astype(np.float64)
         merge = nat.forward_rows(xd, yd, pd, pd2, 1.0, f | nat.FLAG_NO_AREA, plan).cpu().numpy().astype(np.float64)
@@ -991,13 +991,13 @@ def test_p1_same_grid_dispatch_conditions():
     pos = torch.linspace(0, 1, N)[perm]                      # unsorted, same on both sides
     pd, pd2 = pos.to(dev), pos.to(dev).clone()
     plan = nat.PositionPlan(pd, pd2)
-    assert plan.same_grid
+    assert plan.same_grid()
     got = nat.forward_rows(xd, yd, pd, pd2, 1.0, 8, plan).cpu().numpy()
     want = so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=1.0, flags=8)
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-12)
     other = torch.sort(torch.rand(N, generator=torch.Generator().manual_seed(2))).values.to(dev)
     plan2 = nat.PositionPlan(torch.linspace(0, 1, N, device=dev), other)
-    assert not plan2.same_grid
+    assert not plan2.same_grid()
     lin = torch.linspace(0, 1, N, device=dev)
     plan3 = nat.PositionPlan(lin, lin.clone())
     for p, f in ((2.0, 8), (1.0, 8 | 4), (2.0, 15)):         # p = 2 / cutoff: the flag changes nothing

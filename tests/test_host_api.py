@@ -70,9 +70,12 @@ def test_module_surface_matches_reference():
         m(torch.rand(2, 8), torch.rand(2, 8))
     with pytest.raises(AssertionError, match="only valid for p>=1"):
         Wasserstein1D(p=0.5, fixed_x=8)(torch.rand(2, 8), torch.rand(2, 8))
-    # no CPU path: a CPU tensor is a loud error, not a fallback
+    # CPU tensors take the package's torch-op route (the reference is device-agnostic, losses.py:129-211): tests/test_cpu_path.py;
+    # the NATIVE layer has no CPU path and says so
+    assert m2(torch.rand(2, 257), torch.rand(2, 257)).ndim == 0
     with pytest.raises(RuntimeError, match="no CPU path"):
-        m2(torch.rand(2, 257), torch.rand(2, 257))
+        from sot_amd import _native as nat
+        nat.require_hip(torch.rand(3))
     with pytest.raises(TypeError, match="float32"):
         from sot_amd import _native as nat
         nat.require_hip(_FakeCuda())  # fp64 "GPU tensor": the dtype check fires without a GPU
