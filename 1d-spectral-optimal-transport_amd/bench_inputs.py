@@ -22,11 +22,30 @@ def spectrum_pairs(kind: str, rows: int, n: int, m: int, seed: int):
     return x.contiguous(), y.contiguous()
 
 
+def dyadic_pairs(rows: int, n: int, seed: int):
+    """Weights k / 32, k in 0..31 (SURVEY Appendix B.1 iii): they and their squares sum exactly in float32 in ANY order for rows of
+    up to 2^14 points, so the row mass -- and the cutoff's knife edge -- does not depend on who sums.  x drawn before y."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, 32, (rows, n), generator=g).float() / 32
+    y = torch.randint(0, 32, (rows, n), generator=g).float() / 32
+    return x.contiguous(), y.contiguous()
+
+
+def dyadic_ragged_supports(rows: int = 8192, n: int = 512, seed: int = 4242):
+    """BASELINE config 4's ragged supports on dyadic weights: the same dict as ragged_supports()."""
+    x, y = dyadic_pairs(rows, n, seed)
+    return _ragged(x, y, rows, n, seed)
+
+
 def ragged_supports(rows: int = 8192, n: int = 512, seed: int = 1234):
     """BASELINE config 4.  Returns dict(dense=(xm, ym), csr=((xw, xp, xoff), (yw, yp, yoff)), max_n, max_m, pos, kept)
     on the CPU: masked-dense rows (entries below the row's threshold set to 0) and the same supports in CSR form
     (concatenated kept weights and their positions, int64 offsets [rows + 1])."""
     x, y = spectrum_pairs("peaky", rows, n, n, seed)
+    return _ragged(x, y, rows, n, seed)
+
+
+def _ragged(x, y, rows, n, seed):
     g = torch.Generator().manual_seed(seed)
     tau = 10 ** (-3 + 2.7 * torch.rand(rows, 1, generator=g))
     keep_x, keep_y = x >= tau * x.amax(1, keepdim=True), y >= tau * y.amax(1, keepdim=True)

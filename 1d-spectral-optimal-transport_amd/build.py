@@ -59,12 +59,13 @@ def is_stale() -> bool:
         return f.read().strip() != source_digest()
 
 
-def _compile_part(part, extra_flags, verbose: bool) -> str:
+def _compile_part(part, extra_flags, verbose: bool, obj_dir: str = None) -> str:
+    obj_dir = obj_dir or OBJ_DIR
     if part in ("stft", "osc"):
-        obj = os.path.join(OBJ_DIR, f"sot_{part}.o")
+        obj = os.path.join(obj_dir, f"sot_{part}.o")
         cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, STFT_SRC if part == "stft" else OSC_SRC]
     else:
-        obj = os.path.join(OBJ_DIR, f"sot_part{part}.o")
+        obj = os.path.join(obj_dir, f"sot_part{part}.o")
         cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-DSOT_PART={part}", "-c", "-o", obj, SRC]
     if verbose:
         print(" ".join(cmd))
@@ -75,25 +76,42 @@ def _compile_part(part, extra_flags, verbose: bool) -> str:
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
-    """Compile every kernel instantiation for gfx950 and link libsot_hip.so (parts built in parallel)."""
+    """Compile every kernel instantiation for gfx950 and link libsot_hip.so (parts built in parallel).
+
+    One builder at a time per tree (an exclusive lock on a file next to the library: several ranks that find the library
+    stale at once would otherwise compile into the same object files).  The digest is removed before anything is
+    overwritten and only written back for a flag-free build into the product path, so a diagnostic build (extra_flags)
+    that lands on libsot_hip.so is never mistaken for the product library by is_stale()."""
+    import fcntl
     from concurrent.futures import ThreadPoolExecutor
     lib = out or LIB
     if not force and out is None and not is_stale():
         return lib
     os.makedirs(OBJ_DIR, exist_ok=True)
-    workers = max(1, min(len(PARTS), (os.cpu_count() or 2)))
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose), (*PARTS, "stft", "osc")))
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
-    os.replace(lib + ".tmp", lib)
-    if out is None and not extra_flags:
-        with open(DIGEST, "w") as f:
-            f.write(source_digest() + "\n")
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and out is None and not is_stale():   # another process built it while this one waited
+            return lib
+        if out is None and os.path.exists(DIGEST):
+            os.remove(DIGEST)
+        # diagnostic variants (out / extra_flags) get their own object directory: they never mix with the product objects
+        obj_dir = OBJ_DIR if (out is None and not extra_flags) else os.path.join(OBJ_DIR, "variant_%d" % os.getpid())
+        os.makedirs(obj_dir, exist_ok=True)
+        workers = max(1, min(len(PARTS), (os.cpu_count() or 2)))
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose, obj_dir), (*PARTS, "stft", "osc")))
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+        os.replace(lib + ".tmp", lib)
+        if obj_dir != OBJ_DIR:
+            shutil.rmtree(obj_dir, ignore_errors=True)
+        if out is None and not extra_flags:
+            with open(DIGEST, "w") as f:
+                f.write(source_digest() + "\n")
     return lib
 
 

@@ -34,15 +34,51 @@ def analysis_window(name, n_fft: int, device) -> torch.Tensor:
     return torch.as_tensor(get_window(name, n_fft), dtype=torch.float32, device=device)
 
 
-_WINDOWS = {}
+class _DeviceTableCache:
+    """Process-wide cache of small device tables (analysis windows, Hann upsampling windows, synthesiser tap tables).  A table
+    is produced by work enqueued on the stream that first asks for it; like nat.PositionPlan it therefore carries a ready
+    event that other streams wait on, and it is never CREATED while a stream capture is in progress (an H2D copy would
+    invalidate the capture, and memory from a graph's private pool must not outlive it): a capture that needs a missing
+    table gets it uncached when device work alone builds it (built by captured work, owned by that graph's replay) and an
+    error when host data would have to be copied."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, key, device, make, host_side=False):
+        """host_side: `make` copies host data to the device (cannot happen inside a capture: the caller must have used the
+        table once outside it, as any warm-up step does)."""
+        hit = self.entries.get(key)
+        if hit is not None:
+            table, ready, stream = hit
+            if ready is not None:
+                from . import _native as nat
+                if nat.stream_ptr(table.device) != stream:
+                    torch.cuda.current_stream(table.device).wait_event(ready)
+            return table
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            table = make()
+            self.entries[key] = (table, None, None)
+            return table
+        if torch.cuda.is_current_stream_capturing():
+            if host_side:
+                raise RuntimeError(f"sot_amd: table {key} is built from host data and is not cached yet; run the step once outside "
+                                   "the stream capture first")
+            return make()   # not cached: see the class docstring
+        from . import _native as nat
+        table = make()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(table.device))
+        self.entries[key] = (table, ready, nat.stream_ptr(table.device))
+        return table
+
+
+_WINDOWS = _DeviceTableCache()
 
 
 def _cached_window(name, n_fft: int, device) -> torch.Tensor:
-    key = (str(name), int(n_fft), str(device))
-    w = _WINDOWS.get(key)
-    if w is None:
-        w = _WINDOWS[key] = analysis_window(name, n_fft, device)
-    return w
+    return _WINDOWS.get((str(name), int(n_fft), str(device)), device, lambda: analysis_window(name, n_fft, device), host_side=True)
 
 
 class _StftMagnitude(torch.autograd.Function):
@@ -158,27 +194,21 @@ def upsample_linear(frames: torch.Tensor, n_samples: int) -> torch.Tensor:
     return y.permute(0, 2, 1).contiguous()
 
 
-_HANN = {}
+_HANN = _DeviceTableCache()
 
 
 def _hann_on(device, hop: int) -> torch.Tensor:
     """torch.hann_window(2 hop) as the CPU computes it (the reference's dataset is synthesised on the CPU), resident on `device`."""
-    key = (str(device), hop)
-    if key not in _HANN:
-        _HANN[key] = torch.hann_window(2 * hop).to(device)
-    return _HANN[key]
+    return _HANN.get((str(device), hop), device, lambda: torch.hann_window(2 * hop).to(device), host_side=True)
 
 
-_TAPS = {}
+_TAPS = _DeviceTableCache()
 
 
 def _tap_tables_on(window: torch.Tensor, frames: int, n_samples: int) -> torch.Tensor:
     """The synthesiser backward's weight tables for this frame / sample count (they depend on nothing else), built once per device."""
     from . import _native as nat
-    key = (str(window.device), frames, n_samples)
-    if key not in _TAPS:
-        _TAPS[key] = nat.synth_tap_tables(window, frames, n_samples)
-    return _TAPS[key]
+    return _TAPS.get((str(window.device), frames, n_samples), window.device, lambda: nat.synth_tap_tables(window, frames, n_samples))
 
 
 def _envelope_kernels_apply(amplitudes, frequencies, n_samples, harmonic) -> bool:

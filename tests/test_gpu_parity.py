@@ -881,11 +881,25 @@ def test_config4_full_size_csr_equals_masked_dense(mode):
     print(f"config 4 {mode}: batch means {d.mean():.9g} (masked dense) {c.mean():.9g} (CSR), rows differing by > 1e-5: {flips:.4f}, "
           f"median rel {np.median(rel):.2e}")
     if mode == "cutoff":
-        # knife edge: the two forms ARE different inputs to torch.sum (zeros removed -> another cascade order ->
-        # S differs by an ulp in part of the rows), and a level at U_last == 1 +- ulp carries percents of such a row's
-        # loss.  Each form is pinned separately: dense against the reference's scalars (test above), CSR against the
-        # oracle on the ragged rows (below); here only the bulk agreement is asserted.
+        # Two effects separate the forms in the paper's mode (round 3, found with the dyadic fixtures below):
+        #  (1) by the reference's OWN semantics they are different problems under dont_normalize: the levels between V_last and
+        #      U_last take ys[m - 1] (the clamp of losses.py:220) -- the grid's last point in the masked-dense rows, the last KEPT
+        #      point in the ragged rows.  That is the bulk of the rows that differ, and it is not a rounding matter;
+        #  (2) the knife edge: zeros removed -> another cascade order of torch.sum -> S differs by an ulp in part of
+        #      the rows, and a level at U_last == 1 +- ulp carries percents of such a row's loss.
+        # Keeping the grid's last point in the CSR rows (weight 0 where it fell below the threshold) removes (1); what is left is (2).
         assert np.median(rel) <= 1e-6 and flips <= 0.6 and abs(d.mean() - c.mean()) <= 2e-2 * abs(d.mean())
+        kx, ky = xm.cpu() > 0, ym.cpu() > 0
+        kx[:, -1] = True
+        ky[:, -1] = True
+        (aw, ap, ao), (bw, bp, bo) = _to_csr(xm.cpu(), rs["pos"], kx), _to_csr(ym.cpu(), rs["pos"], ky)
+        anch = wasserstein_1d_csr(aw.to(dev), ap.to(dev), ao.to(dev), bw.to(dev), bp.to(dev), bo.to(dev), int(kx.sum(1).max()),
+                                  int(ky.sum(1).max()), **kw).cpu().numpy().astype(np.float64)
+        rel_a = np.abs(d - anch) / np.maximum(np.abs(d), 1e-30)
+        flips_a = float(np.mean(rel_a > 1e-5))
+        print(f"config 4 cutoff, CSR with the grid's last point kept: rows differing from masked dense by > 1e-5: {flips_a:.4f}, "
+              f"batch means {d.mean():.9g} / {anch.mean():.9g}")
+        assert flips_a <= 0.15 and abs(d.mean() - anch.mean()) <= 2e-3 * abs(d.mean())   # the knife edge alone (observed: see DESIGN section 6)
     else:
         assert abs(d.mean() - c.mean()) <= 1e-5 * abs(d.mean()) and flips == 0.0
     for r in range(0, 8192, 512):   # oracle on the ragged rows themselves
@@ -935,7 +949,7 @@ def test_config5_full_size_training_step_matches_reference():
     print(f"config 5 @256 clips: loss rel {abs(float(loss.detach()) - want) / want:.2e}; rows off by > 1e-6: {np.mean(row_rel > 1e-6):.4f}; "
           f"clean clips {int(clean.sum())}/256: max grad err / clip peak {err[clean].max():.2e} (median {np.median(err[clean]):.2e}); "
           f"other clips: max {err[~clean].max() if (~clean).any() else 0:.2e}; overall cosine {cos:.6f}")
-    assert clean.sum() >= 64                                  # enough clean clips for the tight comparison to mean something
+    assert clean.sum() >= 119                                 # observed 133 of 256 (round 2 and 3) minus 10 %
     # clean clips: the gradient agrees with the reference's autograd (observed: median 1e-6 of the clip's peak, max 4e-4 -- a
     # tie between two levels may route a run's gradient to another member, a different valid subgradient)
     assert np.median(err[clean]) <= 5e-6 and np.percentile(err[clean], 99) <= 1e-4 and err[clean].max() <= 1e-3
@@ -1063,3 +1077,141 @@ def test_csr_backward_matches_oracle_on_the_ragged_rows(mode):
     with torch.no_grad():
         again = wasserstein_1d_csr(xw.to(dev), xp.to(dev), xo.to(dev), yw2, yp.to(dev), yo.to(dev), max_n, max_m, **kw)
     assert torch.equal(again, rows.detach())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Dyadic full-size fixtures (SURVEY Appendix B.1 iii; oracle/make_golden_dyadic.py -> tests/golden/dyadic_full_size.npz): weights
+# k/32 sum exactly in float32 in any order, so the row mass and the cutoff's knife edge are the same for the reference, for the
+# dense kernels and for the CSR form -- the comparisons that are "bulk only" on random inputs are row for row here.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _dyadic_fixture():
+    return np.load(os.path.join(GOLDEN, "dyadic_full_size.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["cutoff", "p1"])
+def test_config4_dyadic_dense_and_csr_match_the_reference_row_for_row(mode):
+    """BASELINE config 4 at full size (8192 x 512, ragged supports) on dyadic weights, against the reference's 8192 row losses
+    (computed on the zero-masked dense rows): EVERY row within 1e-5, cutoff mode included, for
+      * the masked-dense rows through the dense kernel,
+      * the CSR kernel on the kept points plus the grid's last point (kept as a zero-weight point when it fell below the row's
+        threshold): in dont_normalize mode the levels between V_last and U_last take ys[m - 1] (the clamp of losses.py:220), so
+        the last point of the support is part of the problem -- the plain ragged form (last KEPT point) is a different problem
+        there and is pinned to the oracle on the ragged rows themselves (every 8th row);
+      * p = 1 (both CDFs end at the same mass): the plain ragged CSR form as well."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import sha256_of
+    from sot_amd.bench_inputs import dyadic_ragged_supports
+    from sot_amd.losses import wasserstein_1d_csr
+    nat = native()
+    dev = device()
+    fx = _dyadic_fixture()
+    rs = dyadic_ragged_supports(8192, 512, int(fx["seed"]))
+    xm, ym = rs["dense"]
+    assert sha256_of(xm, ym) == bytes(fx["c4_inputs_sha256"]).hex(), "the seeded dyadic rows are not the fixture's"
+    kw = {"p1": dict(p=1), "cutoff": dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)}[mode]
+    flags = (1 if kw.get("square_dist") else 0) | (2 if kw.get("dont_normalize") else 0) | (4 if kw.get("limit_quantile_range") else 0) | 8
+    pos = rs["pos"]
+    (xw, xp, xo), (yw, yp, yo) = rs["csr"]
+    want = fx[f"c4_{mode}_rows"].astype(np.float64)
+    scale = np.maximum(np.abs(want), 1e-30)
+
+    def csr_rows(xw_, xp_, xo_, yw_, yp_, yo_):
+        mn, mm = int((xo_[1:] - xo_[:-1]).max()), int((yo_[1:] - yo_[:-1]).max())
+        return wasserstein_1d_csr(xw_.to(dev), xp_.to(dev), xo_.to(dev), yw_.to(dev), yp_.to(dev), yo_.to(dev), mn, mm,
+                                  **kw).cpu().numpy().astype(np.float64)
+
+    dense = nat.forward_rows(xm.to(dev), ym.to(dev), pos.to(dev), pos.to(dev).clone(), float(kw["p"]), flags).cpu().numpy().astype(np.float64)
+    kx, ky = xm > 0, ym > 0
+    kx[:, -1] = True
+    ky[:, -1] = True
+    anchored = csr_rows(*_to_csr(xm, pos, kx), *_to_csr(ym, pos, ky))
+    ragged = csr_rows(xw, xp, xo, yw, yp, yo)
+    rel_d, rel_a = np.abs(dense - want) / scale, np.abs(anchored - want) / scale
+    print(f"config 4 dyadic {mode}: dense max rel {rel_d.max():.2e}, CSR (last grid point kept) max rel {rel_a.max():.2e}, "
+          f"plain ragged CSR vs dense: rows differing by > 1e-5: {np.mean(np.abs(ragged - dense) / scale > 1e-5):.4f}")
+    assert rel_d.max() <= 1e-5, float(rel_d.max())          # 100 % of the rows
+    assert rel_a.max() <= 1e-5, float(rel_a.max())
+    assert abs(dense.mean() - float(fx[f"c4_{mode}_scalar"])) <= 2e-6 * abs(dense.mean())
+    if mode == "p1":
+        assert (np.abs(ragged - want) / scale).max() <= 1e-5
+    for r in range(0, 8192, 8):   # the plain ragged form against the oracle on the ragged rows themselves
+        a, b, e, f = int(xo[r]), int(xo[r + 1]), int(yo[r]), int(yo[r + 1])
+        w = so.forward(xw[a:b].numpy()[None], yw[e:f].numpy()[None], xp[a:b].numpy(), yp[e:f].numpy(), p=float(kw["p"]), flags=flags)[0]
+        assert abs(ragged[r] - w) <= 1e-5 * abs(w), (r, ragged[r], w)
+
+
+@pytest.mark.gpu
+def test_config5_sot_stage_dyadic_matches_the_reference_row_for_row():
+    """The SOT stage of BASELINE config 5 at its real size (4096 rows x 1025 bins, rfftfreq positions, paper mode) on dyadic
+    spectra: loss, ALL 4096 row losses (<= 1e-5 each: no knife-edge excuse when the row mass is order-independent) and the
+    gradient w.r.t. y -- against the oracle's closed form on a sample of rows (<= 1e-5 of the row's largest entry), and against
+    the reference's autograd sample wherever its unstable level sort happened to agree with the stable convention."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import sha256_of
+    from sot_amd import spectra
+    from sot_amd.bench_inputs import dyadic_pairs
+    fx = _dyadic_fixture()
+    x, y = dyadic_pairs(4096, 1025, int(fx["seed"]) + 1)
+    assert sha256_of(x, y) == bytes(fx["c5_inputs_sha256"]).hex()
+    dev = device()
+    ctor = dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    mod = module_for(ctor)
+    pos = spectra.unit_frequencies(2048, 16000.0, dev)
+    yd = y.to(dev).requires_grad_(True)
+    loss = mod(x.to(dev), yd, x_pos=pos, y_pos=pos.clone())
+    loss.backward()
+    want = float(fx["c5_scalar"])
+    assert abs(float(loss.detach()) - want) <= 2e-6 * abs(want), (float(loss.detach()), want)
+    with torch.no_grad():
+        rows = mod.row_losses(x.to(dev), y.to(dev), x_pos=pos, y_pos=pos.clone()).cpu().numpy().astype(np.float64)
+    ref_rows = fx["c5_rows"].astype(np.float64)
+    rel = np.abs(rows - ref_rows) / np.maximum(ref_rows, 1e-30)
+    assert rel.max() <= 1e-5, float(rel.max())               # 100 % of the rows
+    got = yd.grad.cpu().numpy()
+    p, flags = ctor_to_flags(ctor)
+    pn = pos.cpu().numpy()
+    for r in range(0, 4096, 64):
+        _, gy = so.backward(x[r:r + 1].numpy(), y[r:r + 1].numpy(), pn, pn, np.full(1, 1.0 / 4096, np.float32), p=p, flags=flags)
+        assert np.abs(got[r] - gy[0]).max() <= 1e-5 * np.abs(gy[0]).max(), r
+    stride = int(fx["stride"])
+    ref = fx["c5_grad_y_sample"].astype(np.float64)
+    err = np.abs(got[:, ::stride] - ref) / fx["c5_grad_y_rowmax"].astype(np.float64)[:, None]
+    print(f"config 5 SOT stage, dyadic: rows max rel {rel.max():.2e}; gradient vs the reference's autograd sample: median {np.median(err):.2e}, "
+          f"entries within 1e-5 of the row max: {np.mean(err <= 1e-5):.4f}")
+    assert np.median(err) <= 1e-6   # ties (zero-weight bins) may route a run's gradient elsewhere in the reference's unstable sort
+
+
+@pytest.mark.gpu
+def test_csr_backward_dyadic_cutoff_matches_the_oracle_on_every_checked_row():
+    """test_csr_backward_matches_oracle_on_the_ragged_rows[cutoff] without the knife-edge allowance: dyadic weights make the padded
+    rows' mass equal the ragged rows' mass exactly, so EVERY checked row must agree with the oracle's backward."""
+    from oracle import sot_oracle as so
+    from sot_amd.bench_inputs import dyadic_pairs
+    from sot_amd.losses import wasserstein_1d_csr
+    native()
+    dev = device()
+    B, N = 96, 257
+    x, y = dyadic_pairs(B, N, 91)
+    g = torch.Generator().manual_seed(91)
+    tau = 10 ** (-3 + 2.7 * torch.rand(B, 1, generator=g))
+    kx, ky = (x >= tau * x.amax(1, keepdim=True)) & (x > 0), (y >= tau * y.amax(1, keepdim=True)) & (y > 0)
+    pos = torch.linspace(0, 1, N)
+    ctor = dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)
+    p, flags = ctor_to_flags(ctor)
+    xw, xp, xo = _to_csr(x, pos, kx)
+    yw, yp, yo = _to_csr(y, pos, ky)
+    max_n, max_m = int(kx.sum(1).max()), int(ky.sum(1).max())
+    xwd, ywd = xw.to(dev).requires_grad_(True), yw.to(dev).requires_grad_(True)
+    upstream = torch.rand(B, generator=g)
+    rows = wasserstein_1d_csr(xwd, xp.to(dev), xo.to(dev), ywd, yp.to(dev), yo.to(dev), max_n, max_m, **ctor)
+    (rows * upstream.to(dev)).sum().backward()
+    gx, gy = xwd.grad.cpu().numpy(), ywd.grad.cpu().numpy()
+    for r in range(B):
+        xr, yr = x[r][kx[r]][None].numpy(), y[r][ky[r]][None].numpy()
+        want_row = so.forward(xr, yr, pos[kx[r]].numpy(), pos[ky[r]].numpy(), p=p, flags=flags)[0]
+        assert abs(float(rows[r]) - want_row) <= 1e-5 * abs(want_row), r
+        wx, wy = so.backward(xr, yr, pos[kx[r]].numpy(), pos[ky[r]].numpy(), upstream[r:r + 1].numpy(), p=p, flags=flags)
+        a, b = gx[int(xo[r]):int(xo[r + 1])], gy[int(yo[r]):int(yo[r + 1])]
+        scale = max(np.abs(wx).max(), np.abs(wy).max(), 1e-30)
+        assert np.abs(a - wx[0]).max() <= 2e-5 * scale and np.abs(b - wy[0]).max() <= 2e-5 * scale, r

@@ -143,3 +143,46 @@ def test_scipy_cross_check_unsorted_positions():
     got = so.forward(x, y, xp, yp, p=1, flags=so.make_flags())
     want = [wasserstein_distance(xp[r], yp[r], x[r], y[r]) for r in range(4)]
     np.testing.assert_allclose(got, want, rtol=5e-6)
+
+
+def test_oracle_matches_the_reference_on_the_dyadic_full_size_fixtures():
+    """tests/golden/dyadic_full_size.npz (oracle/make_golden_dyadic.py: the reference on dyadic weights, SURVEY B.1 iii): the C
+    oracle reproduces the reference's row losses bit for bit on the masked-dense config-4 rows and on the config-5 SOT stage
+    (a strided sample of rows each: the oracle is a single-threaded checker), and its result does not depend on whether the
+    zero-weight points of a ragged row are present (the CSR form) -- exactly, which is what makes these fixtures a fair
+    100 %-of-rows test for the CSR kernel in cutoff mode."""
+    import os
+    from conftest import GOLDEN
+    from oracle.inputs import sha256_of
+    from sot_amd.bench_inputs import dyadic_pairs, dyadic_ragged_supports
+    fx = np.load(os.path.join(GOLDEN, "dyadic_full_size.npz"))
+    rs = dyadic_ragged_supports(8192, 512, int(fx["seed"]))
+    xm, ym = rs["dense"]
+    assert sha256_of(xm, ym) == bytes(fx["c4_inputs_sha256"]).hex()
+    pos = rs["pos"].numpy()
+    (xw, xp, xo), (yw, yp, yo) = rs["csr"]
+    sel = np.arange(0, 8192, 37)
+    for mode, (p, flags) in (("cutoff", (2.0, so.make_flags(True, True, True, True))), ("p1", (1.0, so.make_flags()))):
+        rows = so.forward(xm.numpy()[sel], ym.numpy()[sel], pos, pos, p=p, flags=flags)
+        assert (bits(rows) == bits(fx[f"c4_{mode}_rows"][sel])).all(), mode
+        for r in sel[:40]:
+            a, b, e, f = int(xo[r]), int(xo[r + 1]), int(yo[r]), int(yo[r + 1])
+            want = fx[f"c4_{mode}_rows"][r]
+            ragged = so.forward(xw[a:b].numpy()[None], yw[e:f].numpy()[None], xp[a:b].numpy(), yp[e:f].numpy(), p=p, flags=flags)[0]
+            # the same supports with the grid's LAST point kept as a zero-weight point on both sides
+            xr, xq = np.append(xw[a:b].numpy(), np.float32(0)), np.append(xp[a:b].numpy(), pos[-1])
+            yr, yq = np.append(yw[e:f].numpy(), np.float32(0)), np.append(yp[e:f].numpy(), pos[-1])
+            anchored = so.forward(xr[None], yr[None], xq, yq, p=p, flags=flags)[0]
+            assert abs(anchored - want) <= 2e-6 * abs(want), (mode, r, anchored, want)   # same levels, other summation order of the terms
+            if mode == "p1":   # both CDFs end at the same mass: no level ever clamps to the last point, removed points are inert
+                assert abs(ragged - want) <= 2e-6 * abs(want), (mode, r, ragged, want)
+    # (dont_normalize: when y carries less mass than x, the levels between V_last and U_last take ys[m - 1] -- losses.py:220's clamp --
+    #  which is the grid's last point in the masked-dense form and the last KEPT point in the ragged form: there the two forms are
+    #  different problems by the reference's own semantics, not a rounding matter; `anchored` above is the ragged form of the dense one.)
+    x, y = dyadic_pairs(4096, 1025, int(fx["seed"]) + 1)
+    assert sha256_of(x, y) == bytes(fx["c5_inputs_sha256"]).hex()
+    f = torch.fft.rfftfreq(2048, d=1.0 / 16000.0)
+    p5 = (f / f.max()).float().numpy()
+    sel = np.arange(0, 4096, 29)
+    rows = so.forward(x.numpy()[sel], y.numpy()[sel], p5, p5, p=2.0, flags=so.make_flags(True, True, True, True))
+    assert (bits(rows) == bits(fx["c5_rows"][sel])).all()
