@@ -22,9 +22,9 @@ LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # sot_hip.hip is compiled in parts (-DSOT_PART=<bit>) in parallel and linked into one shared library:
-# forward/shared positions (no cutoff, cutoff), full-row forward, forward/per-row positions, backward/shared,
-# backward/per-row, everything else, CSR forward.
-PARTS = (1, 64, 128, 2, 4, 8, 16, 32)
+# compile-time-length forward and backward kernels, forward/shared positions (no cutoff, cutoff), forward/per-row positions,
+# backward/shared, backward/per-row, everything else, CSR forward.
+PARTS = (128, 256, 1, 64, 2, 4, 8, 16, 32)   # the two longest first
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "obj")
 
 

@@ -24,9 +24,9 @@
 // kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
 // positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI),
 // bit 5 the CSR (ragged) forward, bit 6 the cutoff (limit_quantile_range) family of forward/shared positions (bit 0 then
-// holds the no-cutoff family), bit 7 the full-row forward (n == m == G*CPT, everything at compile time).
+// holds the no-cutoff family), bit 7 the compile-time-length forward kernels, bit 8 the compile-time-length backward kernels.
 #ifndef SOT_PART
-#define SOT_PART 255
+#define SOT_PART 511
 #endif
 // Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
 // search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
@@ -1273,7 +1273,16 @@ template hipError_t dispatch_forward<true>(const LaunchCfg&, bool, int, bool, co
 #endif
 #endif  // forward parts
 
-#if SOT_PART & 128
+// bit 7: the compile-time-length forward kernels (merge and merge-free), bit 8: the compile-time-length backward kernels.  Diagnostic
+// single-file builds (SOT_STUB_MISSING_PARTS: tools/) select both with bit 7 alone, as before the split.
+#if defined(SOT_STUB_MISSING_PARTS) && (SOT_PART & 128)
+#define SOT_FULL_FWD 1
+#define SOT_FULL_BWD 1
+#else
+#define SOT_FULL_FWD ((SOT_PART & 128) != 0)
+#define SOT_FULL_BWD ((SOT_PART & 256) != 0)
+#endif
+#if SOT_FULL_FWD || SOT_FULL_BWD
 #include "sot_forward_full.inc"
 #endif
 
@@ -1520,7 +1529,7 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
     if (mean_tail != nullptr && row_loss != nullptr) l.a.mt = *mean_tail;  // the batch mean comes out of this launch's last workgroup
     l.a.oUq = uq; l.a.oVq = vq; l.a.oQ = Q; l.a.oU = U; l.a.oV = V;
     // row lengths with a compile-time kernel (forward_full_supports: powers of two 512 ... 8192 and n_fft/2 + 1) take it
-    bool full = !l.rowpos && !quant && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && forward_full_supports(pr->n, l.vec) &&
+    bool full = !l.rowpos && !quant && pr->n == pr->m && forward_full_supports(pr->n, l.vec) &&
                 !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;
@@ -1550,7 +1559,7 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
     // row lengths with a compile-time kernel take it (as in run_forward)
     const bool aligned16 = l.vec && (gx == nullptr || (reinterpret_cast<uintptr_t>(gx) & 15) == 0) &&
                            (gy == nullptr || (reinterpret_cast<uintptr_t>(gy) & 15) == 0);
-    bool full = !l.rowpos && (l.pm == 1 || l.pm == 2) && pr->n == pr->m && backward_full_supports(pr->n, aligned16) &&
+    bool full = !l.rowpos && pr->n == pr->m && backward_full_supports(pr->n, aligned16) &&
                 !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;

@@ -246,22 +246,22 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         torch.cuda.synchronize()
         return 1e6 * host / count
 
-    class _Nothing(torch.autograd.Function):
+    class _Nothing(torch.autograd.Function):   # no kernel: the forward hands out a preallocated scalar, the backward a fresh (uninitialised) gradient
         @staticmethod
-        def forward(ctx, v, out, grad):
-            ctx.grad = grad
+        def forward(ctx, v, out):
+            ctx.shape = v.shape
             return out.view_as(out)
 
         @staticmethod
         def backward(ctx, g):
-            return ctx.grad, None, None
+            return torch.empty(ctx.shape, device=g.device), None
 
-    zero_out, zero_grad = torch.zeros((), device=dev), torch.zeros(1024, 1025, device=dev)
+    zero_out = torch.zeros((), device=dev)
 
     def floor_step(i):
         yv = ys1[i % 2]
         yv.grad = None
-        _Nothing.apply(yv, zero_out, zero_grad).backward()
+        _Nothing.apply(yv, zero_out).backward()
 
     e = entry(timed(paper_step, n), "autograd: loss_and_grad (sot_backward_full_kernel<128, 9, 2, ..., 1025, false, true, 4> + mean) + scale",
               1024 * (12 * 1025 + 4), l3_resident=True)
@@ -272,7 +272,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         out["b1024n1025_cutoff_module_forward"] = entry(timed(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), n),
                                                          forward_kernel_name(1025, "cutoff") + " + batch mean", 1024 * (8 * 1025 + 4), l3_resident=True)
         out["b1024n1025_cutoff_module_forward"]["host_us_per_call"] = wall_us(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), 400)
-    del xs1, ys1, zero_grad
+    del xs1, ys1
 
     # (2) the paper's own row shape: one-sided spectra of n_fft 2048 (1025 bins), 16384 rows, rfftfreq / max positions
     g = torch.Generator(device=dev).manual_seed(7)

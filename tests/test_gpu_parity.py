@@ -106,7 +106,7 @@ def test_config2_full_size_scalars(kind, mode, manifest):
 
 
 @pytest.mark.parametrize("N,B", [(512, 1030), (1024, 777), (2048, 520), (4096, 130), (8192, 70)])
-@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 def test_full_row_kernel_matches_generic(N, B, flags, p):
     """Rows that fill their launch geometry (n == m == G*CPT) run the fully specialised forward kernel: it must agree
     bit for bit with the generic kernel (SOT_FLAG_NO_SPECIALIZE) and, on a sample of rows, with the oracle.  (4096 bins:
@@ -122,8 +122,8 @@ def test_full_row_kernel_matches_generic(N, B, flags, p):
     plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
     spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
     gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
-    if N == 4096:
-        torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
+    if N == 4096 or p not in (1.0, 2.0):   # general p (round 3: compile-time-length kernels with powf in the walk): same terms, the
+        torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)   # loser-form walk may evaluate |a - b| as |b - a| -> same value
     else:
         assert torch.equal(spec, gen), float((spec - gen).abs().max())
     k = min(B, 24)
@@ -132,7 +132,7 @@ def test_full_row_kernel_matches_generic(N, B, flags, p):
 
 
 @pytest.mark.parametrize("N,B", [(512, 530), (1024, 301), (2048, 200), (4096, 67)])
-@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
     """The specialised backward kernel (rows with n == m == 512 / 2048) gives bit for bit the gradients of the generic
     kernel, and the oracle's closed form on a sample of rows."""
@@ -147,7 +147,11 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
     g = torch.linspace(0.5, 1.5, B).to(device())
     sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g, plan=plan, grad_scale=0.25)
     gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g, plan=plan, grad_scale=0.25)
-    assert torch.equal(sx, gx) and torch.equal(sy, gy), (float((sx - gx).abs().max()), float((sy - gy).abs().max()))
+    if p in (1.0, 2.0):
+        assert torch.equal(sx, gx) and torch.equal(sy, gy), (float((sx - gx).abs().max()), float((sy - gy).abs().max()))
+    else:   # general p: the same closed form on powf costs
+        for got, ref in ((sx, gx), (sy, gy)):
+            assert float(((got - ref).abs() / (ref.abs().amax(dim=1, keepdim=True) + 1e-30)).max()) <= 2e-6
     only_y = nat.backward_rows(x, y, pos, pos2, p, flags, g, need_gx=False, plan=plan, grad_scale=0.25)
     assert only_y[0] is None and torch.equal(only_y[1], sy)
     k = min(B, 6)
@@ -159,7 +163,7 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
 
 
 @pytest.mark.parametrize("N,B", [(129, 1500), (257, 1031), (513, 300), (1025, 261), (2049, 133)])
-@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 2 | 4 | 8, 2.0), (2, 2.0)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 2 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 @pytest.mark.parametrize("kind", ["peaky", "uniform"])
 def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
     """n_fft 512 / 1024 / 2048 -> 257 / 513 / 1025 bins run a forward kernel with the row length at compile time (other
@@ -183,7 +187,7 @@ def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
 
 
 @pytest.mark.parametrize("N,B", [(129, 90), (257, 70), (513, 37), (1025, 29), (2049, 21)])
-@pytest.mark.parametrize("flags,p", [(0, 1.0), (1 | 2 | 4, 2.0), (1 | 4 | 8, 2.0), (2, 1.0)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1 | 2 | 4, 2.0), (1 | 4 | 8, 2.0), (2, 1.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 def test_paper_row_lengths_backward(N, B, flags, p):
     """Backward kernel with the row length at compile time (257 / 513 / 1025 bins): gradients equal to the generic kernel's
     (same closed form; the fp64 suffix sums are associated differently) and to the oracle's."""
@@ -319,8 +323,8 @@ def test_known_answers_and_errors():
         Wasserstein1D(p=0.5)(a, b, x_pos=pos, y_pos=pos)
     with pytest.raises(AssertionError):
         wasserstein_1d(pos[None], pos[None], a, b, p=0.5)
-    with pytest.raises(RuntimeError):
-        Wasserstein1D(p=1)(a.cpu(), b.cpu(), x_pos=pos.cpu(), y_pos=pos.cpu())
+    # CPU tensors take the package's torch-op route (tests/test_cpu_path.py) and give the same known answer
+    assert float(Wasserstein1D(p=1)(a.cpu(), b.cpu(), x_pos=pos.cpu(), y_pos=pos.cpu())) == float(d)
     # fixed_x buffer form (metrics.py:148) under inference_mode
     with torch.inference_mode():
         m = Wasserstein1D(p=2, fixed_x=n).to(dev)
