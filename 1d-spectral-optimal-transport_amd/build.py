@@ -24,7 +24,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
 # sot_hip.hip is compiled in parts (-DSOT_PART=<bit>) in parallel and linked into one shared library:
 # compile-time-length forward and backward kernels, forward/shared positions (no cutoff, cutoff), forward/per-row positions,
 # backward/shared, backward/per-row, everything else, CSR forward.
-PARTS = (128, 256, 1, 64, 2, 4, 8, 16, 32)   # the two longest first
+PARTS = (128, 256, 512, 1024, 1, 64, 2, 4, 8, 16, 32)   # the longest first (bits 7-10: compile-time-geometry kernels)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "obj")
 
 

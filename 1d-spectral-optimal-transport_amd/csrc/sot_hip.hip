@@ -26,7 +26,7 @@
 // bit 5 the CSR (ragged) forward, bit 6 the cutoff (limit_quantile_range) family of forward/shared positions (bit 0 then
 // holds the no-cutoff family), bit 7 the compile-time-length forward kernels, bit 8 the compile-time-length backward kernels.
 #ifndef SOT_PART
-#define SOT_PART 511
+#define SOT_PART 2047
 #endif
 // Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
 // search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
@@ -1138,6 +1138,10 @@ hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, 
 hipError_t dispatch_area_full(const FwdArgs& a, hipStream_t s);
 bool forward_full_supports(int n, bool aligned16);
 bool backward_full_supports(int n, bool aligned16);
+int full_rt_capacity(int n);   // capacity of the compile-time geometry that takes a run-time row length n (0: none)
+hipError_t dispatch_forward_full_rt(int pm, const FwdArgs& a, hipStream_t s);
+hipError_t dispatch_area_full_rt(const FwdArgs& a, hipStream_t s);
+hipError_t dispatch_backward_full_rt(int pm, const BwdArgs& b, hipStream_t s);
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                    hipStream_t s);
 int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
@@ -1170,6 +1174,14 @@ hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStre
 hipError_t dispatch_area_full(const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 bool forward_full_supports(int, bool) { return false; }
 bool backward_full_supports(int, bool) { return false; }
+int full_rt_capacity(int) { return 0; }
+#endif
+#if !(SOT_PART & 512)
+hipError_t dispatch_forward_full_rt(int, const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+hipError_t dispatch_area_full_rt(const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+#endif
+#if !(SOT_PART & 1024)
+hipError_t dispatch_backward_full_rt(int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 #endif
 #if !(SOT_PART & 32)
 int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const float*, const float*, const int64_t*, int64_t, int64_t, int,
@@ -1275,6 +1287,7 @@ template hipError_t dispatch_forward<true>(const LaunchCfg&, bool, int, bool, co
 
 // bit 7: the compile-time-length forward kernels (merge and merge-free), bit 8: the compile-time-length backward kernels.  Diagnostic
 // single-file builds (SOT_STUB_MISSING_PARTS: tools/) select both with bit 7 alone, as before the split.
+// Bits 9 / 10: the same kernels for a RUN-TIME row length (any n <= 8192 on the next capacity's geometry), forward / backward.
 #if defined(SOT_STUB_MISSING_PARTS) && (SOT_PART & 128)
 #define SOT_FULL_FWD 1
 #define SOT_FULL_BWD 1
@@ -1282,7 +1295,9 @@ template hipError_t dispatch_forward<true>(const LaunchCfg&, bool, int, bool, co
 #define SOT_FULL_FWD ((SOT_PART & 128) != 0)
 #define SOT_FULL_BWD ((SOT_PART & 256) != 0)
 #endif
-#if SOT_FULL_FWD || SOT_FULL_BWD
+#define SOT_FULL_RT_FWD ((SOT_PART & 512) != 0)
+#define SOT_FULL_RT_BWD ((SOT_PART & 1024) != 0)
+#if SOT_FULL_FWD || SOT_FULL_BWD || SOT_FULL_RT_FWD || SOT_FULL_RT_BWD
 #include "sot_forward_full.inc"
 #endif
 
@@ -1534,10 +1549,17 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;
 #endif
+    // every other row length up to 8192 on shared positions: the same kernels with the length at run time (full_rt_capacity)
+    bool full_rt = !full && !l.rowpos && !quant && pr->n == pr->m && full_rt_capacity(pr->n) != 0 &&
+                   !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
+#if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 512)
+    full_rt = false;
+#endif
     // p = 1 on one grid shared by both measures, no cutoff: the merge-free kernel (sot_forward_full.inc: sot_area_full_kernel)
-    const bool area = full && l.pm == 1 && (pr->flags & SOT_FLAG_SAME_GRID) && !(pr->flags & (SOT_FLAG_LIMIT_Q | SOT_FLAG_NO_AREA));
-    const hipError_t e = area       ? dispatch_area_full(l.a, l.s)
+    const bool area = (full || full_rt) && l.pm == 1 && (pr->flags & SOT_FLAG_SAME_GRID) && !(pr->flags & (SOT_FLAG_LIMIT_Q | SOT_FLAG_NO_AREA));
+    const hipError_t e = area       ? (full ? dispatch_area_full(l.a, l.s) : dispatch_area_full_rt(l.a, l.s))
                          : full     ? dispatch_forward_full(l.cfg, l.pm, l.a, l.lds, l.want, l.block, l.s)
+                         : full_rt  ? dispatch_forward_full_rt(l.pm, l.a, l.s)
                          : l.rowpos ? dispatch_forward<true>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s)
                                     : dispatch_forward<false>(l.cfg, quant, l.pm, l.vec, l.a, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
@@ -1564,12 +1586,18 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full = false;
 #endif
-    if (full && gx == nullptr && row_loss_out != nullptr) {   // the y-only full-row kernel accumulates the loss on its walk
+    bool full_rt = !full && !l.rowpos && pr->n == pr->m && full_rt_capacity(pr->n) != 0 && full_rt_capacity(pr->n) <= 4096 &&
+                   !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
+#if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 1024)
+    full_rt = false;
+#endif
+    if ((full || full_rt) && gx == nullptr && row_loss_out != nullptr) {   // the y-only full-row kernel accumulates the loss on its walk
         b.f.row_loss = row_loss_out;
         if (mean_tail != nullptr) b.f.mt = *mean_tail;
         if (fused) *fused = true;
     }
     const hipError_t e = full       ? dispatch_backward_full(l.cfg, l.pm, b, l.s)
+                         : full_rt  ? dispatch_backward_full_rt(l.pm, b, l.s)
                          : l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s)
                                     : dispatch_backward<false>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s);
     return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;

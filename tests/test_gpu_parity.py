@@ -1219,3 +1219,105 @@ def test_csr_backward_dyadic_cutoff_matches_the_oracle_on_every_checked_row():
         a, b = gx[int(xo[r]):int(xo[r + 1])], gy[int(yo[r]):int(yo[r + 1])]
         scale = max(np.abs(wx).max(), np.abs(wy).max(), 1e-30)
         assert np.abs(a - wx[0]).max() <= 2e-5 * scale and np.abs(b - wy[0]).max() <= 2e-5 * scale, r
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Run-time row lengths on the compile-time geometries (round 3; csrc/sot_forward_full.inc, NX = -1): every n == m <= 8192 on
+# shared positions that has no kernel of its own runs the next capacity's geometry, its tail padded with zero-weight points at
+# the row's last position.  Same results as the generic kernels (SOT_FLAG_NO_SPECIALIZE) and as the oracle.
+# ---------------------------------------------------------------------------------------------------------------------------
+RT_LENGTHS = [(130, 300), (200, 129), (256, 77), (300, 130), (500, 65), (511, 40), (640, 33), (1000, 70), (1023, 9), (1100, 21),
+              (2000, 37), (2047, 5), (3000, 11), (4095, 3), (5000, 7), (8191, 2)]
+
+
+@pytest.mark.parametrize("N,B", RT_LENGTHS)
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1 | 2 | 4, 2.0), (1 | 4 | 8, 2.0), (2, 1.0), (1, 3.0)])
+def test_runtime_length_forward_matches_generic_and_oracle(N, B, flags, p):
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    dev = device()
+    x, y = gen_inputs("peaky", B, N, N, 700 + N)
+    x, y = x.to(dev), y.to(dev)
+    pos = torch.sort(torch.rand(N, generator=torch.Generator().manual_seed(N))).values if N % 2 else torch.linspace(0, 1, N)
+    pos = pos.to(dev)
+    pos2 = pos.clone() * 0.97 + 0.01          # two different grids: the merge kernel
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
+    gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
+    torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
+    k = min(B, 12)
+    want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos2.cpu().numpy(), p=p, flags=flags & 15)
+    np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
+    if p == 1.0 and not (flags & 4):          # one grid on both sides: the merge-free kernel with a run-time length
+        plan1 = nat.PositionPlan(pos, pos.clone())
+        area = nat.forward_rows(x, y, pos, pos, 1.0, flags | 8, plan1)
+        merge = nat.forward_rows(x, y, pos, pos, 1.0, flags | 8 | nat.FLAG_NO_AREA, plan1)
+        torch.testing.assert_close(area, merge, rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,B", [(130, 60), (200, 33), (300, 41), (500, 19), (1000, 23), (1100, 9), (2000, 13), (3000, 5), (4095, 3)])
+@pytest.mark.parametrize("flags,p", [(0, 1.0), (1 | 2 | 4, 2.0), (1 | 4 | 8, 2.0), (2, 1.0), (1, 3.0)])
+def test_runtime_length_backward_and_training_form(N, B, flags, p):
+    """Gradients (both, and y only) against the generic kernels and the oracle; the training form's row losses equal the
+    forward kernel's bit for bit and its gradient equals the y-only backward's."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    dev = device()
+    x, y = gen_inputs("peaky", B, N, N, 900 + N)
+    x, y = x.to(dev), y.to(dev)
+    pos = torch.linspace(0, 1, N).to(dev)
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    g = torch.linspace(0.5, 1.5, B).to(dev)
+    sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g, plan=plan, grad_scale=0.5)
+    gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g, plan=plan, grad_scale=0.5)
+    k = min(B, 6)
+    wx, wy = so.backward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), (0.5 * g[:k]).cpu().numpy(),
+                         p=p, flags=flags & 15)
+    for got, ref, want in ((sx, gx, wx), (sy, gy, wy)):
+        scale = ref.abs().amax(dim=1, keepdim=True) + 1e-30
+        assert float(((got - ref).abs() / scale).max()) <= 2e-6
+        wscale = np.abs(want).max(axis=1, keepdims=True) + 1e-30
+        assert np.max(np.abs(got[:k].cpu().numpy() - want) / wscale) <= 1e-5
+    only_y = nat.backward_rows(x, y, pos, pos2, p, flags, g, need_gx=False, plan=plan, grad_scale=0.5)
+    assert only_y[0] is None and torch.equal(only_y[1], sy)
+    rows = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)
+    mean, rows2, gy2 = nat.loss_and_grad(x, y, pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)
+    assert torch.equal(rows, rows2)
+    ones = nat.backward_rows(x, y, pos, pos2, p, flags, torch.ones(1, device=dev), need_gx=False, plan=plan, grad_scale=1.0 / B)[1]
+    assert torch.equal(gy2, ones)
+
+
+def test_runtime_length_unsorted_positions_strides_and_module():
+    """Unsorted shared positions (the plan's permutation), strided rows, a 3-D batch through the module and autograd."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    from sot_amd.losses import Wasserstein1D
+    nat = native()
+    dev = device()
+    B, N = 50, 1000
+    x, y = gen_inputs("peaky", B, N, N, 31)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(2))
+    pos = torch.linspace(0, 1, N)[perm]
+    big_x = torch.zeros(B, N + 24, device=dev)
+    big_x[:, 3:N + 3] = x.to(dev)
+    xv = big_x[:, 3:N + 3]                      # unaligned, strided rows
+    yd = y.to(dev)
+    pd, pd2 = pos.to(dev), pos.to(dev).clone()
+    plan = nat.PositionPlan(pd, pd2)
+    for p, flags in ((2.0, 15), (1.0, 8)):
+        got = nat.forward_rows(nat.rows_view(xv), yd, pd, pd2, p, flags, plan).cpu().numpy()
+        want = so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=p, flags=flags)
+        np.testing.assert_allclose(got, want, rtol=RTOL)
+        _, gy = nat.backward_rows(nat.rows_view(xv), yd, pd, pd2, p, flags, torch.ones(1, device=dev), need_gx=False, plan=plan)
+        _, wy = so.backward(x[:4].numpy(), y[:4].numpy(), pos.numpy(), pos.numpy(), np.ones(4, np.float32), p=p, flags=flags)
+        assert np.max(np.abs(gy[:4].cpu().numpy() - wy) / (np.abs(wy).max(axis=1, keepdims=True) + 1e-30)) <= 1e-5
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+    y3 = yd.reshape(5, 10, N).clone().requires_grad_(True)
+    loss = mod(x.to(dev).reshape(5, 10, N), y3, x_pos=pd, y_pos=pd2)
+    loss.backward()
+    want = so.mean(so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=2.0, flags=15))
+    assert abs(float(loss.detach()) - float(want)) <= 1e-5 * abs(float(want))
+    assert torch.isfinite(y3.grad).all() and float(y3.grad.abs().max()) > 0
