@@ -138,6 +138,51 @@ class SotError(RuntimeError):
     pass
 
 
+_glue = None
+_glue_tried = False
+
+
+def glue():
+    """The C++ host path of the module's default call (csrc/sot_torch_glue.cpp -> _sot_glue.so, built in-tree by build.build_glue):
+    one pybind11 call per forward and a C++ autograd node instead of this file's ctypes marshalling + a Python autograd.Function
+    (~100 -> ~60 us of host time per forward + backward at the paper's step size).  Returns the bound extension module, or None
+    -- with one warning -- when it is missing, stale or disabled (SOT_NO_GLUE=1): the callers then use this file's Python binding,
+    which launches the same kernels."""
+    global _glue, _glue_tried
+    if _glue_tried:
+        return _glue
+    load()   # before taking the (non-reentrant) lock: load() takes it too
+    with _lock:
+        if _glue_tried:
+            return _glue
+        mod = None
+        if os.environ.get("SOT_NO_GLUE", "0") != "1":
+            try:
+                if _build.glue_is_stale():
+                    raise RuntimeError(f"{_build.GLUE_LIB} is missing or was built from other sources (run `python __graft_entry__.py`)")
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("_sot_glue", _build.GLUE_LIB)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.bind(library_path()) != ABI_VERSION:
+                    raise RuntimeError("ABI version mismatch")
+            except Exception as exc:  # noqa: BLE001 -- the Python binding is complete; say why the C++ path is off
+                import warnings
+                warnings.warn(f"sot_amd: the C++ host path is not available ({exc}); using the Python binding (same kernels, more host time)")
+                mod = None
+        _glue, _glue_tried = mod, True
+    return _glue
+
+
+def problem_flags(p, flags, plan) -> int:
+    """The flag word of a call: the caller's flags plus SOT_FLAG_SAME_GRID when the plan says both measures live on one grid --
+    asked only by the p = 1 forward without cutoff, the one call with a use for the answer (it may cost one synchronisation per plan)."""
+    flags = int(flags)
+    if plan is not None and p == 1 and not (flags & (FLAG_LIMIT_Q | FLAG_NO_AREA | FLAG_PRENORMALIZED)) and plan.same_grid():
+        flags |= FLAG_SAME_GRID
+    return flags
+
+
 def check(rc: int, p=None):
     if rc == SOT_OK:
         return
@@ -204,10 +249,7 @@ def make_problem(x, y, xpos, ypos, p, flags, plan=None) -> SotProblem:
     pr.B, pr.n, pr.m = B, n, m
     pr.x_row_stride = x.stride(0) if B > 1 else n
     pr.y_row_stride = y.stride(0) if B > 1 else m
-    pr.p, pr.flags = float(p), int(flags)
-    # only the p = 1 forward without cutoff has a use for the same-grid answer (and may pay one synchronisation per plan for it)
-    if plan is not None and p == 1 and not (flags & (FLAG_LIMIT_Q | FLAG_NO_AREA | FLAG_PRENORMALIZED)) and plan.same_grid():
-        pr.flags |= FLAG_SAME_GRID
+    pr.p, pr.flags = float(p), problem_flags(p, flags, plan)
     if plan is not None:
         pr.xpos, pr.ypos = plan.xpos_sorted.data_ptr(), plan.ypos_sorted.data_ptr()
         pr.xperm, pr.yperm = plan.xperm.data_ptr(), plan.yperm.data_ptr()

@@ -115,5 +115,59 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     return lib
 
 
+# ---- the C++ host path of the module (csrc/sot_torch_glue.cpp): a torch extension WITHOUT device code, built in-tree -----------
+GLUE_SRC = os.path.join(PKG_DIR, "csrc", "sot_torch_glue.cpp")
+GLUE_LIB = os.path.join(PKG_DIR, "_sot_glue.so")
+GLUE_DIGEST = GLUE_LIB + ".digest"
+
+
+def glue_digest() -> str:
+    import hashlib
+    import torch
+    h = hashlib.sha256()
+    for d in (GLUE_SRC, os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")):
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()
+
+
+def glue_is_stale() -> bool:
+    if not (os.path.exists(GLUE_LIB) and os.path.exists(GLUE_DIGEST)):
+        return True
+    with open(GLUE_DIGEST) as f:
+        return f.read().strip() != glue_digest()
+
+
+def build_glue(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/sot_torch_glue.cpp against this interpreter's torch (host compiler only; c10_hip supplies the current HIP
+    stream) into _sot_glue.so next to this file.  Same locking / digest discipline as build()."""
+    import fcntl
+    import torch
+    from torch.utils import cpp_extension
+    if not force and not glue_is_stale():
+        return GLUE_LIB
+    work = os.path.join(OBJ_DIR, "glue")
+    os.makedirs(work, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".glue.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not glue_is_stale():
+            return GLUE_LIB
+        if os.path.exists(GLUE_DIGEST):
+            os.remove(GLUE_DIGEST)
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+        cpp_extension.load(name="_sot_glue", sources=[GLUE_SRC], build_directory=work, verbose=verbose, is_python_module=False,
+                           extra_cflags=["-O2", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-Wno-unused-function"],
+                           extra_include_paths=[os.path.join(rocm, "include")],
+                           extra_ldflags=["-ldl", f"-L{torch_lib}", "-lc10_hip", f"-Wl,-rpath,{torch_lib}"], with_cuda=False)
+        shutil.copyfile(os.path.join(work, "_sot_glue.so"), GLUE_LIB + ".tmp")
+        os.replace(GLUE_LIB + ".tmp", GLUE_LIB)
+        with open(GLUE_DIGEST, "w") as f:
+            f.write(glue_digest() + "\n")
+    return GLUE_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_glue(force=True, verbose=True))

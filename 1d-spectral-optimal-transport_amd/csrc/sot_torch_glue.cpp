@@ -1,0 +1,194 @@
+// sot_torch_glue.cpp -- the host path of `Wasserstein1D(...)(x, y)` [+ `.backward()`] in C++ (round 3).
+//
+// Why: at the paper's own step size (64 clips x 16 frames = 1024 rows x 1025 bins, trainer.py:199-228) the kernels need ~10 us while
+// the Python binding needed ~100 us of host time per forward + backward (ctypes marshalling of 15 arguments, three torch.empty, a
+// Python autograd.Function whose backward re-enters the interpreter on the autograd engine's device thread).  This file is that
+// host path as one pybind11 call: argument checks, output allocation through torch's caching allocator, ONE call into the C ABI
+// (include/sot_hip.h -- the kernels stay behind it, this file contains no device code and no arithmetic on tensor data) and a
+// C++ torch::autograd::Function whose backward rescales the gradient that the training-form kernel produced together with the
+// loss (sot_w1d_loss_and_grad), without taking the GIL.
+//
+// Covers the module's hot call: 2-D float32 HIP tensors, shared (planned) positions, default reduction (mean over every row), no
+// hinge, gradient wanted for y only or not at all.  Everything else stays on the Python binding (_native.py), which remains the
+// complete implementation.  The library is the process's libsot_hip.so (bound by path with dlopen: the same handle ctypes holds).
+#include <torch/extension.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <dlfcn.h>
+#include <string>
+
+#include "../../include/sot_hip.h"
+
+namespace {
+
+struct Api {
+    decltype(&sot_abi_version) abi = nullptr;
+    decltype(&sot_status_string) status_string = nullptr;
+    decltype(&sot_w1d_loss) loss = nullptr;
+    decltype(&sot_w1d_loss_and_grad) loss_and_grad = nullptr;
+    decltype(&sot_w1d_backward) backward = nullptr;
+    decltype(&sot_scale_inplace) scale_inplace = nullptr;
+};
+Api g_api;
+
+template <typename F>
+void bind_symbol(void* handle, const char* name, F& slot)
+{
+    void* sym = dlsym(handle, name);
+    TORCH_CHECK(sym != nullptr, "sot glue: libsot_hip.so does not export ", name);
+    slot = reinterpret_cast<F>(sym);
+}
+
+int64_t bind_library(const std::string& path)
+{
+    void* handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    TORCH_CHECK(handle != nullptr, "sot glue: cannot open ", path, ": ", dlerror());
+    bind_symbol(handle, "sot_abi_version", g_api.abi);
+    bind_symbol(handle, "sot_status_string", g_api.status_string);
+    bind_symbol(handle, "sot_w1d_loss", g_api.loss);
+    bind_symbol(handle, "sot_w1d_loss_and_grad", g_api.loss_and_grad);
+    bind_symbol(handle, "sot_w1d_backward", g_api.backward);
+    bind_symbol(handle, "sot_scale_inplace", g_api.scale_inplace);
+    TORCH_CHECK(g_api.abi() == SOT_ABI_VERSION, "sot glue: libsot_hip.so has ABI version ", g_api.abi(), ", this glue was built for ",
+                SOT_ABI_VERSION);
+    return g_api.abi();
+}
+
+void check_status(int rc, double p)
+{
+    if (rc == SOT_OK) return;
+    // same exception type and text as losses.py:271
+    if (rc == SOT_ERR_INVALID_P) {
+        PyErr_SetString(PyExc_AssertionError, ("The OT loss is only valid for p>=1, " + std::to_string(p) + " was given").c_str());
+        throw pybind11::error_already_set();
+    }
+    TORCH_CHECK(false, "libsot_hip: ", g_api.status_string(rc), " (status ", rc, ")");
+}
+
+// the module's rows: 2-D float32 HIP tensors with unit inner stride
+void check_rows(const at::Tensor& t, const char* what)
+{
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.dim() == 2, "sot glue: ", what, " must be a 2-D float32 GPU tensor");
+    TORCH_CHECK(t.size(1) >= 1 && (t.size(1) == 1 || t.stride(1) == 1) && (t.size(0) <= 1 || t.stride(0) >= t.size(1)),
+                "sot glue: ", what, " must have unit inner stride and non-overlapping rows");
+}
+
+struct Plan {   // the position plan of sot_prepare_positions (sorted positions, permutations, identity flags), kept by the Python side
+    at::Tensor xs, ys, xperm, yperm, ident;
+};
+
+sot_problem make_problem(const at::Tensor& x, const at::Tensor& y, const Plan& plan, double p, int64_t flags)
+{
+    check_rows(x, "x");
+    check_rows(y, "y");
+    TORCH_CHECK(x.size(0) == y.size(0), "row count mismatch: ", x.size(0), " vs ", y.size(0));
+    TORCH_CHECK(plan.xs.numel() == x.size(1) && plan.ys.numel() == y.size(1), "positions and weights must have the same number of features");
+    TORCH_CHECK(x.device() == y.device() && plan.xs.device() == x.device(), "sot glue: all tensors must live on one GPU");
+    sot_problem pr{};
+    pr.x = x.data_ptr<float>();
+    pr.y = y.data_ptr<float>();
+    pr.xpos = plan.xs.data_ptr<float>();
+    pr.ypos = plan.ys.data_ptr<float>();
+    pr.B = x.size(0);
+    pr.n = (int32_t)x.size(1);
+    pr.m = (int32_t)y.size(1);
+    pr.x_row_stride = pr.B > 1 ? x.stride(0) : pr.n;
+    pr.y_row_stride = pr.B > 1 ? y.stride(0) : pr.m;
+    pr.xpos_row_stride = pr.ypos_row_stride = 0;
+    pr.p = (float)p;
+    pr.flags = (uint32_t)flags;
+    pr.xperm = plan.xperm.data_ptr<int32_t>();
+    pr.yperm = plan.yperm.data_ptr<int32_t>();
+    pr.perm_is_identity = plan.ident.data_ptr<int32_t>();
+    return pr;
+}
+
+void* current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// forward + batch mean, no gradient (sot_w1d_loss): the eval / no-grad call of the module
+at::Tensor mean_loss_nograd(const at::Tensor& x, const at::Tensor& y, const Plan& plan, double p, int64_t flags)
+{
+    sot_problem pr = make_problem(x, y, plan, p, flags);
+    TORCH_CHECK(pr.B > 0, "libsot_hip: bad shape or stride (status ", (int)SOT_ERR_BAD_SHAPE, ")");
+    const c10::hip::HIPGuard guard(x.device());
+    at::Tensor rows = at::empty({pr.B}, x.options());
+    at::Tensor mean = at::empty({}, x.options());
+    check_status(g_api.loss(&pr, rows.data_ptr<float>(), (double)pr.B, 0, 0.0f, mean.data_ptr<float>(), nullptr, nullptr, nullptr, 0,
+                            current_stream(x)), p);
+    return mean;
+}
+
+// The training step's node: the loss AND d mean / d y out of one pass over the rows (sot_w1d_loss_and_grad); the backward multiplies
+// the stored gradient by the upstream scalar (a kernel that exits at once when that scalar is 1).  A second backward through a
+// retained graph recomputes the gradient with the backward kernel (sot_w1d_backward).
+class FusedMeanLoss : public torch::autograd::Function<FusedMeanLoss> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& y, const at::Tensor& xs,
+                              const at::Tensor& ys, const at::Tensor& xperm, const at::Tensor& yperm, const at::Tensor& ident, double p,
+                              int64_t flags)
+    {
+        const Plan plan{xs, ys, xperm, yperm, ident};
+        sot_problem pr = make_problem(x, y, plan, p, flags);
+        TORCH_CHECK(pr.B > 0, "libsot_hip: bad shape or stride (status ", (int)SOT_ERR_BAD_SHAPE, ")");
+        const c10::hip::HIPGuard guard(x.device());
+        at::Tensor rows = at::empty({pr.B}, x.options());
+        at::Tensor mean = at::empty({}, x.options());
+        at::Tensor gy = at::empty({pr.B, (int64_t)pr.m}, x.options());
+        check_status(g_api.loss_and_grad(&pr, rows.data_ptr<float>(), (double)pr.B, mean.data_ptr<float>(), nullptr, (float)(1.0 / (double)pr.B),
+                                         gy.data_ptr<float>(), nullptr, nullptr, 0, current_stream(x)), p);
+        ctx->save_for_backward({x, y, xs, ys, xperm, yperm, ident});
+        ctx->saved_data["gy"] = gy;
+        ctx->saved_data["p"] = p;
+        ctx->saved_data["flags"] = flags;
+        return mean;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs)
+    {
+        at::Tensor g = grad_outputs[0];
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        g = g.contiguous();
+        const c10::hip::HIPGuard guard(g.device());
+        at::Tensor gy;
+        const c10::IValue held = ctx->saved_data["gy"];
+        if (held.isTensor() && held.toTensor().defined()) {
+            gy = held.toTensor();
+            ctx->saved_data["gy"] = c10::IValue();   // consumed once
+            const int rc = g_api.scale_inplace(gy.data_ptr<float>(), gy.numel(), g.data_ptr<float>(), current_stream(gy));
+            check_status(rc, 1.0);
+        } else {   // a second backward through a retained graph
+            const auto saved = ctx->get_saved_variables();
+            const double p = ctx->saved_data["p"].toDouble();
+            const Plan plan{saved[2], saved[3], saved[4], saved[5], saved[6]};
+            sot_problem pr = make_problem(saved[0], saved[1], plan, p, ctx->saved_data["flags"].toInt());
+            gy = at::empty({pr.B, (int64_t)pr.m}, saved[1].options());
+            const int rc = g_api.backward(&pr, g.data_ptr<float>(), 0, (float)(1.0 / (double)pr.B), nullptr, gy.data_ptr<float>(), nullptr, 0,
+                                          current_stream(gy));
+            check_status(rc, p);
+        }
+        return {at::Tensor(), gy, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+// The module's default call.  Gradient wanted for y only -> the autograd node above; none -> the forward alone.  (x or the positions
+// wanting a gradient is the caller's case to route elsewhere: the Python binding has those paths.)
+at::Tensor mean_loss(const at::Tensor& x, const at::Tensor& y, const at::Tensor& xs, const at::Tensor& ys, const at::Tensor& xperm,
+                     const at::Tensor& yperm, const at::Tensor& ident, double p, int64_t flags)
+{
+    TORCH_CHECK(g_api.loss != nullptr, "sot glue: bind() has not been called");
+    const bool grad = at::GradMode::is_enabled() && y.requires_grad();
+    TORCH_CHECK(!(at::GradMode::is_enabled() && x.requires_grad()), "sot glue: a gradient w.r.t. x is not this path's case");
+    if (grad) return FusedMeanLoss::apply(x, y, xs, ys, xperm, yperm, ident, p, flags);
+    return mean_loss_nograd(x, y, Plan{xs, ys, xperm, yperm, ident}, p, flags);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "host path of sot_amd.losses.Wasserstein1D in C++ (one call per forward, C++ autograd node); kernels: libsot_hip.so";
+    m.def("bind", &bind_library, "dlopen libsot_hip.so at `path` and resolve the entry points; returns its ABI version");
+    m.def("mean_loss", &mean_loss, "mean over the rows of W_p^p(x_r, y_r) on planned shared positions; differentiable w.r.t. y");
+}

@@ -200,9 +200,10 @@ class _PlanCache:
         return plan
 
 
-def _prepare(x, y, xpos, ypos):
-    """Common marshalling: 2-D fp32 HIP rows and matching positions."""
-    nat.require_hip(x, y, xpos, ypos)
+def _prepare(x, y, xpos, ypos, checked=False):
+    """Common marshalling: 2-D fp32 HIP rows and matching positions (checked: the caller has established _hip_domain)."""
+    if not checked:
+        nat.require_hip(x, y, xpos, ypos)
     if x.ndim != 2 or y.ndim != 2:
         raise ValueError(f"expected 2-D [rows, features] weights, got {tuple(x.shape)} and {tuple(y.shape)}")
     if x.shape[0] != y.shape[0]:
@@ -354,7 +355,7 @@ class Wasserstein1D(torch.nn.Module):
         limit_q = bool(kwargs.get("limit_quantile_range", False) or self.limit_quantile_range)
         flags = _flags(self.square_dist, dont_normalize, limit_q, self.require_sort)
 
-        x, y, x_pos_, y_pos_ = _prepare(x, y, x_pos_, y_pos_)
+        x, y, x_pos_, y_pos_ = _prepare(x, y, x_pos_, y_pos_, checked=True)
         plan = self._plans.get(x_pos_, y_pos_) if (self.require_sort and x_pos_.ndim == 1) else None
         return x, y, x_pos_, y_pos_, flags, plan, original_shape
 
@@ -397,7 +398,14 @@ class Wasserstein1D(torch.nn.Module):
         if dims is None and not self.hinge:
             # default reduction: forward and the mean over every row (losses.py:211) in one native call
             x2, y2, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
-            if torch.is_grad_enabled() and any(t.requires_grad for t in (x2, y2, x_pos_, y_pos_)):
+            grad_on = torch.is_grad_enabled()
+            glue = nat.glue() if (plan is not None and EARLY_GRADIENT) else None
+            if glue is not None and not (grad_on and (x2.requires_grad or x_pos_.requires_grad or y_pos_.requires_grad)):
+                # the hot call (trainer.py:220-228: gradient for the estimate's spectrum only; metrics.py:148: none): C++ host path
+                plan.use_on_current_stream(x2.device)
+                return glue.mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p),
+                                      nat.problem_flags(self.p, flags, plan))
+            if grad_on and any(t.requires_grad for t in (x2, y2, x_pos_, y_pos_)):
                 return _FusedMeanLoss.apply(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
             return nat.loss_fused(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)[0]
         loss = self.row_losses(x, y, x_pos, y_pos, **kwargs)

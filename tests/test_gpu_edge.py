@@ -178,3 +178,59 @@ def test_position_gradients_match_the_reference_autograd(case):
     for got, want in ((xpd.grad, xpr.grad), (ypd.grad, ypr.grad)):
         assert got.shape == want.shape
         assert float((got.cpu() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-6), case
+
+
+@pytest.mark.gpu
+def test_cpp_host_path_equals_the_python_binding():
+    """The module's default call goes through the C++ host path (csrc/sot_torch_glue.cpp: one pybind11 call, C++ autograd node); it
+    must give bit for bit what the Python binding gives (same C-ABI calls): value, gradient, an upstream scalar other than 1
+    (MixOfLosses weights), a second backward through a retained graph, inference mode, 3-D inputs, strided rows, p = 1 on one grid."""
+    import sot_amd.losses as L
+    from sot_amd.losses import Wasserstein1D
+    nat = native()
+    dev = device()
+    assert nat.glue() is not None, "the in-tree _sot_glue.so must load on the GPU box"
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.rand(6, 5, 1025, device=dev, generator=g)
+    y = torch.rand(6, 5, 1025, device=dev, generator=g)
+    pos = torch.linspace(0, 1, 1025, device=dev)
+    pos2 = pos.clone()
+    for ctor in (dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True), dict(p=1), dict(p=3)):
+        mod = Wasserstein1D(**ctor).to(dev)
+        x2, y2, xp, yp, flags, plan, _ = mod._marshal(x, y, pos, pos2, {})
+        want_mean, _, want_gy = nat.loss_and_grad(x2, y2, xp, yp, float(mod.p), flags, plan)
+        ya = y.clone().requires_grad_(True)
+        out = mod(x, ya, x_pos=pos, y_pos=pos2)
+        assert out.grad_fn is not None and "FusedMeanLoss" in type(out.grad_fn).__name__ and "Backward" in type(out.grad_fn).__name__
+        assert not type(out.grad_fn).__name__.startswith("_FusedMeanLoss"), "the Python autograd.Function ran instead of the C++ node"
+        assert torch.equal(out.detach(), want_mean)
+        (out * 0.37).backward(retain_graph=True)
+        assert torch.equal(ya.grad.reshape(-1, 1025), want_gy * 0.37)
+        ya.grad = None
+        out.backward()                                    # second backward: recomputed by the backward kernel
+        torch.testing.assert_close(ya.grad.reshape(-1, 1025), want_gy, rtol=1e-6, atol=1e-12)
+        with torch.inference_mode():
+            assert torch.equal(mod(x, y, x_pos=pos, y_pos=pos2), nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan)[0])
+        # the Python binding on the same call
+        L.EARLY_GRADIENT = False
+        try:
+            yb = y.clone().requires_grad_(True)
+            ref = mod(x, yb, x_pos=pos, y_pos=pos2)
+            assert type(ref.grad_fn).__name__.startswith("_FusedMeanLoss")
+            ref.backward()
+        finally:
+            L.EARLY_GRADIENT = True
+        assert torch.equal(ref.detach(), out.detach())
+        torch.testing.assert_close(yb.grad, ya.grad, rtol=1e-6, atol=1e-12)
+    # strided rows (a slice of a wider buffer) and a weight on x that must NOT take this path
+    wide = torch.rand(30, 1100, device=dev, generator=g)
+    xv, yv = wide[:, 7:1032], wide[:, 40:1065].clone().requires_grad_(True)
+    mod = Wasserstein1D(p=2, square_dist=True).to(dev)
+    a = mod(xv, yv, x_pos=pos, y_pos=pos2)
+    b = mod(xv.contiguous(), yv, x_pos=pos, y_pos=pos2)
+    assert torch.equal(a, b)
+    xg = xv.clone().requires_grad_(True)
+    both = mod(xg, yv, x_pos=pos, y_pos=pos2)
+    assert type(both.grad_fn).__name__.startswith("_FusedMeanLoss")   # both gradients: the Python node with the two-gradient backward kernel
+    both.backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()

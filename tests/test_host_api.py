@@ -142,3 +142,19 @@ def test_stale_library_is_detected_by_content_not_by_mtime(tmp_path, monkeypatch
     assert b.is_stale()                         # digest of other sources -> stale
     (tmp_path / "other.digest").write_text(b.source_digest() + "\n")
     assert not b.is_stale()
+
+
+def test_cpp_host_path_is_built_in_tree_and_loads_without_a_gpu():
+    """_sot_glue.so (build.build_glue: csrc/sot_torch_glue.cpp, no device code) sits next to the package, is current with its
+    sources and exports the two entry points the module uses; binding it resolves every C-ABI symbol it calls."""
+    import sot_amd
+    from sot_amd import _native as nat
+    assert os.path.exists(sot_amd.build.GLUE_LIB) and not sot_amd.build.glue_is_stale()
+    g = nat.glue()
+    assert g is not None and callable(g.mean_loss) and callable(g.bind)
+    assert g.bind(nat.library_path()) == nat.ABI_VERSION
+    import torch
+    with pytest.raises(RuntimeError, match="2-D float32 GPU tensor"):
+        t = torch.rand(2, 8)
+        i = torch.zeros(8, dtype=torch.int32)
+        g.mean_loss(t, t, t[0], t[0], i, i, i[:2], 1.0, 8)
