@@ -160,7 +160,7 @@ def build_glue(force: bool = False, verbose: bool = False) -> str:
         cpp_extension.load(name="_sot_glue", sources=[GLUE_SRC], build_directory=work, verbose=verbose, is_python_module=False,
                            extra_cflags=["-O2", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-Wno-unused-function"],
                            extra_include_paths=[os.path.join(rocm, "include")],
-                           extra_ldflags=["-ldl", f"-L{torch_lib}", "-lc10_hip", f"-Wl,-rpath,{torch_lib}"], with_cuda=False)
+                           extra_ldflags=["-ldl", f"-L{torch_lib}", "-lc10_hip", "-ltorch_hip", f"-Wl,-rpath,{torch_lib}"], with_cuda=False)
         shutil.copyfile(os.path.join(work, "_sot_glue.so"), GLUE_LIB + ".tmp")
         os.replace(GLUE_LIB + ".tmp", GLUE_LIB)
         with open(GLUE_DIGEST, "w") as f:

@@ -13,8 +13,9 @@
 // complete implementation.  The library is the process's libsot_hip.so (bound by path with dlopen: the same handle ctypes holds).
 #include <torch/extension.h>
 #include <torch/csrc/autograd/custom_function.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm presents HIP devices as DeviceType::CUDA ("masquerading"): the guard and the stream accessor of that convention
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <dlfcn.h>
 #include <string>
@@ -105,14 +106,14 @@ sot_problem make_problem(const at::Tensor& x, const at::Tensor& y, const Plan& p
     return pr;
 }
 
-void* current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 // forward + batch mean, no gradient (sot_w1d_loss): the eval / no-grad call of the module
 at::Tensor mean_loss_nograd(const at::Tensor& x, const at::Tensor& y, const Plan& plan, double p, int64_t flags)
 {
     sot_problem pr = make_problem(x, y, plan, p, flags);
     TORCH_CHECK(pr.B > 0, "libsot_hip: bad shape or stride (status ", (int)SOT_ERR_BAD_SHAPE, ")");
-    const c10::hip::HIPGuard guard(x.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     at::Tensor rows = at::empty({pr.B}, x.options());
     at::Tensor mean = at::empty({}, x.options());
     check_status(g_api.loss(&pr, rows.data_ptr<float>(), (double)pr.B, 0, 0.0f, mean.data_ptr<float>(), nullptr, nullptr, nullptr, 0,
@@ -132,7 +133,7 @@ public:
         const Plan plan{xs, ys, xperm, yperm, ident};
         sot_problem pr = make_problem(x, y, plan, p, flags);
         TORCH_CHECK(pr.B > 0, "libsot_hip: bad shape or stride (status ", (int)SOT_ERR_BAD_SHAPE, ")");
-        const c10::hip::HIPGuard guard(x.device());
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
         at::Tensor rows = at::empty({pr.B}, x.options());
         at::Tensor mean = at::empty({}, x.options());
         at::Tensor gy = at::empty({pr.B, (int64_t)pr.m}, x.options());
@@ -150,7 +151,7 @@ public:
         at::Tensor g = grad_outputs[0];
         if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
         g = g.contiguous();
-        const c10::hip::HIPGuard guard(g.device());
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.device());
         at::Tensor gy;
         const c10::IValue held = ctx->saved_data["gy"];
         if (held.isTensor() && held.toTensor().defined()) {
