@@ -43,6 +43,16 @@ constexpr int kMaxFft = 4096;
 #ifndef SOT_STFT_WAVE_FRAMES
 #define SOT_STFT_WAVE_FRAMES 1
 #endif
+// Timing-only ablation (tools/fusion_probe.py; results are WRONG on purpose, never defined in the product build): the forward kernels
+// compute every magnitude but store none -- what a consumer fused behind the transform would save on the producer's side.
+#ifndef SOT_STFT_ABLATE_STORE
+#define SOT_STFT_ABLATE_STORE 0
+#endif
+__device__ __forceinline__ void store_mag(float* dst, int k, float v)
+{
+    if (SOT_STFT_ABLATE_STORE) { if (v == 12345.678f) dst[k] = v; }   // keeps the value alive, never true for |.| / sqrt(n) of audio
+    else dst[k] = v;
+}
 
 // synchronisation of one frame slot (see Geo::wave_sync): the LDS executes a wavefront's instructions in issue order
 template <bool WAVE>
@@ -286,8 +296,8 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
         for (int k = lid; k <= G::m / 2; k += G::tpf) {
             v2f xk, xm;
             unpack_pair<LOGM>(z, wn, k, xk, xm);
-            dst[k] = magnitude(xk) * scale;
-            dst[G::m - k] = magnitude(xm) * scale;
+            store_mag(dst, k, magnitude(xk) * scale);
+            store_mag(dst, G::m - k, magnitude(xm) * scale);
         }
     }
 }
@@ -361,8 +371,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SOT_ST
                 if (k <= G::m / 2) {
                     v2f xk, xm;
                     unpack_pair_w<LOGM>(z, wnr[j], k, xk, xm);
-                    dst[k] = magnitude(xk) * scale;
-                    dst[G::m - k] = magnitude(xm) * scale;
+                    store_mag(dst, k, magnitude(xk) * scale);
+                    store_mag(dst, G::m - k, magnitude(xm) * scale);
                 }
             }
         }
@@ -506,8 +516,8 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
             if (k <= m / 2) {
                 v2f xk, xm;
                 unpack_pair<LOGM>(zl, wn, k, xk, xm);
-                dst[k] = magnitude(xk) * scale;
-                dst[m - k] = magnitude(xm) * scale;
+                store_mag(dst, k, magnitude(xk) * scale);
+                store_mag(dst, m - k, magnitude(xm) * scale);
             }
         }
         slot_sync<true>();   // the unpack reads are issued before the next frame's exchange writes
