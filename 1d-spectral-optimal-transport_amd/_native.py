@@ -30,7 +30,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 4                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 5                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -96,6 +96,12 @@ EXPORTS = {
                                                  ctypes.c_int, _vp, _vp]),
     "sot_stft_mag_backward": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
                                              _vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "sot_stft_mag_forward_spec": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
+                                                 _vp, _vp, _vp]),
+    "sot_stft_mag_forward_pair_spec": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int,
+                                                      ctypes.c_int, _vp, _vp, _vp]),
+    "sot_stft_mag_backward_spec": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int,
+                                                  _vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
 }
 
 _lib = None
@@ -541,8 +547,9 @@ def _aligned8(t: torch.Tensor) -> torch.Tensor:
     return t if t.data_ptr() % 8 == 0 else t.clone()
 
 
-def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
-    """[batch, samples] fp32 on the GPU -> [batch, frames, n_fft/2+1] magnitudes (sot_stft_mag_forward)."""
+def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, want_spec: bool = False):
+    """[batch, samples] fp32 on the GPU -> [batch, frames, n_fft/2+1] magnitudes (sot_stft_mag_forward).  want_spec: returns
+    (magnitudes, spectrum [batch, frames, n_fft/2+1, 2]) -- the complex spectrum for stft_mag_backward(spec=...) (sot_stft_mag_forward_spec)."""
     require_hip(audio, window)
     lib = load()
     if audio.ndim != 2 or window.numel() != n_fft:
@@ -553,15 +560,17 @@ def stft_mag_forward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
     batch, samples = audio.shape
     frames = int(lib.sot_stft_frames(samples, hop))
     mag = torch.empty(batch, frames, n_fft // 2 + 1, dtype=torch.float32, device=audio.device)
+    spec = torch.empty(batch, frames, n_fft // 2 + 1, 2, dtype=torch.float32, device=audio.device) if want_spec else None
     with _on_device(audio.device):
-        check(lib.sot_stft_mag_forward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
-                                       int(n_fft), int(hop), mag.data_ptr(), stream_ptr(audio.device)))
-    return mag
+        check(lib.sot_stft_mag_forward_spec(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
+                                            int(n_fft), int(hop), mag.data_ptr(), _ptr(spec), stream_ptr(audio.device)))
+    return (mag, spec) if want_spec else mag
 
 
-def stft_mag_forward_pair(audio_a: torch.Tensor, audio_b: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int):
+def stft_mag_forward_pair(audio_a: torch.Tensor, audio_b: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, want_spec_b: bool = False):
     """Two [batch, samples] signals -> their [batch, frames, n_fft/2+1] magnitudes from ONE launch (sot_stft_mag_forward_pair);
-    the two results are the halves of one allocation."""
+    the two results are the halves of one allocation.  want_spec_b: a third result, the complex spectrum of audio_b
+    [batch, frames, n_fft/2+1, 2] for stft_mag_backward(spec=...)."""
     require_hip(audio_a, audio_b, window)
     lib = load()
     if audio_a.ndim != 2 or audio_a.shape != audio_b.shape or window.numel() != n_fft:
@@ -574,19 +583,21 @@ def stft_mag_forward_pair(audio_a: torch.Tensor, audio_b: torch.Tensor, window: 
     batch, samples = audio_a.shape
     frames = int(lib.sot_stft_frames(samples, hop))
     mag = torch.empty(2 * batch, frames, n_fft // 2 + 1, dtype=torch.float32, device=audio_a.device)
+    spec = torch.empty(batch, frames, n_fft // 2 + 1, 2, dtype=torch.float32, device=audio_a.device) if want_spec_b else None
     with _on_device(audio_a.device):
-        check(lib.sot_stft_mag_forward_pair(audio_a.data_ptr(), audio_a.stride(0) if batch > 1 else samples, audio_b.data_ptr(),
-                                            audio_b.stride(0) if batch > 1 else samples, batch, samples, window.data_ptr(), int(n_fft),
-                                            int(hop), mag.data_ptr(), stream_ptr(audio_a.device)))
-    return mag[:batch], mag[batch:]
+        check(lib.sot_stft_mag_forward_pair_spec(audio_a.data_ptr(), audio_a.stride(0) if batch > 1 else samples, audio_b.data_ptr(),
+                                                 audio_b.stride(0) if batch > 1 else samples, batch, samples, window.data_ptr(), int(n_fft),
+                                                 int(hop), mag.data_ptr(), _ptr(spec), stream_ptr(audio_a.device)))
+    return (mag[:batch], mag[batch:], spec) if want_spec_b else (mag[:batch], mag[batch:])
 
 
 def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, grad_mag: torch.Tensor,
-                      grad_scale: torch.Tensor = None, accumulate_into: torch.Tensor = None) -> torch.Tensor:
+                      grad_scale: torch.Tensor = None, accumulate_into: torch.Tensor = None, spec: torch.Tensor = None) -> torch.Tensor:
     """dL/d(audio) [batch, samples] from dL/d(mag) [batch, frames, n_fft/2+1] (sot_stft_mag_backward); grad_scale: optional
     one-element fp32 device tensor multiplying grad_mag; accumulate_into: an existing contiguous [batch, samples] gradient
-    that the result is added to (and that is returned)."""
-    require_hip(audio, window, grad_mag, grad_scale)
+    that the result is added to (and that is returned); spec: the complex spectrum the forward stored (want_spec) -- the kernel
+    then skips its own forward transform of every frame (same result bit for bit) and `audio` only supplies the shape."""
+    require_hip(audio, window, grad_mag, grad_scale, spec)
     if grad_scale is not None and grad_scale.numel() != 1:
         raise RuntimeError("stft_mag_backward: grad_scale must hold one element")
     lib = load()
@@ -605,9 +616,12 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
     ws = torch.empty(max(1, int(lib.sot_stft_backward_workspace_bytes(batch, samples, int(n_fft), int(hop)))), dtype=torch.uint8,
                      device=audio.device)
     with _on_device(audio.device):
-        check(lib.sot_stft_mag_backward(audio.data_ptr(), batch, samples, audio.stride(0) if batch > 1 else samples, window.data_ptr(),
-                                        int(n_fft), int(hop), grad_mag.data_ptr(), _ptr(grad_scale), grad_audio.data_ptr(),
-                                        0 if accumulate_into is None else 1, ws.data_ptr(), ws.numel(), stream_ptr(audio.device)))
+        if spec is not None and (not spec.is_contiguous() or spec.shape != (batch, grad_mag.shape[1], n_fft // 2 + 1, 2)):
+            raise RuntimeError("stft_mag_backward: spec must be the contiguous [batch, frames, n_fft/2+1, 2] spectrum of the forward pass")
+        check(lib.sot_stft_mag_backward_spec(audio.data_ptr(), _ptr(spec), batch, samples, audio.stride(0) if batch > 1 else samples,
+                                             window.data_ptr(), int(n_fft), int(hop), grad_mag.data_ptr(), _ptr(grad_scale),
+                                             grad_audio.data_ptr(), 0 if accumulate_into is None else 1, ws.data_ptr(), ws.numel(),
+                                             stream_ptr(audio.device)))
     return grad_audio
 
 

@@ -69,6 +69,12 @@ __device__ __forceinline__ void slot_sync()
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // one complex point; arithmetic maps to v_pk_*_f32
 
+__device__ __forceinline__ void store_spec(float2* sp, int k, int mk, v2f xk, v2f xm)
+{
+    sp[k] = make_float2(xk.x, xk.y);
+    sp[mk] = make_float2(xm.x, xm.y);
+}
+
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) { return a.xx * b + a.yy * (v2f){-b.y, b.x}; }
 __device__ __forceinline__ v2f cconj(v2f a) { return (v2f){a.x, -a.y}; }
 __device__ __forceinline__ v2f mul_i(v2f a) { return (v2f){-a.y, a.x}; }    // a * (+i)
@@ -175,6 +181,9 @@ struct StftArgs {
     const float* audio_b; int64_t split, row_stride_b;   // forward of two signals in one launch: clips >= split come from audio_b
     const float* window; int n_fft, logm, hop; int64_t frames;   // logm = log2(n_fft / 2)
     float* mag;                 // forward output [batch, frames, n_fft/2+1]
+    float2* spec;               // forward, optional: the complex spectrum X of the clips >= spec_first, [batch - spec_first, frames, n_fft/2+1]
+    int64_t spec_first;         //   (what abs()'s autograd would save: the backward then needs no second forward transform)
+    const float2* spec_in;      // backward, optional: that spectrum for all `batch` clips (then `audio` is not read)
     const float* grad_mag;      // backward input, same shape
     const float* grad_scale;    // backward: optional device scalar multiplying grad_mag (an upstream gradient), or null
     int accumulate;             // backward: grad_audio += result (the sum over the scales of MSSLoss)
@@ -292,12 +301,14 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_kernel(const StftAr
     fft_inplace<LOGM, false>(z, tw, lid);
     if (active) {
         float* dst = a.mag + (int64_t)fr * G::nb;
+        float2* sp = (a.spec != nullptr && (int64_t)b >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * G::nb : nullptr;
 #pragma unroll
         for (int k = lid; k <= G::m / 2; k += G::tpf) {
             v2f xk, xm;
             unpack_pair<LOGM>(z, wn, k, xk, xm);
             store_mag(dst, k, magnitude(xk) * scale);
             store_mag(dst, G::m - k, magnitude(xm) * scale);
+            if (sp != nullptr) store_spec(sp, k, G::m - k, xk, xm);
         }
     }
 }
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SOT_ST
         fft_inplace<LOGM, false>(z, tw, lid);
         if (fr < total) {
             float* dst = a.mag + (int64_t)fr * G::nb;
+            float2* sp = (a.spec != nullptr && (int64_t)(fr / frames) >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * G::nb : nullptr;
 #pragma unroll
             for (int j = 0; j < PERK; ++j) {
                 const int k = lid + j * G::tpf;
@@ -373,6 +385,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(SOT_ST
                     unpack_pair_w<LOGM>(z, wnr[j], k, xk, xm);
                     store_mag(dst, k, magnitude(xk) * scale);
                     store_mag(dst, G::m - k, magnitude(xm) * scale);
+                    if (sp != nullptr) store_spec(sp, k, G::m - k, xk, xm);
                 }
             }
         }
@@ -510,6 +523,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
         fft1024_wave<false>(r, zl, tw, lane);
         slot_sync<true>();
         float* dst = a.mag + (int64_t)fr * nb;
+        float2* sp = (a.spec != nullptr && (int64_t)b >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * nb : nullptr;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int k = lane + 64 * j;
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
                 unpack_pair<LOGM>(zl, wn, k, xk, xm);
                 store_mag(dst, k, magnitude(xk) * scale);
                 store_mag(dst, m - k, magnitude(xm) * scale);
+                if (sp != nullptr) store_spec(sp, k, m - k, xk, xm);
             }
         }
         slot_sync<true>();   // the unpack reads are issued before the next frame's exchange writes
@@ -532,8 +547,11 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
 // Pass 1 (this kernel): one frame slot per group of kFramesPerGroup consecutive frames; their windowed gradients are
 // overlap-added in LDS and stored as the group's partial result.  Pass 2 (stft_overlap_add_kernel) adds, per sample, the
 // partial results of the groups that cover it in ascending group order: deterministic, no atomics.
-template <int LOGM>
-__global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(const StftArgs a)
+// SPEC: the frames' complex spectra come from the forward pass (StftArgs::spec_in: what the forward kernels store on request, bit for
+// bit the X this kernel would recompute): no audio is read and the forward transform of every frame is skipped -- the kernel is
+// the magnitude / phase arithmetic, ONE (inverse) transform per frame and the overlap-add.
+template <int LOGM, bool SPEC>
+__device__ __forceinline__ void backward_partial_body(const StftArgs& a)
 {
     using G = Geo<LOGM>;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -572,16 +590,18 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
             cur[j].y = (2 * i + 1 < left) ? s0[2 * i + 1] : 0.0f;
         }
     };
-    fetch_audio(f_begin);
+    if constexpr (!SPEC) fetch_audio(f_begin);
     for (int t = lid; t < a.span; t += G::tpf) acc[t] = 0.0f;
     for (int fi = 0; fi < kFramesPerGroup; ++fi) {
         const int64_t f = f_begin + fi;
         const bool has = active && f < a.frames;   // idle slots / missing frames run the same passes on zeros
         slot_sync<G::wave_sync>();
+        if constexpr (!SPEC) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j)
-            z[zi(bitrev(lid + j * G::tpf, LOGM))] = (v2f){cur[j].x * wt[j].x, cur[j].y * wt[j].y};
-        if (fi + 1 < kFramesPerGroup) fetch_audio(f + 1);
+            for (int j = 0; j < PER; ++j)
+                z[zi(bitrev(lid + j * G::tpf, LOGM))] = (v2f){cur[j].x * wt[j].x, cur[j].y * wt[j].y};
+            if (fi + 1 < kFramesPerGroup) fetch_audio(f + 1);
+        }
         // this frame's upstream gradients: requested before the transform, consumed after it
         const float* g = a.grad_mag + ((int64_t)b * a.frames + (has ? f : 0)) * G::nb;
         float gup_k[kPairIters], gup_m[kPairIters];
@@ -592,7 +612,20 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
             gup_k[r] = use ? g[k] : 0.0f;
             gup_m[r] = use ? g[m - k] : 0.0f;
         }
-        fft_inplace<LOGM, false>(z, tw, lid);
+        // the frame's spectrum: recomputed here, or the one the forward pass stored
+        const float2* sp = SPEC ? a.spec_in + ((int64_t)b * a.frames + (has ? f : 0)) * G::nb : nullptr;
+        v2f sxk[SPEC ? kPairIters : 1], sxm[SPEC ? kPairIters : 1];
+        if constexpr (SPEC) {
+#pragma unroll
+            for (int r = 0; r < kPairIters; ++r) {
+                const int k = lid + r * G::tpf;
+                const bool use = has && k <= m / 2;
+                const float2 pk = use ? sp[k] : make_float2(0.0f, 0.0f), pm = use ? sp[m - k] : make_float2(0.0f, 0.0f);
+                sxk[r] = (v2f){pk.x, pk.y}; sxm[r] = (v2f){pm.x, pm.y};
+            }
+        } else {
+            fft_inplace<LOGM, false>(z, tw, lid);
+        }
         // pairs (k, m-k): spectrum -> Zin -> H -> G, kept in registers until every thread has read z
         v2f gk[kPairIters], gm[kPairIters];
 #pragma unroll
@@ -601,7 +634,8 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
             gk[r] = (v2f){0.0f, 0.0f}; gm[r] = (v2f){0.0f, 0.0f};
             if (has && k <= m / 2) {
                 v2f xk, xm;
-                unpack_pair<LOGM>(z, wn, k, xk, xm);
+                if constexpr (SPEC) { xk = sxk[r]; xm = sxm[r]; }
+                else unpack_pair<LOGM>(z, wn, k, xk, xm);
                 const float mk = magnitude(xk), mm = magnitude(xm);
                 const float ck = mk > 0.0f ? (gup_k[r] * up) / mk : 0.0f;      // torch: sgn(0) = 0
                 const float cm = mm > 0.0f ? (gup_m[r] * up) / mm : 0.0f;
@@ -615,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
                 gm[r] = cconj(sk) + mul_i(cmul(wk, cconj(dk)));
             }
         }
-        slot_sync<G::wave_sync>();
+        if constexpr (!SPEC) slot_sync<G::wave_sync>();   // (SPEC: nobody has read z since the barrier at the top of the frame)
 #pragma unroll
         for (int r = 0; r < kPairIters; ++r) {
             const int k = lid + r * G::tpf;
@@ -642,6 +676,12 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
         for (int t = lid; t < a.span; t += G::tpf) dst[t] = acc[t];
     }
 }
+
+template <int LOGM>
+__global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(const StftArgs a) { backward_partial_body<LOGM, false>(a); }
+
+template <int LOGM>
+__global__ __launch_bounds__(kThreads) void stft_mag_backward_spec_kernel(const StftArgs a) { backward_partial_body<LOGM, true>(a); }
 
 __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftArgs a)
 {
@@ -876,13 +916,21 @@ int64_t sot_stft_frames(int64_t samples, int hop) { return (samples < 1 || hop <
 int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int64_t audio_row_stride, const float* window,
                          int n_fft, int hop, float* mag, void* stream)
 {
+    return sot_stft_mag_forward_spec(audio, batch, samples, audio_row_stride, window, n_fft, hop, mag, nullptr, stream);
+}
+
+int sot_stft_mag_forward_spec(const float* audio, int64_t batch, int64_t samples, int64_t audio_row_stride, const float* window,
+                              int n_fft, int hop, float* mag, float* spec, void* stream)
+{
     using namespace sot_stft;
     StftArgs a{};
     const int rc = fill_args(audio, batch, samples, audio_row_stride, window, n_fft, hop, &a);
     if (rc != SOT_OK) return rc;
     if (batch == 0) return SOT_OK;
     if (mag == nullptr) return SOT_ERR_NULL_POINTER;
+    if (spec != nullptr && reinterpret_cast<uintptr_t>(spec) % 8 != 0) return SOT_ERR_BAD_SHAPE;
     a.mag = mag;
+    a.spec = reinterpret_cast<float2*>(spec); a.spec_first = 0;
     (void)hipGetLastError();
     if (!launch_forward_wave(a, batch * a.frames, reinterpret_cast<hipStream_t>(stream)))
         launch_forward(batch * a.frames, reinterpret_cast<hipStream_t>(stream), a);
@@ -892,6 +940,13 @@ int sot_stft_mag_forward(const float* audio, int64_t batch, int64_t samples, int
 int sot_stft_mag_forward_pair(const float* audio_a, int64_t row_stride_a, const float* audio_b, int64_t row_stride_b,
                               int64_t batch_each, int64_t samples, const float* window, int n_fft, int hop, float* mag, void* stream)
 {
+    return sot_stft_mag_forward_pair_spec(audio_a, row_stride_a, audio_b, row_stride_b, batch_each, samples, window, n_fft, hop, mag, nullptr, stream);
+}
+
+int sot_stft_mag_forward_pair_spec(const float* audio_a, int64_t row_stride_a, const float* audio_b, int64_t row_stride_b,
+                                   int64_t batch_each, int64_t samples, const float* window, int n_fft, int hop, float* mag, float* spec_b,
+                                   void* stream)
+{
     using namespace sot_stft;
     if (row_stride_b < samples) return SOT_ERR_BAD_SHAPE;
     StftArgs a{};
@@ -899,8 +954,10 @@ int sot_stft_mag_forward_pair(const float* audio_a, int64_t row_stride_a, const 
     if (rc != SOT_OK) return rc;
     if (batch_each == 0) return SOT_OK;
     if (mag == nullptr || audio_b == nullptr) return SOT_ERR_NULL_POINTER;
+    if (spec_b != nullptr && reinterpret_cast<uintptr_t>(spec_b) % 8 != 0) return SOT_ERR_BAD_SHAPE;
     a.audio_b = audio_b; a.split = batch_each; a.row_stride_b = row_stride_b;
     a.mag = mag;
+    a.spec = reinterpret_cast<float2*>(spec_b); a.spec_first = batch_each;   // the spectrum of the SECOND signal only (the estimate: the one that is differentiated)
     (void)hipGetLastError();
     if (!launch_forward_wave(a, 2 * batch_each * a.frames, reinterpret_cast<hipStream_t>(stream)))
         launch_forward(2 * batch_each * a.frames, reinterpret_cast<hipStream_t>(stream), a);
@@ -920,10 +977,21 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
                           int n_fft, int hop, const float* grad_mag, const float* grad_scale, float* grad_audio, int accumulate,
                           void* workspace, size_t workspace_bytes, void* stream)
 {
+    return sot_stft_mag_backward_spec(audio, nullptr, batch, samples, audio_row_stride, window, n_fft, hop, grad_mag, grad_scale, grad_audio,
+                                      accumulate, workspace, workspace_bytes, stream);
+}
+
+int sot_stft_mag_backward_spec(const float* audio, const float* spec, int64_t batch, int64_t samples, int64_t audio_row_stride,
+                               const float* window, int n_fft, int hop, const float* grad_mag, const float* grad_scale, float* grad_audio,
+                               int accumulate, void* workspace, size_t workspace_bytes, void* stream)
+{
     using namespace sot_stft;
     StftArgs a{};
+    if (spec != nullptr && audio == nullptr) { audio = spec; audio_row_stride = samples; }   // never read: the spectra replace the audio
+    if (spec != nullptr && reinterpret_cast<uintptr_t>(spec) % 8 != 0) return SOT_ERR_BAD_SHAPE;
     const int rc = fill_args(audio, batch, samples, audio_row_stride, window, n_fft, hop, &a);
     if (rc != SOT_OK) return rc;
+    a.spec_in = reinterpret_cast<const float2*>(spec);
     if (batch == 0) return SOT_OK;
     if (grad_mag == nullptr || grad_audio == nullptr || workspace == nullptr) return SOT_ERR_NULL_POINTER;
     if (workspace_bytes < sot_stft_backward_workspace_bytes(batch, samples, n_fft, hop)) return SOT_ERR_WORKSPACE;
@@ -936,7 +1004,8 @@ int sot_stft_mag_backward(const float* audio, int64_t batch, int64_t samples, in
     a.span = (int)span;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
+    if (spec != nullptr) SOT_STFT_LAUNCH(stft_mag_backward_spec_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
+    else SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
     const int64_t per_clip = (samples + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(stft_overlap_add_kernel, dim3((unsigned)(per_clip < 64 ? per_clip : 64), (unsigned)(batch < 65535 ? batch : 65535)), dim3(kThreads), 0, st, a);

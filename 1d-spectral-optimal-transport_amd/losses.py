@@ -425,25 +425,34 @@ class _MultiScaleSpectral(torch.autograd.Function):
         from . import spectra
         target_audio, audio = target_audio.contiguous(), audio.contiguous()
         total = None
-        saved = []
+        saved, specs = [], []
         for size in fft_sizes:
             hop = int(size * (1.0 - 0.75))                      # compute_mag's default overlap (features.py:214-216)
             win = spectra._cached_window(None, size, audio.device)   # window=None -> hann (features.py:203-204)
+            cplx = None
             if target_audio.shape == audio.shape:
-                t, v = nat.stft_mag_forward_pair(target_audio, audio, win, size, hop)   # one launch for both signals
+                if ctx.needs_input_grad[1] and spectra.SAVE_SPECTRUM:   # + the estimate's complex spectrum for the backward
+                    t, v, cplx = nat.stft_mag_forward_pair(target_audio, audio, win, size, hop, want_spec_b=True)
+                else:
+                    t, v = nat.stft_mag_forward_pair(target_audio, audio, win, size, hop)   # one launch for both signals
             else:
                 t, v = nat.stft_mag_forward(target_audio, win, size, hop), nat.stft_mag_forward(audio, win, size, hop)
             total = nat.spec_distance_forward(t, v, mag_weight, logmag_weight, 1e-5, l2, accumulate_into=total)   # total += d
             saved += [t, v]
-        ctx.save_for_backward(target_audio, audio, *saved)
-        ctx.cfg = (tuple(fft_sizes), mag_weight, logmag_weight, l2)
+            specs.append(cplx)
+        have = [c is not None for c in specs]
+        ctx.save_for_backward(target_audio, audio, *saved, *[c for c in specs if c is not None])
+        ctx.cfg = (tuple(fft_sizes), mag_weight, logmag_weight, l2, have)
         return total
 
     @staticmethod
     def backward(ctx, g):
         from . import spectra
         target_audio, audio, *saved = ctx.saved_tensors
-        fft_sizes, mag_weight, logmag_weight, l2 = ctx.cfg
+        fft_sizes, mag_weight, logmag_weight, l2, have = ctx.cfg
+        cplx_list = saved[2 * len(fft_sizes):]
+        cplx_iter = iter(cplx_list)
+        cplx = [next(cplx_iter) if h else None for h in have]
         need_t, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = g.float().reshape(1)
         grad_t = grad_v = None   # the first scale's kernel writes the gradient, the later ones add to it
@@ -453,7 +462,7 @@ class _MultiScaleSpectral(torch.autograd.Function):
             t, v = saved[2 * i], saved[2 * i + 1]
             gt, gv = nat.spec_distance_backward(t, v, mag_weight, logmag_weight, g, 1.0, 1e-5, l2, need_target=need_t, need_value=need_v)
             if need_v:
-                grad_v = nat.stft_mag_backward(audio, win, size, hop, gv, accumulate_into=grad_v)
+                grad_v = nat.stft_mag_backward(audio, win, size, hop, gv, accumulate_into=grad_v, spec=cplx[i])
             if need_t:
                 grad_t = nat.stft_mag_backward(target_audio, win, size, hop, gt, accumulate_into=grad_t)
         return grad_t, grad_v, None, None, None, None

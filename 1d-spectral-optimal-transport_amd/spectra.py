@@ -81,6 +81,9 @@ def _cached_window(name, n_fft: int, device) -> torch.Tensor:
     return _WINDOWS.get((str(name), int(n_fft), str(device)), device, lambda: analysis_window(name, n_fft, device), host_side=True)
 
 
+SAVE_SPECTRUM = True   # module switch (tests compare both forms): differentiated forwards also store the complex spectrum
+
+
 class _StftMagnitude(torch.autograd.Function):
     """sot_stft_mag_forward / sot_stft_mag_backward (include/sot_hip.h)."""
 
@@ -88,15 +91,21 @@ class _StftMagnitude(torch.autograd.Function):
     def forward(ctx, audio, window, n_fft, hop):
         from . import _native as nat
         audio = audio.contiguous()
-        ctx.save_for_backward(audio, window)
         ctx.n_fft, ctx.hop = n_fft, hop
+        if ctx.needs_input_grad[0] and SAVE_SPECTRUM:   # keep the complex spectrum (what abs o stft's autograd saves): no recompute in backward
+            mag, spec = nat.stft_mag_forward(audio, window, n_fft, hop, want_spec=True)
+            ctx.save_for_backward(audio, window, spec)
+            return mag
+        ctx.save_for_backward(audio, window)
         return nat.stft_mag_forward(audio, window, n_fft, hop)
 
     @staticmethod
     def backward(ctx, grad_mag):
         from . import _native as nat
-        audio, window = ctx.saved_tensors
-        grad_audio = nat.stft_mag_backward(audio, window, ctx.n_fft, ctx.hop, grad_mag.float()) if ctx.needs_input_grad[0] else None
+        audio, window, *spec = ctx.saved_tensors
+        grad_audio = None
+        if ctx.needs_input_grad[0]:
+            grad_audio = nat.stft_mag_backward(audio, window, ctx.n_fft, ctx.hop, grad_mag.float(), spec=spec[0] if spec else None)
         return grad_audio, None, None, None
 
 
@@ -343,7 +352,11 @@ class _AudioToLoss(torch.autograd.Function):
     def forward(ctx, audio_target, audio_estimate, window, pos_x, pos_y, n_fft, hop, p, flags, plan):
         from . import _native as nat
         audio_estimate = audio_estimate.contiguous()
-        spec_x, spec_y = nat.stft_mag_forward_pair(audio_target.contiguous(), audio_estimate, window, n_fft, hop)
+        cplx = None
+        if ctx.needs_input_grad[1] and SAVE_SPECTRUM:   # the estimate's complex spectrum rides along: the backward skips its forward transforms
+            spec_x, spec_y, cplx = nat.stft_mag_forward_pair(audio_target.contiguous(), audio_estimate, window, n_fft, hop, want_spec_b=True)
+        else:
+            spec_x, spec_y = nat.stft_mag_forward_pair(audio_target.contiguous(), audio_estimate, window, n_fft, hop)
         rows_x = spec_x.view(-1, spec_x.shape[-1])
         rows_y = spec_y.view(-1, spec_y.shape[-1])
         ctx.early_gy = None
@@ -351,23 +364,24 @@ class _AudioToLoss(torch.autograd.Function):
             mean, _, ctx.early_gy = nat.loss_and_grad(rows_x, rows_y, pos_x, pos_y, p, flags, plan)
         else:
             mean, _, _ = nat.loss_fused(rows_x, rows_y, pos_x, pos_y, p, flags, plan)
-        ctx.save_for_backward(audio_estimate, window, rows_x, rows_y, pos_x, pos_y)
+        ctx.save_for_backward(audio_estimate, window, rows_x, rows_y, pos_x, pos_y, *([cplx] if cplx is not None else []))
         ctx.cfg = (n_fft, hop, p, flags, plan, tuple(spec_y.shape))
         return mean
 
     @staticmethod
     def backward(ctx, g):
         from . import _native as nat
-        audio_estimate, window, rows_x, rows_y, pos_x, pos_y = ctx.saved_tensors
+        audio_estimate, window, rows_x, rows_y, pos_x, pos_y, *cplx = ctx.saved_tensors
+        cplx = cplx[0] if cplx else None
         n_fft, hop, p, flags, plan, shape = ctx.cfg
         if not ctx.needs_input_grad[1]:
             return (None,) * 10
         if ctx.early_gy is not None:   # d mean / d spectrum from the forward pass; the STFT backward applies the upstream scalar
-            grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, ctx.early_gy.view(shape), g.float().contiguous())
+            grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, ctx.early_gy.view(shape), g.float().contiguous(), spec=cplx)
         else:
             _, gy = nat.backward_rows(rows_x, rows_y, pos_x, pos_y, p, flags, g.float(), need_gx=False, need_gy=True, plan=plan,
                                       grad_scale=1.0 / rows_x.shape[0])
-            grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, gy.view(shape))
+            grad_audio = nat.stft_mag_backward(audio_estimate, window, n_fft, hop, gy.view(shape), spec=cplx)
         return None, grad_audio, None, None, None, None, None, None, None, None
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 4   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 5   /* bumped on every change of a signature below; the binding checks it */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -229,6 +229,20 @@ int sot_stft_mag_forward_pair(const float *audio_a, int64_t row_stride_a, const 
  * no gradient, as torch's sgn(0) = 0); deterministic (groups of frames overlap-added in a fixed order, no atomics).
  * grad_scale: optional DEVICE scalar that multiplies grad_mag (the upstream gradient of a loss whose dL/d(mag) was
  * computed ahead of the backward pass, sot_w1d_loss_and_grad), or NULL. */
+/* Round 3: the forward can also hand out the COMPLEX spectrum X (what torch.abs's autograd node saves of torch.stft's output), `spec`:
+ * [batch, frames, n_fft/2 + 1] interleaved (re, im) float pairs, 8-byte aligned, or NULL; in the pair form for the SECOND signal only
+ * (`spec_b`: [batch_each, frames, n_fft/2 + 1, 2]; the estimate, the one a training step differentiates).  sot_stft_mag_backward_spec
+ * then takes that spectrum instead of the audio (audio may be NULL) and skips the forward transform it would otherwise recompute per
+ * frame: the same gradient bit for bit, n_fft 2048 on 4096 frames 46 -> ~30 us. */
+int sot_stft_mag_forward_spec(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,
+                              const float *window, int n_fft, int hop, float *mag, float *spec /* or NULL */, void *stream);
+int sot_stft_mag_forward_pair_spec(const float *audio_a, int64_t row_stride_a, const float *audio_b, int64_t row_stride_b,
+                                   int64_t batch_each, int64_t samples, const float *window, int n_fft, int hop,
+                                   float *mag, float *spec_b /* or NULL */, void *stream);
+int sot_stft_mag_backward_spec(const float *audio /* may be NULL when spec is given */, const float *spec /* or NULL */, int64_t batch,
+                               int64_t samples, int64_t audio_row_stride, const float *window, int n_fft, int hop,
+                               const float *grad_mag, const float *grad_scale, float *grad_audio, int accumulate,
+                               void *workspace, size_t workspace_bytes, void *stream);
 size_t sot_stft_backward_workspace_bytes(int64_t batch, int64_t samples, int n_fft, int hop);
 int sot_stft_mag_backward(const float *audio, int64_t batch, int64_t samples, int64_t audio_row_stride,
                           const float *window, int n_fft, int hop, const float *grad_mag, const float *grad_scale,

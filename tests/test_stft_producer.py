@@ -433,3 +433,77 @@ def test_chain_with_n_fft_4096_runs_the_2049_bin_kernels():
         assert abs(float(loss.detach()) - float(want.detach())) <= tol_loss * abs(float(want.detach())), mode
         assert float((a1.grad - a2.grad).abs().max()) <= tol_grad * float(a2.grad.abs().max()), mode
         assert float((a1.grad - a2.grad).norm()) <= 5e-2 * float(a2.grad.norm()), mode   # observed: p1 1.9e-2 (see above)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,samples,batch", [(2048, 256, 4096, 9), (512, 256, 4096, 33), (512, 128, 1000, 5), (1024, 256, 5000, 3),
+                                                      (64, 16, 100, 17), (128, 32, 777, 6), (256, 64, 4096, 4), (4096, 1024, 9000, 2)])
+def test_backward_from_the_saved_spectrum_is_bit_identical(n_fft, hop, samples, batch):
+    """Round 3: the forward can store the complex spectrum (sot_stft_mag_forward_spec / _pair_spec) and the backward takes it instead
+    of recomputing every frame's forward transform (sot_stft_mag_backward_spec).  The stored spectrum is torch.stft's (normalized) up
+    to the 1/sqrt(n_fft) the magnitudes carry; magnitudes and gradients are bit for bit those of the recomputing kernels, in the
+    single form, the pair form (second signal) and with accumulation + an upstream scalar."""
+    from sot_amd import spectra
+    nat = native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(n_fft + samples)
+    a = torch.rand(batch, samples, device=dev, generator=g) - 0.5
+    b = torch.rand(batch, samples, device=dev, generator=g) - 0.5
+    win = spectra._cached_window("flattop", n_fft, dev)
+    mag = nat.stft_mag_forward(a, win, n_fft, hop)
+    mag2, spec = nat.stft_mag_forward(a, win, n_fft, hop, want_spec=True)
+    assert torch.equal(mag, mag2) and spec.shape == mag.shape + (2,)
+    ref = torch.stft(spectra.end_padded(a, n_fft, hop), n_fft=n_fft, hop_length=hop, win_length=n_fft, window=win, center=False,
+                     normalized=False, return_complex=True).permute(0, 2, 1)
+    got = torch.view_as_complex(spec)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    gm = torch.rand(mag.shape, device=dev, generator=g)
+    want = nat.stft_mag_backward(a, win, n_fft, hop, gm)
+    assert torch.equal(nat.stft_mag_backward(a, win, n_fft, hop, gm, spec=spec), want)
+    # pair form: the spectrum of the SECOND signal
+    ma, mb, spec_b = nat.stft_mag_forward_pair(a, b, win, n_fft, hop, want_spec_b=True)
+    ma0, mb0 = nat.stft_mag_forward_pair(a, b, win, n_fft, hop)
+    assert torch.equal(ma, ma0) and torch.equal(mb, mb0)
+    _, spec_b1 = nat.stft_mag_forward(b, win, n_fft, hop, want_spec=True)
+    assert torch.equal(spec_b, spec_b1)
+    up = torch.full((1,), 0.37, device=dev)
+    base = torch.rand(batch, samples, device=dev, generator=g)
+    want2 = nat.stft_mag_backward(b, win, n_fft, hop, gm, grad_scale=up, accumulate_into=base.clone())
+    got2 = nat.stft_mag_backward(b, win, n_fft, hop, gm, grad_scale=up, accumulate_into=base.clone(), spec=spec_b)
+    assert torch.equal(got2, want2)
+
+
+@pytest.mark.gpu
+def test_autograd_nodes_with_and_without_the_saved_spectrum_agree():
+    """stft_magnitude, the one-node training slice and MSSLoss with spectra.SAVE_SPECTRUM on (default) and off: identical values and
+    gradients."""
+    from sot_amd import spectra
+    from sot_amd.losses import MSSLoss, Wasserstein1D
+    native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(4)
+    tgt = spectra.harmonic_batch(12, generator=g, device=dev)
+    est = spectra.harmonic_batch(12, generator=g, device=dev)
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+    mss = MSSLoss(mag_weight=1.0, logmag_weight=1.0).to(dev)
+    out = {}
+    for on in (True, False):
+        spectra.SAVE_SPECTRUM = on
+        try:
+            res = []
+            e = est.clone().requires_grad_(True)
+            spectra.stft_magnitude(e, 512, 256).pow(2).sum().backward()
+            res.append(e.grad.clone())
+            e = est.clone().requires_grad_(True)
+            loss = spectra.training_step_slice(mod, tgt, e)
+            (loss * 1.7).backward()
+            res += [loss.detach().clone(), e.grad.clone()]
+            e = est.clone().requires_grad_(True)
+            loss = mss(tgt, e)
+            loss.backward()
+            res += [loss.detach().clone(), e.grad.clone()]
+            out[on] = res
+        finally:
+            spectra.SAVE_SPECTRUM = True
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
