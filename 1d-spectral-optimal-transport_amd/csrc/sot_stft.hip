@@ -28,7 +28,10 @@
 namespace sot_stft {
 
 constexpr int kThreads = 256;
-constexpr int kFramesPerGroup = 2;  // backward: one frame slot per group of consecutive frames of a clip
+#ifndef SOT_STFT_FRAMES_PER_GROUP
+#define SOT_STFT_FRAMES_PER_GROUP 2
+#endif
+constexpr int kFramesPerGroup = SOT_STFT_FRAMES_PER_GROUP;  // backward: one frame slot per group of consecutive frames of a clip
 constexpr int kMaxFft = 4096;
 
 #include "sot_stft_tables.inc"      // kPassTw, kWn (csrc/gen/make_stft_tables.py)

@@ -55,7 +55,17 @@ def test_kernel_name_follows_shape_and_mode():
     assert b.forward_kernel_name(1025, "cutoff") == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
     assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<128, 9, 2, 2, true, true, 1025, false, true, 4>"
     assert b.forward_kernel_name(2048, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 2, 2, true, true, 0, false, true, 1>"
-    assert "generic" in b.forward_kernel_name(3000, "p1")
+    assert b.forward_kernel_name(3000, "p1") == "sot_area_full_kernel<512, 8, 1, false, -1>"            # run-time length on the 4096 geometry
+    assert b.forward_kernel_name(2000, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 1, 2, true, true, -1, false, false, 1>"
+    assert "generic" in b.forward_kernel_name(100, "p1") and "generic" in b.forward_kernel_name(9000, "p1")
+
+
+def test_visible_gpus_reads_the_environment_not_the_runtime(monkeypatch):
+    b = _bench_module()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3,5")
+    assert b.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert b.visible_gpus() == 0
 
 
 def test_bench_uses_the_oracle_only_for_the_cpu_baseline():

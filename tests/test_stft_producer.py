@@ -443,6 +443,7 @@ def test_backward_from_the_saved_spectrum_is_bit_identical(n_fft, hop, samples, 
     of recomputing every frame's forward transform (sot_stft_mag_backward_spec).  The stored spectrum is torch.stft's (normalized) up
     to the 1/sqrt(n_fft) the magnitudes carry; magnitudes and gradients are bit for bit those of the recomputing kernels, in the
     single form, the pair form (second signal) and with accumulation + an upstream scalar."""
+    from gpu_util import device, native
     from sot_amd import spectra
     nat = native()
     dev = device()
@@ -477,6 +478,7 @@ def test_backward_from_the_saved_spectrum_is_bit_identical(n_fft, hop, samples, 
 def test_autograd_nodes_with_and_without_the_saved_spectrum_agree():
     """stft_magnitude, the one-node training slice and MSSLoss with spectra.SAVE_SPECTRUM on (default) and off: identical values and
     gradients."""
+    from gpu_util import device, native
     from sot_amd import spectra
     from sot_amd.losses import MSSLoss, Wasserstein1D
     native()
