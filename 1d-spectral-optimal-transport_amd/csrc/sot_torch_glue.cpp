@@ -31,6 +31,10 @@ struct Api {
     decltype(&sot_w1d_loss_and_grad) loss_and_grad = nullptr;
     decltype(&sot_w1d_backward) backward = nullptr;
     decltype(&sot_scale_inplace) scale_inplace = nullptr;
+    decltype(&sot_stft_frames) stft_frames = nullptr;
+    decltype(&sot_stft_mag_forward_pair_spec) stft_pair = nullptr;
+    decltype(&sot_stft_mag_backward_spec) stft_backward = nullptr;
+    decltype(&sot_stft_backward_workspace_bytes) stft_backward_ws = nullptr;
 };
 Api g_api;
 
@@ -52,6 +56,10 @@ int64_t bind_library(const std::string& path)
     bind_symbol(handle, "sot_w1d_loss_and_grad", g_api.loss_and_grad);
     bind_symbol(handle, "sot_w1d_backward", g_api.backward);
     bind_symbol(handle, "sot_scale_inplace", g_api.scale_inplace);
+    bind_symbol(handle, "sot_stft_frames", g_api.stft_frames);
+    bind_symbol(handle, "sot_stft_mag_forward_pair_spec", g_api.stft_pair);
+    bind_symbol(handle, "sot_stft_mag_backward_spec", g_api.stft_backward);
+    bind_symbol(handle, "sot_stft_backward_workspace_bytes", g_api.stft_backward_ws);
     TORCH_CHECK(g_api.abi() == SOT_ABI_VERSION, "sot glue: libsot_hip.so has ABI version ", g_api.abi(), ", this glue was built for ",
                 SOT_ABI_VERSION);
     return g_api.abi();
@@ -185,6 +193,84 @@ at::Tensor mean_loss(const at::Tensor& x, const at::Tensor& y, const at::Tensor&
     return mean_loss_nograd(x, y, Plan{xs, ys, xperm, yperm, ident}, p, flags);
 }
 
+// ---- the training-step slice trainer.py:192-228 runs around the loss, audio in (spectra.training_step_slice / _AudioToLoss): magnitude
+// STFT of target and estimate in one launch (keeping the estimate's complex spectrum), SOT loss + d mean / d spectrum in one pass,
+// and on the way back the STFT backward from the stored spectrum with the upstream scalar applied inside it.  Differentiates w.r.t.
+// the estimate's audio only.
+class AudioToLoss : public torch::autograd::Function<AudioToLoss> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate,
+                              const at::Tensor& window, const at::Tensor& xs, const at::Tensor& ys, const at::Tensor& xperm,
+                              const at::Tensor& yperm, const at::Tensor& ident, int64_t n_fft, int64_t hop, double p, int64_t flags, bool grad)
+    {
+        TORCH_CHECK(target.is_cuda() && target.scalar_type() == at::kFloat && target.dim() == 2 && target.is_contiguous() &&
+                    estimate.is_cuda() && estimate.scalar_type() == at::kFloat && estimate.is_contiguous() && estimate.sizes() == target.sizes(),
+                    "sot glue: target and estimate must be contiguous float32 GPU tensors [clips, samples] of one shape");
+        TORCH_CHECK(window.is_cuda() && window.scalar_type() == at::kFloat && window.is_contiguous() && window.numel() == n_fft &&
+                    reinterpret_cast<uintptr_t>(window.data_ptr<float>()) % 8 == 0, "sot glue: window must hold n_fft float32 taps, 8-byte aligned");
+        const int64_t clips = target.size(0), samples = target.size(1);
+        const int64_t frames = g_api.stft_frames(samples, (int)hop), bins = n_fft / 2 + 1;
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(target.device());
+        void* st = current_stream(target);
+        at::Tensor mag = at::empty({2 * clips, frames, bins}, target.options());
+        at::Tensor cplx = grad ? at::empty({clips, frames, bins, 2}, target.options()) : at::Tensor();
+        check_status(g_api.stft_pair(target.data_ptr<float>(), samples, estimate.data_ptr<float>(), samples, clips, samples,
+                                     window.data_ptr<float>(), (int)n_fft, (int)hop, mag.data_ptr<float>(),
+                                     grad ? cplx.data_ptr<float>() : nullptr, st), p);
+        const at::Tensor rows_x = mag.narrow(0, 0, clips).view({clips * frames, bins});
+        const at::Tensor rows_y = mag.narrow(0, clips, clips).view({clips * frames, bins});
+        const Plan plan{xs, ys, xperm, yperm, ident};
+        sot_problem pr = make_problem(rows_x, rows_y, plan, p, flags);
+        at::Tensor rows = at::empty({pr.B}, target.options());
+        at::Tensor mean = at::empty({}, target.options());
+        if (grad) {
+            at::Tensor gy = at::empty({clips, frames, bins}, target.options());
+            check_status(g_api.loss_and_grad(&pr, rows.data_ptr<float>(), (double)pr.B, mean.data_ptr<float>(), nullptr, (float)(1.0 / (double)pr.B),
+                                             gy.data_ptr<float>(), nullptr, nullptr, 0, st), p);
+            ctx->save_for_backward({window});
+            ctx->saved_data["gy"] = gy;
+            ctx->saved_data["cplx"] = cplx;
+            ctx->saved_data["n_fft"] = n_fft;
+            ctx->saved_data["hop"] = hop;
+            ctx->saved_data["samples"] = samples;
+        } else {
+            check_status(g_api.loss(&pr, rows.data_ptr<float>(), (double)pr.B, 0, 0.0f, mean.data_ptr<float>(), nullptr, nullptr, nullptr, 0, st), p);
+        }
+        return mean;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs)
+    {
+        at::Tensor g = grad_outputs[0];
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        g = g.contiguous();
+        const at::Tensor gy = ctx->saved_data["gy"].toTensor(), cplx = ctx->saved_data["cplx"].toTensor();
+        const at::Tensor window = ctx->get_saved_variables()[0];
+        const int64_t n_fft = ctx->saved_data["n_fft"].toInt(), hop = ctx->saved_data["hop"].toInt(), samples = ctx->saved_data["samples"].toInt();
+        const int64_t clips = gy.size(0);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(gy.device());
+        at::Tensor grad_audio = at::empty({clips, samples}, gy.options());
+        const size_t ws_bytes = g_api.stft_backward_ws(clips, samples, (int)n_fft, (int)hop);
+        at::Tensor ws = at::empty({(int64_t)(ws_bytes > 0 ? ws_bytes : 1)}, gy.options().dtype(at::kByte));
+        // the gradient is read, never modified: a second backward through a retained graph runs the same call again
+        check_status(g_api.stft_backward(nullptr, cplx.data_ptr<float>(), clips, samples, samples, window.data_ptr<float>(), (int)n_fft, (int)hop,
+                                         gy.data_ptr<float>(), g.data_ptr<float>(), grad_audio.data_ptr<float>(), 0, ws.data_ptr(), ws_bytes,
+                                         current_stream(gy)), 1.0);
+        return {at::Tensor(), grad_audio, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor audio_to_loss(const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window, const at::Tensor& xs,
+                         const at::Tensor& ys, const at::Tensor& xperm, const at::Tensor& yperm, const at::Tensor& ident, int64_t n_fft,
+                         int64_t hop, double p, int64_t flags)
+{
+    TORCH_CHECK(g_api.stft_pair != nullptr, "sot glue: bind() has not been called");
+    TORCH_CHECK(!(at::GradMode::is_enabled() && target.requires_grad()), "sot glue: a gradient w.r.t. the target is not this path's case");
+    const bool grad = at::GradMode::is_enabled() && estimate.requires_grad();   // decided here: forward() runs with grad mode off
+    return AudioToLoss::apply(target, estimate, window, xs, ys, xperm, yperm, ident, n_fft, hop, p, flags, grad);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -192,4 +278,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.doc() = "host path of sot_amd.losses.Wasserstein1D in C++ (one call per forward, C++ autograd node); kernels: libsot_hip.so";
     m.def("bind", &bind_library, "dlopen libsot_hip.so at `path` and resolve the entry points; returns its ABI version");
     m.def("mean_loss", &mean_loss, "mean over the rows of W_p^p(x_r, y_r) on planned shared positions; differentiable w.r.t. y");
+    m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
 }

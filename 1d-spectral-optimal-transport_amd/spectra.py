@@ -407,10 +407,18 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
              hip_stft_supported(n_fft, hop, audio_target.shape[1]) and not getattr(loss_module, "hinge", False) and
              not target_needs_grad)
     if fused:
-        from .losses import _flags
+        from . import _native as nat
+        from .losses import EARLY_GRADIENT, _flags
         flags = _flags(loss_module.square_dist, bool(loss_module.dont_normalize), bool(loss_module.limit_quantile_range),
                        loss_module.require_sort)
         plan = loss_module._plans.get(pos[0], pos[1]) if loss_module.require_sort else None
+        glue = nat.glue() if (plan is not None and EARLY_GRADIENT and SAVE_SPECTRUM and audio_target.dtype == torch.float32 and
+                              audio_estimate.dtype == torch.float32) else None
+        if glue is not None:   # the same four / three kernels behind ONE C++ call and a C++ autograd node (csrc/sot_torch_glue.cpp)
+            plan.use_on_current_stream(dev)
+            return glue.audio_to_loss(audio_target.contiguous(), audio_estimate.contiguous(), _cached_window(window, n_fft, dev),
+                                      plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, int(n_fft), int(hop),
+                                      float(loss_module.p), nat.problem_flags(loss_module.p, flags, plan))
         return _AudioToLoss.apply(audio_target.float(), audio_estimate.float(), _cached_window(window, n_fft, dev), pos[0], pos[1],
                                   int(n_fft), int(hop), float(loss_module.p), flags, plan)
     spec_x = stft_magnitude(audio_target, n_fft, hop, window)

@@ -509,3 +509,37 @@ def test_autograd_nodes_with_and_without_the_saved_spectrum_agree():
             spectra.SAVE_SPECTRUM = True
     for a, b in zip(out[True], out[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_cpp_training_slice_equals_the_python_node():
+    """spectra.training_step_slice goes through the C++ host path (glue.audio_to_loss: one call, C++ autograd node); same C-ABI calls as
+    the Python node _AudioToLoss, hence the same bits: loss, audio gradient, an upstream factor, a second backward, no-grad."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    from sot_amd.losses import Wasserstein1D, _flags
+    nat = native()
+    dev = device()
+    assert nat.glue() is not None
+    g = torch.Generator(device=dev).manual_seed(8)
+    tgt = spectra.harmonic_batch(20, generator=g, device=dev)
+    est = spectra.harmonic_batch(20, generator=g, device=dev)
+    for n_fft, hop in ((2048, 256), (512, 256)):
+        mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+        e1 = est.clone().requires_grad_(True)
+        out = spectra.training_step_slice(mod, tgt, e1, n_fft=n_fft, hop=hop)
+        assert type(out.grad_fn).__name__ == "CppFunction" and "AudioToLoss" in out.grad_fn.name()
+        (out * 0.5).backward(retain_graph=True)
+        g_half = e1.grad.clone()
+        e1.grad = None
+        out.backward()
+        pos = spectra._POSITIONS[(n_fft, 16000.0, str(dev))]
+        flags = _flags(True, True, True, True)
+        plan = mod._plans.get(pos[0], pos[1])
+        e2 = est.clone().requires_grad_(True)
+        ref = spectra._AudioToLoss.apply(tgt, e2, spectra._cached_window("flattop", n_fft, dev), pos[0], pos[1], n_fft, hop, 2.0, flags, plan)
+        ref.backward()
+        assert torch.equal(out.detach(), ref.detach()) and torch.equal(e1.grad, e2.grad)
+        torch.testing.assert_close(g_half, 0.5 * e2.grad, rtol=1e-6, atol=1e-12)
+        with torch.no_grad():
+            assert torch.equal(spectra.training_step_slice(mod, tgt, est, n_fft=n_fft, hop=hop), ref.detach())
