@@ -3,6 +3,7 @@
 # Usage: tools/profile_round.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r1}; shift || true
+case " $* " in *" --gpus "*) echo "profile_round.sh profiles ONE process: bench.py --gpus N > 1 starts its ranks as grandchildren of rocprofv3, which would then profile the launcher only" >&2; exit 2;; esac
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
