@@ -730,6 +730,17 @@ def main():
                     break
         except Exception:
             traffic = None
+        for key in ("paper_mode", "training_form"):   # the same committed PMC passes hold these kernels' traffic
+            try:
+                import glob
+                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{key}.json")), reverse=True):
+                    pj = json.load(open(path))
+                    if key in side and pj.get("kernel") == side[key].get("kernel") and pj.get("workload", "").startswith(f"B={B},N={N},"):
+                        side[key]["traffic"] = pj["hbm_bytes_per_launch"]
+                        side[key]["traffic_source"] = f"{os.path.relpath(path, ROOT)} (committed PMC passes; not measured in this run)"
+                        break
+            except Exception:
+                pass
         rec = {
             "metric": "sot_loss_evals_per_sec", "value": world * B * args.steps / elapsed, "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
