@@ -141,7 +141,7 @@ def load(build_if_missing: bool = True):
 
 
 class SotError(RuntimeError):
-    pass
+    status = None   # the library's negative status code (include/sot_hip.h: sot_status)
 
 
 _glue = None
@@ -194,7 +194,9 @@ def check(rc: int, p=None):
         return
     if rc == SOT_ERR_INVALID_P:  # same exception type and text as losses.py:271
         raise AssertionError(f"The OT loss is only valid for p>=1, {p} was given")
-    raise SotError(f"libsot_hip: {load().sot_status_string(rc).decode()} (status {rc})")
+    err = SotError(f"libsot_hip: {load().sot_status_string(rc).decode()} (status {rc})")
+    err.status = rc
+    raise err
 
 
 def require_hip(*tensors):

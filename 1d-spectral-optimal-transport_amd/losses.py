@@ -60,6 +60,22 @@ def _hip_domain(*tensors) -> bool:
     return False
 
 
+ROW_POINT_LIMIT = 18000   # n + m of the longest row pair the kernels take for sure (one pair's working set lives in ONE CU's 160 KiB
+                          # of LDS; include/sot_hip.h: SOT_ERR_UNSUPPORTED_SIZE beyond ~19000 forward / ~13000 backward)
+
+
+def _beyond_one_cu(x, y) -> bool:
+    """Rows too long for the LDS-resident kernels (n_fft >= 32768): the reference has no size limit (losses.py:223-313), so such GPU
+    tensors run the package's torch-op composition -- said once -- instead of failing.  No paper configuration comes near."""
+    n, m = x.shape[-1], y.shape[-1]
+    limit = ROW_POINT_LIMIT if not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)) else 12000
+    if n + m <= limit:
+        return False
+    warn_once("row-too-long", f"sot_amd: rows of {n} + {m} points exceed what one CU's LDS holds; this call runs the torch-op composition "
+                              "on the GPU instead of the HIP kernels")
+    return True
+
+
 def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized=False):
     return ((nat.FLAG_SQUARE if square_dist else 0) | (nat.FLAG_DONT_NORMALIZE if dont_normalize else 0)
             | (nat.FLAG_LIMIT_Q if limit_quantile_range else 0) | (nat.FLAG_REQUIRE_SORT if require_sort else 0)
@@ -245,7 +261,7 @@ def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, requ
         u_weights = torch.full(u_values.shape, 1.0 / n, device=u_values.device, dtype=u_values.dtype)
     if v_weights is None:
         v_weights = torch.full(v_values.shape, 1.0 / m, device=v_values.device, dtype=v_values.dtype)
-    if not _hip_domain(u_values, v_values, u_weights, v_weights):
+    if not _hip_domain(u_values, v_values, u_weights, v_weights) or _beyond_one_cu(u_weights, v_weights):
         return tp.transport_rows(u_values, v_values, u_weights, v_weights, p=p, require_sort=require_sort,
                                  return_quantiles=return_quantiles, limit_quantile_range=limit_quantile_range)
 
@@ -373,7 +389,7 @@ class Wasserstein1D(torch.nn.Module):
         """Flat [rows] tensor of W_p^p per spectrum pair (after the optional hinge, before the mean):
         what losses.py:186-205 holds before its reshape/mean.  Used by the row-sharded multi-GPU path."""
         x_pos_, y_pos_ = self._positions(x_pos, y_pos)
-        if not _hip_domain(x, y, x_pos_, y_pos_):
+        if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y):
             return self._torch_forward(x, y, x_pos_, y_pos_, kwargs, rows_only=True)
         x, y, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (x, y, x_pos_, y_pos_)):
@@ -386,8 +402,11 @@ class Wasserstein1D(torch.nn.Module):
 
     def forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
         x_pos_, y_pos_ = self._positions(x_pos, y_pos)
-        if not _hip_domain(x, y, x_pos_, y_pos_):
+        if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y):
             return self._torch_forward(x, y, x_pos_, y_pos_, kwargs)
+        return self._hip_forward(x, y, x_pos, y_pos, x_pos_, y_pos_, kwargs)
+
+    def _hip_forward(self, x, y, x_pos, y_pos, x_pos_, y_pos_, kwargs):
         if kwargs.get("return_quantiles", False):
             x2, y2, x_pos_, y_pos_, flags, plan, original_shape = self._marshal(x, y, x_pos, y_pos, kwargs)
             out = nat.quantiles(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)

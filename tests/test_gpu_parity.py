@@ -435,10 +435,16 @@ def test_size_limit_is_an_error_not_a_crash():
     native()
     dev = device()
     x = torch.rand(2, 30000, device=dev)
+    y = torch.rand(2, 30000, device=dev)
     pos = torch.linspace(0, 1, 30000, device=dev)
     from sot_amd.losses import Wasserstein1D
-    with pytest.raises(nat.SotError):
-        Wasserstein1D(p=1)(x, x, x_pos=pos, y_pos=pos)
+    with pytest.raises(nat.SotError) as info:          # the NATIVE layer refuses rows that do not fit one CU's LDS ...
+        nat.forward_rows(x, y, pos, pos.clone(), 1.0, 8)
+    assert info.value.status == nat.SOT_ERR_UNSUPPORTED_SIZE
+    # ... and the module, like the reference (no size limit in losses.py:223-313), still answers: torch ops on the GPU, said once
+    got = Wasserstein1D(p=1)(x, y, x_pos=pos, y_pos=pos)
+    want = Wasserstein1D(p=1)(x.cpu(), y.cpu(), x_pos=pos.cpu(), y_pos=pos.cpu())
+    assert got.is_cuda and abs(float(got) - float(want)) <= 1e-5 * abs(float(want))
 
 
 def test_masked_dense_equals_ragged_removal():
