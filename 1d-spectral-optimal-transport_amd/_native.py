@@ -279,18 +279,23 @@ class PositionPlan:
         lib = load()
         n, m = xpos.numel(), ypos.numel()
         dev = xpos.device
-        self.xpos_sorted = torch.empty(n, dtype=torch.float32, device=dev)
-        self.ypos_sorted = torch.empty(m, dtype=torch.float32, device=dev)
-        self.xperm = torch.empty(n, dtype=torch.int32, device=dev)
-        self.yperm = torch.empty(m, dtype=torch.int32, device=dev)
-        self.ident = torch.empty(2, dtype=torch.int32, device=dev)
         xp, yp = xpos.contiguous(), ypos.contiguous()
         self._same_tensor = n == m and xpos.data_ptr() == ypos.data_ptr()
+        g = glue()
         with _on_device(dev):
             self.stream = stream_ptr(dev)
-            check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
-                                            self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
-                                            self.yperm.data_ptr(), self.ident.data_ptr(), self.stream))
+            if g is not None and xp.ndim == 1 and yp.ndim == 1:
+                # one allocation + one launch (the reference's trainer makes fresh positions, hence a fresh plan, every step)
+                self.xpos_sorted, self.ypos_sorted, self.xperm, self.yperm, self.ident = g.make_plan(xp, yp)
+            else:
+                self.xpos_sorted = torch.empty(n, dtype=torch.float32, device=dev)
+                self.ypos_sorted = torch.empty(m, dtype=torch.float32, device=dev)
+                self.xperm = torch.empty(n, dtype=torch.int32, device=dev)
+                self.yperm = torch.empty(m, dtype=torch.int32, device=dev)
+                self.ident = torch.empty(2, dtype=torch.int32, device=dev)
+                check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
+                                                self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
+                                                self.yperm.data_ptr(), self.ident.data_ptr(), self.stream))
             # the plan is cached and may be consumed from other streams: they wait on this event (see use_plan)
             self.ready = torch.cuda.Event()
             self.ready.record(torch.cuda.current_stream(dev))

@@ -31,6 +31,7 @@ struct Api {
     decltype(&sot_w1d_loss_and_grad) loss_and_grad = nullptr;
     decltype(&sot_w1d_backward) backward = nullptr;
     decltype(&sot_scale_inplace) scale_inplace = nullptr;
+    decltype(&sot_prepare_positions) prepare_positions = nullptr;
     decltype(&sot_stft_frames) stft_frames = nullptr;
     decltype(&sot_stft_mag_forward_pair_spec) stft_pair = nullptr;
     decltype(&sot_stft_mag_backward_spec) stft_backward = nullptr;
@@ -56,6 +57,7 @@ int64_t bind_library(const std::string& path)
     bind_symbol(handle, "sot_w1d_loss_and_grad", g_api.loss_and_grad);
     bind_symbol(handle, "sot_w1d_backward", g_api.backward);
     bind_symbol(handle, "sot_scale_inplace", g_api.scale_inplace);
+    bind_symbol(handle, "sot_prepare_positions", g_api.prepare_positions);
     bind_symbol(handle, "sot_stft_frames", g_api.stft_frames);
     bind_symbol(handle, "sot_stft_mag_forward_pair_spec", g_api.stft_pair);
     bind_symbol(handle, "sot_stft_mag_backward_spec", g_api.stft_backward);
@@ -193,6 +195,30 @@ at::Tensor mean_loss(const at::Tensor& x, const at::Tensor& y, const at::Tensor&
     return mean_loss_nograd(x, y, Plan{xs, ys, xperm, yperm, ident}, p, flags);
 }
 
+// The position plan of one pair of shared grids (sot_prepare_positions) with all five outputs in ONE allocation: the reference's
+// trainer builds x_pos / y_pos afresh every step (trainer.py:187-197), so a plan per step must cost one allocation and one launch,
+// not five allocations.  Returns (sorted x positions, sorted y positions, x permutation, y permutation, identity flags): views of one
+// buffer, each 256-byte aligned.
+std::vector<at::Tensor> make_plan(const at::Tensor& xpos, const at::Tensor& ypos)
+{
+    TORCH_CHECK(g_api.prepare_positions != nullptr, "sot glue: bind() has not been called");
+    TORCH_CHECK(xpos.is_cuda() && ypos.is_cuda() && xpos.scalar_type() == at::kFloat && ypos.scalar_type() == at::kFloat && xpos.dim() == 1 &&
+                ypos.dim() == 1 && xpos.is_contiguous() && ypos.is_contiguous() && xpos.numel() >= 1 && ypos.numel() >= 1,
+                "sot glue: positions must be contiguous 1-D float32 GPU tensors");
+    const int64_t n = xpos.numel(), m = ypos.numel();
+    auto pad = [](int64_t v) { return (v + 63) / 64 * 64; };   // in 4-byte words: 256-byte aligned pieces
+    const int64_t o_ys = pad(n), o_xp = o_ys + pad(m), o_yp = o_xp + pad(n), o_id = o_yp + pad(m), total = o_id + 64;
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(xpos.device());
+    at::Tensor buf = at::empty({total}, xpos.options());
+    at::Tensor ints = buf.view(at::kInt);
+    at::Tensor xs = buf.narrow(0, 0, n), ys = buf.narrow(0, o_ys, m);
+    at::Tensor xperm = ints.narrow(0, o_xp, n), yperm = ints.narrow(0, o_yp, m), ident = ints.narrow(0, o_id, 2);
+    check_status(g_api.prepare_positions(xpos.data_ptr<float>(), ypos.data_ptr<float>(), (int32_t)n, (int32_t)m, xs.data_ptr<float>(),
+                                         ys.data_ptr<float>(), xperm.data_ptr<int32_t>(), yperm.data_ptr<int32_t>(), ident.data_ptr<int32_t>(),
+                                         current_stream(xpos)), 1.0);
+    return {xs, ys, xperm, yperm, ident};
+}
+
 // ---- the training-step slice trainer.py:192-228 runs around the loss, audio in (spectra.training_step_slice / _AudioToLoss): magnitude
 // STFT of target and estimate in one launch (keeping the estimate's complex spectrum), SOT loss + d mean / d spectrum in one pass,
 // and on the way back the STFT backward from the stored spectrum with the upstream scalar applied inside it.  Differentiates w.r.t.
@@ -278,5 +304,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.doc() = "host path of sot_amd.losses.Wasserstein1D in C++ (one call per forward, C++ autograd node); kernels: libsot_hip.so";
     m.def("bind", &bind_library, "dlopen libsot_hip.so at `path` and resolve the entry points; returns its ABI version");
     m.def("mean_loss", &mean_loss, "mean over the rows of W_p^p(x_r, y_r) on planned shared positions; differentiable w.r.t. y");
+    m.def("make_plan", &make_plan, "sot_prepare_positions into one allocation: (sorted x, sorted y, x permutation, y permutation, identity flags)");
     m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
 }

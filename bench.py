@@ -279,6 +279,15 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     e["host_us_per_call"] = wall_us(paper_step, 400)
     e["autograd_floor_us"] = wall_us(floor_step, 400)
     out["b1024n1025_cutoff_module_forward_backward"] = e
+    def paper_step_fresh_positions(i):   # trainer.py:187-197 verbatim: x_pos rebuilt and y_pos = x_pos.clone() on EVERY step -> a new position plan per step
+        yv = ys1[i % 2]
+        yv.grad = None
+        xp_ = pf1 / 1.0
+        cut(xs1, yv, x_pos=xp_, y_pos=xp_.clone()).backward()
+
+    e2 = entry(timed(paper_step_fresh_positions, n), "the same + two elementwise torch kernels + sot_prepare_positions per step", 1024 * (12 * 1025 + 4), l3_resident=True)
+    e2["host_us_per_call"] = wall_us(paper_step_fresh_positions, 400)
+    out["b1024n1025_cutoff_module_forward_backward_fresh_positions"] = e2
     with torch.no_grad():
         out["b1024n1025_cutoff_module_forward"] = entry(timed(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), n),
                                                          forward_kernel_name(1025, "cutoff") + " + batch mean", 1024 * (8 * 1025 + 4), l3_resident=True)
