@@ -234,3 +234,53 @@ def test_cpp_host_path_equals_the_python_binding():
     assert type(both.grad_fn).__name__.startswith("_FusedMeanLoss")   # both gradients: the Python node with the two-gradient backward kernel
     both.backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.gpu
+def test_hot_call_cache_is_invalidated_by_everything_it_depends_on():
+    """Wasserstein1D remembers its last default call (same position tensors, no keywords) and then goes straight to the C++ host path.
+    The entry must not survive: other position tensors, an in-place change of the positions, changed module settings, call keywords,
+    other row lengths, a gradient wanted for x, EARLY_GRADIENT off."""
+    import sot_amd.losses as L
+    from sot_amd.losses import Wasserstein1D
+    nat = native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(12)
+    x, y = torch.rand(8, 300, device=dev, generator=g), torch.rand(8, 300, device=dev, generator=g)
+    pos = torch.linspace(0, 1, 300, device=dev)
+    pos2 = pos.clone()
+    mod = Wasserstein1D(p=2, square_dist=True).to(dev)
+
+    def ref(m, a, b, px, py, **kw):
+        m2 = Wasserstein1D(p=m.p, square_dist=m.square_dist, dont_normalize=m.dont_normalize, limit_quantile_range=m.limit_quantile_range,
+                           require_sort=m.require_sort).to(dev)
+        return m2(a, b, x_pos=px, y_pos=py, **kw)
+
+    first = mod(x, y, x_pos=pos, y_pos=pos2)
+    assert mod._hot is not None
+    assert torch.equal(mod(x, y, x_pos=pos, y_pos=pos2), first)                       # the hot path gives the same bits
+    other = torch.sort(torch.rand(300, device=dev, generator=g)).values
+    assert torch.equal(mod(x, y, x_pos=other, y_pos=other.clone()), ref(mod, x, y, other, other.clone()))
+    mod(x, y, x_pos=pos, y_pos=pos2)
+    pos2.mul_(0.5)                                                                     # in-place change: version counter
+    assert torch.equal(mod(x, y, x_pos=pos, y_pos=pos2), ref(mod, x, y, pos, pos2.clone()))
+    mod.dont_normalize = True                                                          # a module setting changed after the entry was made
+    assert torch.equal(mod(x, y, x_pos=pos, y_pos=pos2), ref(mod, x, y, pos, pos2))
+    assert torch.equal(mod(x, y, x_pos=pos, y_pos=pos2, limit_quantile_range=True),    # call keyword
+                       Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)(x, y, x_pos=pos, y_pos=pos2))
+    with pytest.raises(RuntimeError):
+        mod(x[:, :200], y[:, :200], x_pos=pos, y_pos=pos2)                            # other row length than the positions
+    xg = x.clone().requires_grad_(True)
+    out = mod(xg, y, x_pos=pos, y_pos=pos2)
+    out.backward()
+    assert xg.grad is not None                                                         # gradient for x: not the hot path's case
+    L.EARLY_GRADIENT = False
+    try:
+        yg = y.clone().requires_grad_(True)
+        assert type(mod(x, yg, x_pos=pos, y_pos=pos2).grad_fn).__name__.startswith("_FusedMeanLoss")
+    finally:
+        L.EARLY_GRADIENT = True
+    m3 = Wasserstein1D(p=1, fixed_x=300).to(dev)                                        # the fixed_x buffer form, 3-D rows
+    a = m3(x.reshape(2, 4, 300), y.reshape(2, 4, 300))
+    assert torch.equal(m3(x.reshape(2, 4, 300), y.reshape(2, 4, 300)), a) and m3._hot is not None
+    assert torch.equal(a, m3(x, y))

@@ -444,7 +444,8 @@ def test_size_limit_is_an_error_not_a_crash():
     # ... and the module, like the reference (no size limit in losses.py:223-313), still answers: torch ops on the GPU, said once
     got = Wasserstein1D(p=1)(x, y, x_pos=pos, y_pos=pos)
     want = Wasserstein1D(p=1)(x.cpu(), y.cpu(), x_pos=pos.cpu(), y_pos=pos.cpu())
-    assert got.is_cuda and abs(float(got) - float(want)) <= 1e-5 * abs(float(want))
+    # (ATen's GPU cumsum / sum associate differently from its CPU ones: 30000-point rows of near-identical CDFs agree to ~2e-5)
+    assert got.is_cuda and abs(float(got) - float(want)) <= 1e-4 * abs(float(want))
 
 
 def test_masked_dense_equals_ragged_removal():
