@@ -543,3 +543,31 @@ def test_cpp_training_slice_equals_the_python_node():
         torch.testing.assert_close(g_half, 0.5 * e2.grad, rtol=1e-6, atol=1e-12)
         with torch.no_grad():
             assert torch.equal(spectra.training_step_slice(mod, tgt, est, n_fft=n_fft, hop=hop), ref.detach())
+
+
+def test_eval_metric_wasserstein_distance_cpu():
+    """spectra.wasserstein_distance = metrics.py:144-149: compute_mag (hann, 75 % overlap) of both signals -> Wasserstein1D(p, fixed_x)."""
+    from sot_amd import spectra
+    from sot_amd.losses import Wasserstein1D
+    g = torch.Generator().manual_seed(1)
+    x, xh = torch.rand(3, 2000, generator=g) - 0.5, torch.rand(3, 2000, generator=g) - 0.5
+    for p in (1, 2):
+        got = spectra.wasserstein_distance(x, xh, p=p, n_fft=256)
+        mx = torch.stft(spectra.end_padded(x, 256, 64), 256, 64, 256, torch.hann_window(256), center=False, normalized=True, return_complex=True).abs().permute(0, 2, 1)
+        mh = torch.stft(spectra.end_padded(xh, 256, 64), 256, 64, 256, torch.hann_window(256), center=False, normalized=True, return_complex=True).abs().permute(0, 2, 1)
+        want = Wasserstein1D(p=p, fixed_x=129)(mx, mh)
+        assert got.ndim == 0 and abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+
+
+@pytest.mark.gpu
+def test_eval_metric_wasserstein_distance_gpu_matches_cpu():
+    from gpu_util import device, native
+    from sot_amd import spectra
+    native()
+    dev = device()
+    g = torch.Generator().manual_seed(2)
+    x, xh = torch.rand(8, 4096, generator=g) - 0.5, torch.rand(8, 4096, generator=g) - 0.5
+    for p, n_fft in ((1, 512), (2, 512), (1, 2048)):
+        got = spectra.wasserstein_distance(x.to(dev), xh.to(dev), p=p, n_fft=n_fft)
+        want = spectra.wasserstein_distance(x, xh, p=p, n_fft=n_fft)
+        assert got.is_cuda and abs(float(got) - float(want)) <= 1e-5 * abs(float(want)), (p, n_fft, float(got), float(want))
