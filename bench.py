@@ -414,7 +414,8 @@ def rccl_world1_probe():
             return {"rccl_world1": {"error": f"rc={r.returncode}: " + (r.stderr or "")[-300:]}}
         rec = json.loads(line[-1])
         return {"rccl_world1_ms_per_step": rec["ms_per_step"], "rccl_world1": {"collective": rec["config"]["collective"], "streams": rec["config"]["streams"],
-                "ms_per_step_without_collective": rec["extras"].get("ms_per_step_without_collective"), "loss_set0": rec["config"]["loss_set0"]}}
+                "ms_per_step_without_collective": rec["extras"].get("ms_per_step_without_collective"),
+                "host_enqueue_ms_per_step": rec["extras"].get("host_enqueue_ms_per_step"), "loss_set0": rec["config"]["loss_set0"]}}
     except Exception as exc:  # noqa: BLE001 -- a probe must not take the bench line with it
         return {"rccl_world1": {"error": repr(exc)[:300]}}
 
@@ -546,10 +547,10 @@ def main():
                 # the FFI call Wasserstein1D.forward makes (sot_w1d_loss: the row kernel, then the fixed-order mean kernel), into
                 # preallocated outputs
                 return nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, row_out=rowbuf[slot], mean_out=meanbuf[slot])[0]
-            rows = nat.forward_rows(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot])
-            # N > 1: local kernels -> ONE all-reduce(SUM) of the fp64 partial sum over RCCL -> global mean
+            # N > 1: local kernels (one FFI crossing: row kernel + fixed-order reduction, the fp64 partial sum into ring[slot]) -> ONE
+            # all-reduce(SUM) of that sum over RCCL -> global mean
             import torch.distributed as dist
-            nat.reduce_mean(rows, sum_out=ring[slot])
+            nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, row_out=rowbuf[slot], mean_out=meanbuf[slot], sum_out=ring[slot])
             dist.all_reduce(ring[slot], op=dist.ReduceOp.SUM)   # in place: the slot then holds the global sum
             return ring[slot]   # the mean is ring[slot] * inv_global_rows (applied where the value is read)
 
