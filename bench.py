@@ -532,25 +532,35 @@ def main():
     meanbuf = [torch.empty((), dtype=torch.float32, device=dev) for _ in range(4)]
     inv_global_rows = 1.0 / float(world * B)   # weak scaling: every rank owns exactly B rows
 
+    # The step's native call with its arguments marshalled once per (input set, output slot) pair (nat.prepared_loss_call): the timed
+    # loop then enters the C function directly -- the same call Wasserstein1D.forward makes (sot_w1d_loss: row kernel + fixed-order
+    # reduction), minus the per-call struct fill.  With N > 1 this keeps the host (issuing kernel, reduction and all-reduce for
+    # every step) ahead of the GPU: 36 us of host time per step before, against 33 us of kernel time.
+    prepared = {}
+
+    def native_step(i, slot):
+        key = (i % len(sets), slot)
+        call = prepared.get(key)
+        if call is None:
+            x2, y2, xp, yp, flags, plan, _ = marshalled[key[0]]
+            call = prepared[key] = nat.prepared_loss_call(x2, y2, xp, yp, float(mod.p), flags, plan, rowbuf[slot], meanbuf[slot],
+                                                          sum_out=ring[slot] if dist_on else None)
+        return call()
+
     def step(i, profile=None):
         with torch.no_grad():
-            x2, y2, xp, yp, flags, plan, _ = marshalled[i % len(sets)]
             slot = i % len(ring)
-            if n_lanes == 1:
-                cur = torch.cuda.current_stream()
-            else:
-                cur, other = lanes[i & 1], lanes[1 - (i & 1)]
-                torch.cuda.set_stream(cur)
+            if n_lanes != 1:
+                torch.cuda.set_stream(lanes[i & 1])
             if profile is not None:
                 nat.profile_next_launch(profile)   # start / stop events attached to the next row-kernel dispatch
             if not dist_on:
                 # the FFI call Wasserstein1D.forward makes (sot_w1d_loss: the row kernel, then the fixed-order mean kernel), into
                 # preallocated outputs
-                return nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, row_out=rowbuf[slot], mean_out=meanbuf[slot])[0]
+                return native_step(i, slot)
             # N > 1: local kernels (one FFI crossing: row kernel + fixed-order reduction, the fp64 partial sum into ring[slot]) -> ONE
             # all-reduce(SUM) of that sum over RCCL -> global mean
-            import torch.distributed as dist
-            nat.loss_fused(x2, y2, xp, yp, float(mod.p), flags, plan, row_out=rowbuf[slot], mean_out=meanbuf[slot], sum_out=ring[slot])
+            native_step(i, slot)
             dist.all_reduce(ring[slot], op=dist.ReduceOp.SUM)   # in place: the slot then holds the global sum
             return ring[slot]   # the mean is ring[slot] * inv_global_rows (applied where the value is read)
 
