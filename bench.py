@@ -630,10 +630,10 @@ def main():
         torch.cuda.synchronize()
     kern_ms = sum(nat.profile_elapsed_ms(sl) for sl in timed_slots) / len(timed_slots)
 
-    def attached_ms(call, count=24):
+    def attached_ms(call, count=32):
         """Average duration of the FIRST kernel `call(i)` launches (a compile-time-length row kernel), from HIP events attached to
         the dispatch: the figure rocprofv3's kernel trace reports for it."""
-        for i in range(4):
+        for i in range(60):   # the first launches of a kernel run slower (code load, clock ramp): the headline gets 400 untimed steps, these get 60
             call(i)
         slots = list(range(min(count, PROFILE_SLOTS)))
         for i in slots:
