@@ -670,6 +670,17 @@ def main():
                     ms = attached_ms(call)
                     side[key] = {"kernel": kern, "kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
                                  "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    # the same launches back to back between two stream events (per launch: the kernel + its launch gap, plus the
+                    # batch-mean kernel for the training form): a dispatch with attached events ends with a system-scope release,
+                    # which for the training form (64 MB of gradients) flushes what a following kernel would not wait for
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for i in range(100):
+                        call(i)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    side[key]["stream_ms_per_call"] = e0.elapsed_time(e1) / 100
                 except Exception as exc:  # noqa: BLE001
                     side[key] = {"error": repr(exc)[:200]}
         del cm
