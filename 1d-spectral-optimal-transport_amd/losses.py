@@ -349,6 +349,19 @@ class Wasserstein1D(torch.nn.Module):
         self._plans = _PlanCache()
         self._hot = None   # the last default call's (positions, their versions, module settings, plan, flag word, extension, n, m): see forward
 
+    def __getstate__(self):
+        # the caches hold device events and the extension module: a copy / pickle of the module (copy.deepcopy for an EMA model,
+        # torch.save(model)) starts with empty ones
+        state = self.__dict__.copy()
+        state["_plans"] = None
+        state["_hot"] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plans = _PlanCache()
+        self._hot = None
+
     def _positions(self, x_pos, y_pos):
         if (x_pos is None or y_pos is None) and self.fixed_x is None:
             raise ValueError("If fixed_x is not provided, x_pos and y_pos must be provided")

@@ -158,3 +158,20 @@ def test_cpp_host_path_is_built_in_tree_and_loads_without_a_gpu():
         t = torch.rand(2, 8)
         i = torch.zeros(8, dtype=torch.int32)
         g.mean_loss(t, t, t[0], t[0], i, i, i[:2], 1.0, 8)
+
+
+def test_module_can_be_copied_and_pickled():
+    """copy.deepcopy (EMA copies) and pickle (torch.save(model)) of a module that has been used: its caches (position plans with
+    device events, the hot-call entry with the extension module) are not part of the copy."""
+    import copy
+    import pickle
+    import torch
+    from sot_amd.losses import Wasserstein1D
+    m = Wasserstein1D(p=2, fixed_x=33, square_dist=True)
+    x, y = torch.rand(3, 33), torch.rand(3, 33)
+    want = m(x, y)
+    m._hot = ("not", "picklable", lambda: None)          # what a GPU call would have left behind
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone._hot is None and clone._plans is not None and clone._plans.entries == []
+        assert torch.equal(clone.fixed_x, m.fixed_x) and (clone.p, clone.square_dist) == (2, True)
+        assert torch.equal(clone(x, y), want)
