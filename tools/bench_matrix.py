@@ -14,7 +14,8 @@ MODES = {"p1": dict(p=1), "cutoff": dict(p=2, square_dist=True, dont_normalize=T
          "nocut": dict(p=2, square_dist=True), "p3": dict(p=3)}
 CASES = [(8192, 2048, "p1"), (8192, 2048, "cutoff"), (8192, 2048, "p3"), (8192, 512, "cutoff"), (8192, 512, "p1"),
          (1024, 1025, "cutoff"), (4096, 1025, "cutoff"), (16384, 1025, "cutoff"), (4096, 257, "cutoff"), (65536, 257, "cutoff"),
-         (2048, 4096, "p1"), (1024, 8192, "p1")]
+         (2048, 4096, "p1"), (1024, 8192, "p1"),
+         (8192, 2000, "p1"), (8192, 2000, "cutoff"), (8192, 2000, "p3"), (8192, 3000, "cutoff"), (16384, 1000, "cutoff")]   # run-time lengths
 if len(sys.argv) > 1:
     CASES = [tuple(int(v) if v.isdigit() else v for v in a.split(",")) for a in sys.argv[1:]]
 
