@@ -284,3 +284,31 @@ def test_hot_call_cache_is_invalidated_by_everything_it_depends_on():
     a = m3(x.reshape(2, 4, 300), y.reshape(2, 4, 300))
     assert torch.equal(m3(x.reshape(2, 4, 300), y.reshape(2, 4, 300)), a) and m3._hot is not None
     assert torch.equal(a, m3(x, y))
+
+
+def test_module_under_make_graphed_callables():
+    """torch.cuda.make_graphed_callables(module, ...) -- forward and backward each captured into a HIP graph by PyTorch -- gives the eager
+    module's loss and gradient bit for bit, also on inputs other than the ones it was captured with."""
+    import warnings
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    B, N = 256, 1025
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True, fixed_x=N).to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    sample_x = torch.rand(B, N, device=dev, generator=g)
+    sample_y = torch.rand(B, N, device=dev, generator=g).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        graphed = torch.cuda.make_graphed_callables(mod, (sample_x, sample_y))
+        for _ in range(2):
+            x = torch.rand(B, N, device=dev, generator=g)
+            y = torch.rand(B, N, device=dev, generator=g).requires_grad_(True)
+            want = mod(x, y)
+            want.backward()
+            y2 = y.detach().clone().requires_grad_(True)
+            got = graphed(x, y2)
+            got.backward()
+            torch.cuda.synchronize()
+            assert torch.equal(got.detach(), want.detach())
+            assert torch.equal(y2.grad, y.grad)
