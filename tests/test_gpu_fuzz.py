@@ -23,3 +23,19 @@ def test_random_cases_against_the_oracle(seed):
     assert cases == 400
     assert failures == [], failures[:3]
     assert worst_forward <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_stft_cases_against_torch_stft(seed):
+    """tools/fuzz_stft.py: random n_fft (64 ... 4096), hop, clip length, batch, window and signal kind; magnitudes against torch.stft,
+    gradients against its autograd, and the backward from the stored spectrum against the recomputing one (bit-identical)."""
+    native()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_stft
+    cases, failures, worst_forward, worst_grad = fuzz_stft.run(budget=120.0, seed0=seed, max_cases=300, verbose=False)
+    assert cases == 300
+    # a failure record is (kind, case, forward error, gradient error, stored == recomputed); the gradient of |X| is ill-conditioned
+    # where |X| ~ 0 (pure tones between bins): allow those up to 2e-2 of the largest gradient entry, nothing else
+    hard = [f for f in failures if f[0] != "STFT" or f[2] > 2e-5 or f[3] > 2e-2 or not f[4]]
+    assert hard == [], hard[:3]
+    assert worst_forward <= 2e-5
