@@ -628,3 +628,51 @@ class MixOfLosses(torch.nn.Module):
             loss_ = loss_fn(x, y, **kwargs) * weight
             loss[loss_fn.__class__.__name__] = loss_
         return loss
+
+
+# ---- the other operands a MixOfLosses configuration of the reference may name (losses.py:7-86).  Not on the OT path and not HIP: plain
+# ---- torch-op compositions with the reference's call signature, so that a configuration that mixes them with Wasserstein1D loads.
+
+def mean_difference(target, value, loss_type="L1", weights=None, dims=None):
+    """losses.py:7-36: mean over `dims` (all axes when None) of |d·w| ("L1") or d²·w ("L2"), d = target − value."""
+    kind = loss_type.upper()
+    if kind not in ("L1", "L2"):
+        raise ValueError('Loss type ({}), must be "L1", "L2" '.format(kind))
+    delta = target - value
+    w = 1.0 if weights is None else weights
+    term = (delta * w).abs() if kind == "L1" else delta ** 2 * w
+    return torch.mean(term, dim=list(range(term.ndim)) if dims is None else dims)
+
+
+class MeanDifference(torch.nn.Module):
+    """losses.py:39-54: mean_difference of the two inputs, optionally after sorting each along its last axis."""
+
+    def __init__(self, loss_type="L1"):
+        super().__init__()
+        self.loss_type = loss_type
+
+    def forward(self, x, y, weights=None, sort=False, **kwargs):
+        if sort:
+            x, y = torch.sort(x, dim=-1)[0], torch.sort(y, dim=-1)[0]
+        return mean_difference(x, y, loss_type=self.loss_type, weights=weights, dims=kwargs.get("dims", None))
+
+
+class KL(torch.nn.Module):
+    """losses.py:57-86: rows normalised to unit mass (safe_divide), KL(input ‖ target) = Σ a·(log(a + eps) − log(b + eps)) per row
+    (`reverse` swaps the roles), mean over `dims`."""
+
+    def __init__(self, eps=1e-10, **kwargs):
+        super().__init__()
+        self.eps = eps
+        self.reverse = kwargs.get("reverse", False)
+
+    def forward(self, input, target, **kwargs):
+        lead = input.shape[:-1]
+        rows = lambda t: t.reshape(-1, t.shape[-1]) if t.ndim == 3 else t   # noqa: E731
+        a, b = rows(input), rows(target)
+        if self.reverse:
+            a, b = b, a
+        a = safe_divide(a, a.sum(dim=-1, keepdim=True))
+        b = safe_divide(b, b.sum(dim=-1, keepdim=True))
+        per_row = (a * (torch.log(a + self.eps) - torch.log(b + self.eps))).sum(dim=-1)
+        return torch.mean(per_row.reshape(lead), dim=kwargs.get("dims", None))

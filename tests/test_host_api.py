@@ -175,3 +175,32 @@ def test_module_can_be_copied_and_pickled():
         assert clone._hot is None and clone._plans is not None and clone._plans.entries == []
         assert torch.equal(clone.fixed_x, m.fixed_x) and (clone.p, clone.square_dist) == (2, True)
         assert torch.equal(clone(x, y), want)
+
+
+def test_sibling_losses_of_a_mix_configuration():
+    """MeanDifference / KL (losses.py:7-86), the operands a MixOfLosses configuration may name next to Wasserstein1D: known answers."""
+    import numpy as np
+    import pytest
+    import torch
+    from sot_amd.losses import KL, MeanDifference, MixOfLosses, Wasserstein1D, mean_difference
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.rand(2, 3, 5, generator=g), torch.rand(2, 3, 5, generator=g)
+    w = torch.rand(5, generator=g)
+    xn, yn, wn = x.numpy().astype(np.float64), y.numpy().astype(np.float64), w.numpy().astype(np.float64)
+    np.testing.assert_allclose(mean_difference(x, y).item(), np.abs(xn - yn).mean(), rtol=1e-6)
+    np.testing.assert_allclose(mean_difference(x, y, "l2", weights=w).item(), ((xn - yn) ** 2 * wn).mean(), rtol=1e-6)
+    np.testing.assert_allclose(mean_difference(x, y, "L1", dims=[1, 2]).numpy(), np.abs(xn - yn).mean(axis=(1, 2)), rtol=1e-6)
+    with pytest.raises(ValueError):
+        mean_difference(x, y, "cosine")
+    srt = MeanDifference("L2")(x, y, sort=True)
+    np.testing.assert_allclose(srt.item(), ((np.sort(xn, -1) - np.sort(yn, -1)) ** 2).mean(), rtol=1e-6)
+    a, b = xn / xn.sum(-1, keepdims=True), yn / yn.sum(-1, keepdims=True)
+    kl = (a * (np.log(a + 1e-10) - np.log(b + 1e-10))).sum(-1)
+    np.testing.assert_allclose(KL()(x, y).item(), kl.mean(), rtol=1e-5)
+    np.testing.assert_allclose(KL(reverse=True)(y, x).item(), kl.mean(), rtol=1e-5)
+    np.testing.assert_allclose(KL()(x, y, dims=1).numpy(), kl.mean(axis=1), rtol=1e-5)
+    assert KL()(torch.zeros(2, 4), torch.rand(2, 4)).item() == 0.0            # safe_divide: a zero row stays zero
+    mix = MixOfLosses([Wasserstein1D(p=1, fixed_x=5), KL(), MeanDifference()], weights=[1.0, 0.5, 2.0])
+    out = mix(x, y)
+    assert set(out) == {"Wasserstein1D", "KL", "MeanDifference"}
+    np.testing.assert_allclose(out["KL"].item(), 0.5 * kl.mean(), rtol=1e-5)
