@@ -71,8 +71,9 @@ FULL_ROW_GEOMETRY = {512: (64, 8, 4, 0), 1024: (128, 8, 2, 0), 2048: (256, 8, 1,
                      129: (64, 3, 4, 129), 257: (64, 5, 4, 257), 513: (64, 9, 4, 513), 1025: (128, 9, 2, 1025), 2049: (256, 9, 1, 2049)}
 
 
-def forward_kernel_name(n, mode, backward=False, same_grid=True):
-    """Name of the dominant kernel as rocprofv3 lists it (template arguments G, CPT, ROWS, PM, LIM, SQ, NX[, WANT_X, SLIM])."""
+def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
+    """Name of the dominant kernel as rocprofv3 lists it (template arguments G, CPT, ROWS, PM, LIM, SQ, NX[, WANT_X, SLIM]); `batch`: rows
+    of the launch (large batches of 1025-bin / <= 1024-point rows run the merge forward with one wave per row)."""
     c = MODES[mode]
     pm, lim, sq = int(c.get("p", 1)), bool(c.get("limit_quantile_range", False)), bool(c.get("square_dist", False))
     geo = FULL_ROW_GEOMETRY.get(n)
@@ -85,8 +86,11 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True):
         pmt = pm if pm in (1, 2) else 0
         if pm == 1 and not lim and not backward and same_grid:
             return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, -1>"
-        if backward:
-            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1, false, false, 1>"
+        if backward:   # y-only (training) kernel; the 1024-point geometry in the layout without U gradient slots, capped at 128 VGPRs
+            tail = "false, true, 4" if cap == 1024 else "false, false, 1"
+            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1, {tail}>"
+        if cap == 1024 and batch >= 8192:
+            g, cpt, rows = 64, 16, 4
         return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1>"
     if pm not in (1, 2):
         pm = 0
@@ -102,6 +106,8 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True):
         if n in (1024, 2049):
             return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
         return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false, 1>"
+    if n == 1025 and batch >= 6144:
+        g, cpt, rows = 64, 17, 4
     return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
 
 
@@ -196,9 +202,9 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
 
         fb = 4 * 2 * nbins + 4
         with torch.no_grad():
-            out[f"{tag}_cutoff_forward"] = entry(timed(fwd, n), forward_kernel_name(nbins, "cutoff"), rows * fb, l3_resident=l3)
-            out[f"{tag}_cutoff_forward_with_mean"] = entry(timed(fwd_mean, n), forward_kernel_name(nbins, "cutoff") + " + batch mean", rows * fb, l3_resident=l3)
-            out[f"{tag}_cutoff_forward_with_in_kernel_mean"] = entry(timed(fwd_mean_one_kernel, n), forward_kernel_name(nbins, "cutoff") + " (mean by its last workgroup)",
+            out[f"{tag}_cutoff_forward"] = entry(timed(fwd, n), forward_kernel_name(nbins, "cutoff", batch=rows), rows * fb, l3_resident=l3)
+            out[f"{tag}_cutoff_forward_with_mean"] = entry(timed(fwd_mean, n), forward_kernel_name(nbins, "cutoff", batch=rows) + " + batch mean", rows * fb, l3_resident=l3)
+            out[f"{tag}_cutoff_forward_with_in_kernel_mean"] = entry(timed(fwd_mean_one_kernel, n), forward_kernel_name(nbins, "cutoff", batch=rows) + " (mean by its last workgroup)",
                                                                       rows * fb, l3_resident=l3)
             out[f"{tag}_cutoff_backward_y"] = entry(timed(bwd_y, n), forward_kernel_name(nbins, "cutoff", backward=True), rows * (fb + 4 * nbins), l3_resident=l3)
             out[f"{tag}_cutoff_loss_and_grad"] = entry(timed(loss_and_grad, n), forward_kernel_name(nbins, "cutoff", backward=True) + " + batch mean",

@@ -1328,3 +1328,28 @@ def test_runtime_length_unsorted_positions_strides_and_module():
     want = so.mean(so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=2.0, flags=15))
     assert abs(float(loss.detach()) - float(want)) <= 1e-5 * abs(float(want))
     assert torch.isfinite(y3.grad).all() and float(y3.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("N,B", [(1025, 6144), (1025, 9001), (1000, 8192), (777, 8200)])
+@pytest.mark.parametrize("flags,p", [(1 | 2 | 4 | 8, 2.0), (8, 2.0), (0, 3.0)])
+def test_large_batches_one_wave_per_row_forward(N, B, flags, p):
+    """Batches of >= 6144 1025-bin rows (>= 8192 rows of any other length up to 1024) run the merge forward with ONE wave per row
+    (17 / 16 elements per thread).  Its row losses agree with the oracle like every other kernel's, and with the two-wave kernel's (the
+    same rows as a small batch) to rounding -- its thread-local sums group the row differently, so not bit for bit."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    dev = device()
+    x, y = gen_inputs("peaky", B, N, N, 31 + N)
+    x, y = x.to(dev), y.to(dev)
+    pos = torch.linspace(0, 1, N).to(dev)
+    pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
+    big = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)
+    k = 64
+    want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
+    np.testing.assert_allclose(big[:k].cpu().numpy(), want, rtol=RTOL)
+    small = torch.cat([nat.forward_rows(x[i:i + 2000], y[i:i + 2000], pos, pos2, p, flags | nat.FLAG_NO_AREA, plan) for i in range(0, B, 2000)])
+    torch.testing.assert_close(big, small, rtol=2e-6, atol=1e-12)
+    last = nat.forward_rows(x[B - 3:], y[B - 3:], pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)     # the end of the batch (partial workgroup)
+    torch.testing.assert_close(big[B - 3:], last, rtol=2e-6, atol=1e-12)

@@ -1,4 +1,4 @@
-"""Correctness spot check of diagnostic library variants (tools/ablate_libs/*.so) against the C oracle: B=48, N=2048."""
+"""Correctness spot check of diagnostic library variants (tools/ablate_libs/*.so) against the C oracle: B=48, N=2048 (AB_N=... for another length)."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for name in sys.argv[1:]:
@@ -14,8 +14,9 @@ from oracle import sot_oracle as so
 dev = torch.device('cuda:0')
 worst = 0.0
 for kind in ('peaky', 'uniform', 'dyadic'):
-    x, y = gen_inputs(kind, 48, 2048, 2048, 7)
-    pos = torch.linspace(0, 1, 2048)
+    N = {int(os.environ.get('AB_N', '2048'))}
+    x, y = gen_inputs(kind, 48, N, N, 7)
+    pos = torch.linspace(0, 1, N)
     for flags, p in ((0, 1.0), (15, 2.0), (1, 1.0)):
         got = nat.forward_rows(x.to(dev), y.to(dev), pos.to(dev), pos.to(dev).clone(), p, flags).cpu().numpy()
         want = so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=p, flags=flags)
