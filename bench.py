@@ -85,6 +85,8 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
         g, cpt, rows = {256: (64, 4, 4), 512: (64, 8, 4), 1024: (128, 8, 2), 2048: (256, 8, 1), 4096: (512, 8, 1), 8192: (1024, 8, 1)}[cap]
         pmt = pm if pm in (1, 2) else 0
         if pm == 1 and not lim and not backward and same_grid:
+            if cap == 1024:
+                g, cpt, rows = 64, 16, 4      # one wave per row
             return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, -1>"
         if backward:   # y-only (training) kernel; the 1024-point geometry in the layout without U gradient slots, capped at 128 VGPRs
             tail = "false, true, 4" if cap == 1024 else "false, false, 1"
@@ -96,6 +98,8 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
         pm = 0
     g, cpt, rows, nx = geo
     if pm == 1 and not lim and not backward and same_grid:   # p = 1 on one grid: the merge-free kernel (sot_area_full_kernel)
+        if n == 1025:
+            g, cpt, rows = 64, 17, 4          # one wave per row
         return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, {nx}>"
     if backward:   # the y-only (training) kernels <..., WANT_X, SLIM, MINB>: 2048-bin rows run two per workgroup in the layout without
         # U gradient slots, 1025- and 513-bin rows in that layout compiled for four workgroups per CU
