@@ -79,10 +79,11 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
     geo = FULL_ROW_GEOMETRY.get(n)
     b = lambda v: "true" if v else "false"  # noqa: E731
     if geo is None:   # any other length: the next capacity's geometry with the length at run time (NX = -1), backward up to 4096
-        cap = next((c for c in (256, 512, 1024, 2048, 4096, 8192) if n <= c), None) if n > 128 else None
+        cap = next((c for c in (256, 512, 1024, 1536, 2048, 3072, 4096, 8192) if n <= c), None) if n > 128 else None
         if cap is None or (backward and cap > 4096):
             return "sot_backward_kernel (generic)" if backward else "sot_forward_kernel (generic)"
-        g, cpt, rows = {256: (64, 4, 4), 512: (64, 8, 4), 1024: (128, 8, 2), 2048: (256, 8, 1), 4096: (512, 8, 1), 8192: (1024, 8, 1)}[cap]
+        g, cpt, rows = {256: (64, 4, 4), 512: (64, 8, 4), 1024: (128, 8, 2), 1536: (192, 8, 1), 2048: (256, 8, 1), 3072: (384, 8, 1), 4096: (512, 8, 1),
+                        8192: (1024, 8, 1)}[cap]
         pmt = pm if pm in (1, 2) else 0
         if pm == 1 and not lim and not backward and same_grid:
             if cap == 1024:

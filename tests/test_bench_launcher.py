@@ -55,7 +55,9 @@ def test_kernel_name_follows_shape_and_mode():
     assert b.forward_kernel_name(1025, "cutoff") == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
     assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<128, 9, 2, 2, true, true, 1025, false, true, 4>"
     assert b.forward_kernel_name(2048, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 2, 2, true, true, 0, false, true, 1>"
-    assert b.forward_kernel_name(3000, "p1") == "sot_area_full_kernel<512, 8, 1, false, -1>"            # run-time length on the 4096 geometry
+    assert b.forward_kernel_name(3000, "p1") == "sot_area_full_kernel<384, 8, 1, false, -1>"            # run-time length on the 3072-point geometry
+    assert b.forward_kernel_name(4000, "p1") == "sot_area_full_kernel<512, 8, 1, false, -1>"
+    assert b.forward_kernel_name(1200, "cutoff") == "sot_forward_full_kernel<192, 8, 1, 2, true, true, -1>"
     assert b.forward_kernel_name(2000, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 1, 2, true, true, -1, false, false, 1>"
     assert b.forward_kernel_name(1000, "cutoff", backward=True) == "sot_backward_full_kernel<128, 8, 2, 2, true, true, -1, false, true, 4>"
     assert b.forward_kernel_name(1025, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 17, 4, 2, true, true, 1025>"     # large batches: one wave per row
