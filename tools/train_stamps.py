@@ -4,7 +4,7 @@ Usage: python tools/train_stamps.py [B] [N]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "tools", "ablate_libs", "stamps.so")
+lib = os.path.join(ROOT, "tools", "ablate_libs", os.environ.get("STAMPS_LIB", "stamps") + ".so")
 os.environ["SOT_LIB_PATH"] = lib
 import torch
 from sot_amd import _native as nat
