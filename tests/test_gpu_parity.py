@@ -1355,3 +1355,41 @@ def test_large_batches_one_wave_per_row_forward(N, B, flags, p):
     torch.testing.assert_close(big, small, rtol=2e-6, atol=1e-12)
     last = nat.forward_rows(x[B - 3:], y[B - 3:], pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)     # the end of the batch (partial workgroup)
     torch.testing.assert_close(big[B - 3:], last, rtol=2e-6, atol=1e-12)
+
+
+def test_one_wave_rows_with_unsorted_positions_strides_and_the_in_kernel_mean():
+    """The large-batch one-wave forward kernels (1025 bins, run-time lengths up to 1024) on a permuted grid, on rows that are views into
+    wider buffers, through the module, and with the batch mean taken by the kernel's last workgroup."""
+    from sot_amd.losses import Wasserstein1D
+    nat = native()
+    dev = device()
+    for N, B in ((1025, 6200), (900, 8300)):
+        g = torch.Generator().manual_seed(N)
+        perm = torch.randperm(N, generator=g)
+        pos_sorted = torch.linspace(0, 1, N)
+        pos = pos_sorted[perm].contiguous()                     # unsorted shared grid: the plan carries the permutation
+        wide_x, wide_y = torch.rand(B, N + 7, generator=g) ** 4, torch.rand(B, N + 7, generator=g) ** 4
+        xs, ys = wide_x.to(dev)[:, 3:3 + N], wide_y.to(dev)[:, 5:5 + N]          # strided, 4-B aligned only
+        mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+        pd_, pd2 = pos.to(dev), pos.to(dev).clone()
+        rows_big = mod.row_losses(xs, ys, x_pos=pd_, y_pos=pd2)
+        rows_small = torch.cat([mod.row_losses(xs[i:i + 1500], ys[i:i + 1500], x_pos=pd_, y_pos=pd2) for i in range(0, B, 1500)])
+        torch.testing.assert_close(rows_big, rows_small, rtol=2e-6, atol=1e-12)
+        # against the oracle on the same permuted grid (it sorts like the reference)
+        from oracle import sot_oracle as so
+        k = 48
+        want = so.forward(xs[:k].cpu().numpy(), ys[:k].cpu().numpy(), pos.numpy(), pos.numpy(), p=2.0, flags=1 | 2 | 4 | 8)
+        np.testing.assert_allclose(rows_big[:k].cpu().numpy(), want, rtol=RTOL)
+        # the same rows on the sorted grid, columns permuted accordingly: the same problem up to the summation order of the row mass
+        # (no cutoff here: in the paper's mode a last-bit change of the mass moves rows across the cutoff's knife edge)
+        plain = Wasserstein1D(p=2, square_dist=True).to(dev)
+        inv = torch.argsort(perm)
+        xs2, ys2 = xs[:, inv.to(dev)].contiguous(), ys[:, inv.to(dev)].contiguous()
+        ps = pos_sorted.to(dev)
+        torch.testing.assert_close(plain.row_losses(xs, ys, x_pos=pd_, y_pos=pd2), plain.row_losses(xs2, ys2, x_pos=ps, y_pos=ps.clone()),
+                                   rtol=5e-5, atol=1e-12)   # (row masses of rand^8 weights summed in another order)
+        plan = nat.PositionPlan(pd_, pd2)
+        flags = 1 | 2 | 4 | 8
+        two = nat.loss_fused(xs, ys, pd_, pd2, 2.0, flags, plan)
+        one = nat.loss_fused(xs, ys, pd_, pd2, 2.0, flags, plan, fused_mean=True)
+        assert torch.equal(two[0] if isinstance(two, tuple) else two, one[0] if isinstance(one, tuple) else one)
