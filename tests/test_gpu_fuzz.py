@@ -39,3 +39,18 @@ def test_random_stft_cases_against_torch_stft(seed):
     hard = [f for f in failures if f[0] != "STFT" or f[2] > 2e-5 or f[3] > 2e-2 or not f[4]]
     assert hard == [], hard[:3]
     assert worst_forward <= 2e-5
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_random_module_calls_against_the_cpu_route(seed):
+    """tools/fuzz_module.py: the drop-in module on GPU tensors (C++ host path, hot-call cache, Python binding, row losses, `dims`, hinge, 3-D
+    inputs, fixed_x / explicit / unsorted / per-row positions, every mode, x / y / both gradients, three calls per module) against the same
+    module on CPU tensors (the torch-op route, bit-identical to the reference)."""
+    native()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_module
+    # losses to 3e-5; gradients to 2 % of the row's largest entry: float32 CDF levels of the two measures tie exactly now and then (N^2 / 2^24
+    # per row), and at a tie the gradient is a convention (DESIGN.md section 2) -- a wrong scale, sign or routing would be an O(1) error
+    cases, failures, worst_loss, worst_grad = fuzz_module.run(budget=120.0, seed0=seed, max_cases=150, verbose=False, grad_tol=2e-2)
+    assert cases == 150
+    assert failures == [], failures[:3]
