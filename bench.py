@@ -101,6 +101,8 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
     if pm == 1 and not lim and not backward and same_grid:   # p = 1 on one grid: the merge-free kernel (sot_area_full_kernel)
         if n == 1025:
             g, cpt, rows = 64, 17, 4          # one wave per row
+        if n == 129:
+            return f"sot_area_half_kernel<5, 8, {b(sq)}, 129>"    # two rows per wave
         return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, {nx}>"
     if backward:   # the y-only (training) kernels <..., WANT_X, SLIM, MINB>: 2048-bin rows run two per workgroup in the layout without
         # U gradient slots, 1025- and 513-bin rows in that layout compiled for four workgroups per CU

@@ -63,6 +63,7 @@ def test_kernel_name_follows_shape_and_mode():
     assert b.forward_kernel_name(1025, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 17, 4, 2, true, true, 1025>"     # large batches: one wave per row
     assert b.forward_kernel_name(1025, "cutoff", batch=4096) == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
     assert b.forward_kernel_name(1025, "p1") == "sot_area_full_kernel<64, 17, 4, false, 1025>"
+    assert b.forward_kernel_name(129, "p1") == "sot_area_half_kernel<5, 8, false, 129>"
     assert b.forward_kernel_name(1000, "p1") == "sot_area_full_kernel<64, 16, 4, false, -1>"
     assert b.forward_kernel_name(1000, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 16, 4, 2, true, true, -1>"
     assert "generic" in b.forward_kernel_name(100, "p1") and "generic" in b.forward_kernel_name(9000, "p1")
