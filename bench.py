@@ -113,6 +113,8 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
         if n in (1024, 2049):
             return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
         return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false, 1>"
+    if (n == 257 and batch >= 40960) or (n == 129 and batch >= 8192):   # two rows per wave
+        return f"sot_forward_half_kernel<{9 if n == 257 else 5}, 8, {pm}, {b(lim)}, {b(sq)}, {n}>"
     if n == 1025 and batch >= 6144:
         g, cpt, rows = 64, 17, 4
     return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"

@@ -64,6 +64,8 @@ def test_kernel_name_follows_shape_and_mode():
     assert b.forward_kernel_name(1025, "cutoff", batch=4096) == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
     assert b.forward_kernel_name(1025, "p1") == "sot_area_full_kernel<64, 17, 4, false, 1025>"
     assert b.forward_kernel_name(129, "p1") == "sot_area_half_kernel<5, 8, false, 129>"
+    assert b.forward_kernel_name(257, "cutoff", batch=65536) == "sot_forward_half_kernel<9, 8, 2, true, true, 257>"      # two rows per wave
+    assert b.forward_kernel_name(257, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 5, 4, 2, true, true, 257>"
     assert b.forward_kernel_name(1000, "p1") == "sot_area_full_kernel<64, 16, 4, false, -1>"
     assert b.forward_kernel_name(1000, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 16, 4, 2, true, true, -1>"
     assert "generic" in b.forward_kernel_name(100, "p1") and "generic" in b.forward_kernel_name(9000, "p1")

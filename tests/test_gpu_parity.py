@@ -1332,11 +1332,11 @@ def test_runtime_length_unsorted_positions_strides_and_module():
     assert torch.isfinite(y3.grad).all() and float(y3.grad.abs().max()) > 0
 
 
-@pytest.mark.parametrize("N,B", [(1025, 6144), (1025, 9001), (1000, 8192), (777, 8200)])
+@pytest.mark.parametrize("N,B", [(1025, 6144), (1025, 9001), (1000, 8192), (777, 8200), (257, 40961), (129, 8195)])
 @pytest.mark.parametrize("flags,p", [(1 | 2 | 4 | 8, 2.0), (8, 2.0), (0, 3.0)])
 def test_large_batches_one_wave_per_row_forward(N, B, flags, p):
     """Batches of >= 6144 1025-bin rows (>= 8192 rows of any other length up to 1024) run the merge forward with ONE wave per row
-    (17 / 16 elements per thread).  Its row losses agree with the oracle like every other kernel's, and with the two-wave kernel's (the
+    (17 / 16 elements per thread); large batches of 257- / 129-bin rows with TWO rows per wave (32 lanes x 9 / 5 elements).  Its row losses agree with the oracle like every other kernel's, and with the two-wave kernel's (the
     same rows as a small batch) to rounding -- its thread-local sums group the row differently, so not bit for bit."""
     from oracle.inputs import gen_inputs
     from oracle import sot_oracle as so
