@@ -67,7 +67,7 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True, grad_tol=2e-3):
                 got = gpu_mod(xg, yg, **pos_gpu, **kwargs)
                 if got.shape != want.shape:
                     failures.append(("SHAPE", desc)); verbose and print("SHAPE", desc, tuple(got.shape), tuple(want.shape)); ok = False; break
-                scale = float(want.detach().abs().max()) + 1e-12
+                scale = float(want.detach().abs().max()) + float(kwargs.get("hinge", 0.0)) + 1e-12   # (relu(row - hinge) cancels: errors scale with the row loss)
                 el = float((got.detach().cpu() - want.detach()).abs().max()) / scale
                 worst_l = max(worst_l, el)
                 if not el <= 3e-5:
