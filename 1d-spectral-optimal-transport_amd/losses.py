@@ -60,16 +60,18 @@ def _hip_domain(*tensors) -> bool:
     return False
 
 
+ROW_SIDE_LIMIT = 16384    # points of ONE side (csrc/sot_hip.hip pick_cfg: at most 1024 threads x 16 points per row)
 ROW_POINT_LIMIT = 18000   # n + m of the longest row pair the kernels take for sure (one pair's working set lives in ONE CU's 160 KiB
                           # of LDS; include/sot_hip.h: SOT_ERR_UNSUPPORTED_SIZE beyond ~19000 forward / ~13000 backward)
 
 
-def _beyond_one_cu(x, y) -> bool:
+def _beyond_one_cu(x, y, *positions) -> bool:
     """Rows too long for the LDS-resident kernels (n_fft >= 32768): the reference has no size limit (losses.py:223-313), so such GPU
     tensors run the package's torch-op composition -- said once -- instead of failing.  No paper configuration comes near."""
     n, m = x.shape[-1], y.shape[-1]
-    limit = ROW_POINT_LIMIT if not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)) else 12000
-    if n + m <= limit:
+    wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, y) + tuple(positions))
+    limit = ROW_POINT_LIMIT if not wants_grad else 12000
+    if n + m <= limit and max(n, m) <= ROW_SIDE_LIMIT:   # the kernels also cap each side (pick_cfg: 1024 threads x 16 points)
         return False
     warn_once("row-too-long", f"sot_amd: rows of {n} + {m} points exceed what one CU's LDS holds; this call runs the torch-op composition "
                               "on the GPU instead of the HIP kernels")
@@ -261,7 +263,7 @@ def wasserstein_1d(u_values, v_values, u_weights=None, v_weights=None, p=1, requ
         u_weights = torch.full(u_values.shape, 1.0 / n, device=u_values.device, dtype=u_values.dtype)
     if v_weights is None:
         v_weights = torch.full(v_values.shape, 1.0 / m, device=v_values.device, dtype=v_values.dtype)
-    if not _hip_domain(u_values, v_values, u_weights, v_weights) or _beyond_one_cu(u_weights, v_weights):
+    if not _hip_domain(u_values, v_values, u_weights, v_weights) or _beyond_one_cu(u_weights, v_weights, u_values, v_values):
         return tp.transport_rows(u_values, v_values, u_weights, v_weights, p=p, require_sort=require_sort,
                                  return_quantiles=return_quantiles, limit_quantile_range=limit_quantile_range)
 
@@ -403,7 +405,7 @@ class Wasserstein1D(torch.nn.Module):
         """Flat [rows] tensor of W_p^p per spectrum pair (after the optional hinge, before the mean):
         what losses.py:186-205 holds before its reshape/mean.  Used by the row-sharded multi-GPU path."""
         x_pos_, y_pos_ = self._positions(x_pos, y_pos)
-        if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y):
+        if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y, x_pos_, y_pos_):
             return self._torch_forward(x, y, x_pos_, y_pos_, kwargs, rows_only=True)
         x, y, x_pos_, y_pos_, flags, plan, _ = self._marshal(x, y, x_pos, y_pos, kwargs)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (x, y, x_pos_, y_pos_)):
@@ -432,12 +434,12 @@ class Wasserstein1D(torch.nn.Module):
                 x2 = x if x.ndim == 2 else x.reshape(-1, x.shape[-1])
                 y2 = y if y.ndim == 2 else y.reshape(-1, y.shape[-1])
                 if (x2.stride(1) == 1 and y2.stride(1) == 1 and x2.shape[1] == hot[8] and y2.shape[1] == hot[9]
-                        and not (x2.requires_grad and torch.is_grad_enabled())):
+                        and not (torch.is_grad_enabled() and (x2.requires_grad or xp.requires_grad or yp.requires_grad))):
                     plan = hot[5]
                     plan.use_on_current_stream(x2.device)
                     return hot[7].mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), hot[6])
         x_pos_, y_pos_ = self._positions(x_pos, y_pos)
-        if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y):
+        if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y, x_pos_, y_pos_):
             return self._torch_forward(x, y, x_pos_, y_pos_, kwargs)
         return self._hip_forward(x, y, x_pos, y_pos, x_pos_, y_pos_, kwargs)
 
@@ -458,7 +460,10 @@ class Wasserstein1D(torch.nn.Module):
                 # the hot call (trainer.py:220-228: gradient for the estimate's spectrum only; metrics.py:148: none): C++ host path
                 plan.use_on_current_stream(x2.device)
                 fl = nat.problem_flags(self.p, flags, plan)
-                if not kwargs and x_pos_.ndim == 1 and y_pos_.ndim == 1 and x2.shape[1] + y2.shape[1] <= 12000:   # remember the hot call (see forward)
+                # remember the hot call (see forward) -- not from inside a stream capture, where plan.same_grid() answers "no" without
+                # remembering it and the flag word frozen here would lack SOT_FLAG_SAME_GRID for good
+                if (not kwargs and x_pos_.ndim == 1 and y_pos_.ndim == 1 and x2.shape[1] + y2.shape[1] <= 12000
+                        and not torch.cuda.is_current_stream_capturing()):
                     self._hot = (x_pos_, y_pos_, _version_of(x_pos_), _version_of(y_pos_), self._settings(), plan, fl, glue, x2.shape[1], y2.shape[1])
                 return glue.mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), fl)
             if grad_on and any(t.requires_grad for t in (x2, y2, x_pos_, y_pos_)):

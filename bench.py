@@ -215,8 +215,8 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
             out[f"{tag}_cutoff_forward_with_mean"] = entry(timed(fwd_mean, n), forward_kernel_name(nbins, "cutoff", batch=rows) + " + batch mean", rows * fb, l3_resident=l3)
             out[f"{tag}_cutoff_forward_with_in_kernel_mean"] = entry(timed(fwd_mean_one_kernel, n), forward_kernel_name(nbins, "cutoff", batch=rows) + " (mean by its last workgroup)",
                                                                       rows * fb, l3_resident=l3)
-            out[f"{tag}_cutoff_backward_y"] = entry(timed(bwd_y, n), forward_kernel_name(nbins, "cutoff", backward=True), rows * (fb + 4 * nbins), l3_resident=l3)
-            out[f"{tag}_cutoff_loss_and_grad"] = entry(timed(loss_and_grad, n), forward_kernel_name(nbins, "cutoff", backward=True) + " + batch mean",
+            out[f"{tag}_cutoff_backward_y"] = entry(timed(bwd_y, n), forward_kernel_name(nbins, "cutoff", backward=True, batch=rows), rows * (fb + 4 * nbins), l3_resident=l3)
+            out[f"{tag}_cutoff_loss_and_grad"] = entry(timed(loss_and_grad, n), forward_kernel_name(nbins, "cutoff", backward=True, batch=rows) + " + batch mean",
                                                        rows * (fb + 4 * nbins), l3_resident=l3)
         return cut
 
@@ -230,7 +230,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         nat.forward_rows(x2, y2, xp, yp, 1.0, flags | nat.FLAG_NO_AREA, plan)
 
     with torch.no_grad():
-        out[f"b{B}n{N}_p1_forward_merge_kernel"] = entry(timed(p1_merge, n), forward_kernel_name(N, "p1", same_grid=False), B * (8 * N + 4),
+        out[f"b{B}n{N}_p1_forward_merge_kernel"] = entry(timed(p1_merge, n), forward_kernel_name(N, "p1", same_grid=False, batch=B), B * (8 * N + 4),
                                                          l3_resident=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
 
     # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
@@ -305,7 +305,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     out["b1024n1025_cutoff_module_forward_backward_fresh_positions"] = e2
     with torch.no_grad():
         out["b1024n1025_cutoff_module_forward"] = entry(timed(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), n),
-                                                         forward_kernel_name(1025, "cutoff") + " + batch mean", 1024 * (8 * 1025 + 4), l3_resident=True)
+                                                         forward_kernel_name(1025, "cutoff", batch=1024) + " + batch mean", 1024 * (8 * 1025 + 4), l3_resident=True)
         out["b1024n1025_cutoff_module_forward"]["host_us_per_call"] = wall_us(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), 400)
     del xs1, ys1
 
@@ -329,7 +329,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     csr_bytes = 8 * (xw.numel() + yw.numel()) + 16 * (8192 + 1) + 4 * 8192
     with torch.no_grad():
         out["config4_b8192n512_masked_dense_forward"] = entry(
-            timed(lambda i: nat.forward_rows(xm, ym, p512, p512b, 2.0, flags, plan512), n), forward_kernel_name(512, "cutoff"), dense_bytes,
+            timed(lambda i: nat.forward_rows(xm, ym, p512, p512b, 2.0, flags, plan512), n), forward_kernel_name(512, "cutoff", batch=8192), dense_bytes,
             l3_resident=True, mean_kept_support=rs["kept"])
         out["config4_b8192n512_csr_forward"] = entry(
             timed(lambda i: wasserstein_1d_csr(xw, xp_, xo, yw, yp_, yo, rs["max_n"], rs["max_m"], **kw), n), "sot_forward_kernel<CSR>",
@@ -678,9 +678,9 @@ def main():
 
         with torch.no_grad():
             for key, call, kern, nbytes in (
-                    ("paper_mode", paper_forward, forward_kernel_name(N, "cutoff"), B * (8 * N + 4)),
-                    ("merge_p1", merge_p1_forward, forward_kernel_name(N, "p1", same_grid=False), B * (8 * N + 4)),
-                    ("training_form", training_form, forward_kernel_name(N, "cutoff", backward=True), B * (12 * N + 4))):
+                    ("paper_mode", paper_forward, forward_kernel_name(N, "cutoff", batch=B), B * (8 * N + 4)),
+                    ("merge_p1", merge_p1_forward, forward_kernel_name(N, "p1", same_grid=False, batch=B), B * (8 * N + 4)),
+                    ("training_form", training_form, forward_kernel_name(N, "cutoff", backward=True, batch=B), B * (12 * N + 4))):
                 try:
                     ms = attached_ms(call)
                     side[key] = {"kernel": kern, "kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes,
@@ -769,7 +769,7 @@ def main():
             import glob
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
                 pj = json.load(open(path))
-                if pj.get("workload") == f"B={B},N={N},{args.mode}" and pj.get("kernel") == forward_kernel_name(N, args.mode):
+                if pj.get("workload") == f"B={B},N={N},{args.mode}" and pj.get("kernel") == forward_kernel_name(N, args.mode, batch=B):
                     traffic = pj["hbm_bytes_per_launch"]
                     traffic_source = (f"{os.path.relpath(path, ROOT)}: rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of this "
                                       "command in an earlier run, committed; NOT measured in this run")
@@ -800,7 +800,7 @@ def main():
                        "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": forward_kernel_name(N, args.mode), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B,
+                         "kernel": forward_kernel_name(N, args.mode, batch=B), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B,
                          **side},
             "extras": extras,
         }

@@ -312,3 +312,47 @@ def test_module_under_make_graphed_callables():
             torch.cuda.synchronize()
             assert torch.equal(got.detach(), want.detach())
             assert torch.equal(y2.grad, y.grad)
+
+
+def test_hot_call_cache_does_not_swallow_position_gradients():
+    """an entry made under no_grad (a validation step) must not serve a later training call whose POSITIONS require a
+    gradient -- requires_grad_() does not bump the version counter, so identity + version alone would still match."""
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(3)
+    x, y = torch.rand(6, 200, device=dev, generator=g), torch.rand(6, 200, device=dev, generator=g)
+    pos = torch.sort(torch.rand(200, device=dev, generator=g)).values
+    pos2 = pos.clone()
+    mod = Wasserstein1D(p=2).to(dev)
+    with torch.no_grad():
+        first = mod(x, y, x_pos=pos, y_pos=pos2)
+    assert mod._hot is not None
+    pos.requires_grad_(True)
+    pos2.requires_grad_(True)
+    out = mod(x, y, x_pos=pos, y_pos=pos2)
+    assert torch.equal(out.detach(), first)
+    out.backward()
+    assert pos.grad is not None and pos2.grad is not None and float(pos.grad.abs().sum()) > 0
+    ref = Wasserstein1D(p=2)   # the same module on CPU tensors (torch-op route): autograd through sort / take_along_dim
+    pc, pc2 = pos.detach().cpu().requires_grad_(True), pos2.detach().cpu().requires_grad_(True)
+    ref(x.cpu(), y.cpu(), x_pos=pc, y_pos=pc2).backward()
+    torch.testing.assert_close(pos.grad.cpu(), pc.grad, rtol=2e-4, atol=1e-7)
+    torch.testing.assert_close(pos2.grad.cpu(), pc2.grad, rtol=2e-4, atol=1e-7)
+
+
+def test_one_long_side_takes_the_torch_route_instead_of_raising():
+    """n + m within the LDS limit but ONE side beyond the kernels' 16384-point cap: the promised torch-op route, not
+    SOT_ERR_UNSUPPORTED_SIZE."""
+    import warnings
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(4)
+    x, y = torch.rand(2, 17000, device=dev, generator=g), torch.rand(2, 500, device=dev, generator=g)
+    px, py = torch.linspace(0, 1, 17000, device=dev), torch.linspace(0, 1, 500, device=dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = Wasserstein1D(p=1)(x, y, x_pos=px, y_pos=py)
+    want = Wasserstein1D(p=1)(x.cpu(), y.cpu(), x_pos=px.cpu(), y_pos=py.cpu())
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=0)
