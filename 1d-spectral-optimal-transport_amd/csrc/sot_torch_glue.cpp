@@ -219,6 +219,23 @@ std::vector<at::Tensor> make_plan(const at::Tensor& xpos, const at::Tensor& ypos
     return {xs, ys, xperm, yperm, ident};
 }
 
+// The module's default call with FRESH position tensors (round 4).  The reference's trainer rebuilds its grid on every step
+// (trainer.py:187-197: x_pos = torch.tensor(freqs).to(device) / max, y_pos = x_pos.clone()), so identity-keyed plan and hot-call caches
+// never hit there.  The grid's CONTENT cannot be compared on the host without a synchronisation, and a cached plan's buffers must not be
+// rewritten in place (an autograd node of an earlier step may still hold them for a retained graph), so each such call gets its own
+// plan -- but as part of THIS one host call: one allocation, sot_prepare_positions (two workgroups: a sortedness check, and a sort
+// only when it fails), then the loss.  The flag word must not carry SOT_FLAG_SAME_GRID unless both arguments are the same tensor:
+// whether two fresh tensors hold one grid is device-side knowledge.
+at::Tensor mean_loss_fresh(const at::Tensor& x, const at::Tensor& y, const at::Tensor& xpos, const at::Tensor& ypos, double p, int64_t flags)
+{
+    TORCH_CHECK(!(at::GradMode::is_enabled() && (xpos.requires_grad() || ypos.requires_grad())),
+                "sot glue: gradients w.r.t. the positions are not this path's case");
+    TORCH_CHECK(xpos.device() == x.device() && ypos.device() == x.device(), "sot glue: all tensors must live on one GPU");
+    if (!(xpos.is_same(ypos) || (xpos.data_ptr() == ypos.data_ptr() && xpos.numel() == ypos.numel()))) flags &= ~(int64_t)SOT_FLAG_SAME_GRID;
+    const std::vector<at::Tensor> plan = make_plan(xpos, ypos);
+    return mean_loss(x, y, plan[0], plan[1], plan[2], plan[3], plan[4], p, flags);
+}
+
 // ---- the training-step slice trainer.py:192-228 runs around the loss, audio in (spectra.training_step_slice / _AudioToLoss): magnitude
 // STFT of target and estimate in one launch (keeping the estimate's complex spectrum), SOT loss + d mean / d spectrum in one pass,
 // and on the way back the STFT backward from the stored spectrum with the upstream scalar applied inside it.  Differentiates w.r.t.
@@ -304,6 +321,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.doc() = "host path of sot_amd.losses.Wasserstein1D in C++ (one call per forward, C++ autograd node); kernels: libsot_hip.so";
     m.def("bind", &bind_library, "dlopen libsot_hip.so at `path` and resolve the entry points; returns its ABI version");
     m.def("mean_loss", &mean_loss, "mean over the rows of W_p^p(x_r, y_r) on planned shared positions; differentiable w.r.t. y");
+    m.def("mean_loss_fresh", &mean_loss_fresh, "mean_loss on raw 1-D position tensors: the plan is prepared inside the call (one allocation, one launch)");
     m.def("make_plan", &make_plan, "sot_prepare_positions into one allocation: (sorted x, sorted y, x permutation, y permutation, identity flags)");
     m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
 }

@@ -78,6 +78,12 @@ def _beyond_one_cu(x, y, *positions) -> bool:
     return True
 
 
+def _fresh_grid_ok(pos, x, width) -> bool:
+    """A caller-made position tensor the fresh-positions branch of Wasserstein1D.forward can hand to the C++ host path as it is."""
+    return (pos.ndim == 1 and pos.shape[0] == width and pos.dtype is torch.float32 and pos.is_cuda and pos.device == x.device
+            and pos.stride(0) == 1)
+
+
 def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, prenormalized=False):
     return ((nat.FLAG_SQUARE if square_dist else 0) | (nat.FLAG_DONT_NORMALIZE if dont_normalize else 0)
             | (nat.FLAG_LIMIT_Q if limit_quantile_range else 0) | (nat.FLAG_REQUIRE_SORT if require_sort else 0)
@@ -438,6 +444,19 @@ class Wasserstein1D(torch.nn.Module):
                     plan = hot[5]
                     plan.use_on_current_stream(x2.device)
                     return hot[7].mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), hot[6])
+            elif (x_pos is not None and y_pos is not None and self._settings() == hot[4] and 2 <= x.ndim <= 3 and x.ndim == y.ndim
+                  and hot[10] and _fresh_grid_ok(xp, x, hot[8]) and _fresh_grid_ok(yp, x, hot[9])):
+                # FRESH position tensors of the shapes seen last time -- the reference's trainer rebuilds its grid on every step
+                # (trainer.py:187-197: x_pos = torch.tensor(freqs).to(device) / max, y_pos = x_pos.clone()).  Their content cannot be
+                # compared on the host without a synchronisation, so the call gets its own plan, but inside the SAME C++ call as the loss
+                # (one allocation, one two-workgroup launch in front of the row kernel): no Python plan object, no cache bookkeeping, no
+                # general path.  hot[11]: the flag word WITHOUT the same-grid bit (whether two fresh tensors hold one grid is device-side
+                # knowledge; the C++ side puts it back when both arguments are one tensor).
+                x2 = x if x.ndim == 2 else x.reshape(-1, x.shape[-1])
+                y2 = y if y.ndim == 2 else y.reshape(-1, y.shape[-1])
+                if (x2.stride(1) == 1 and y2.stride(1) == 1 and x2.shape[1] == hot[8] and y2.shape[1] == hot[9]
+                        and not (torch.is_grad_enabled() and (x2.requires_grad or xp.requires_grad or yp.requires_grad))):
+                    return hot[7].mean_loss_fresh(x2, y2, xp, yp, float(self.p), hot[11] | (nat.FLAG_SAME_GRID if (xp is yp and hot[12]) else 0))
         x_pos_, y_pos_ = self._positions(x_pos, y_pos)
         if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y, x_pos_, y_pos_):
             return self._torch_forward(x, y, x_pos_, y_pos_, kwargs)
@@ -464,7 +483,11 @@ class Wasserstein1D(torch.nn.Module):
                 # remembering it and the flag word frozen here would lack SOT_FLAG_SAME_GRID for good
                 if (not kwargs and x_pos_.ndim == 1 and y_pos_.ndim == 1 and x2.shape[1] + y2.shape[1] <= 12000
                         and not torch.cuda.is_current_stream_capturing()):
-                    self._hot = (x_pos_, y_pos_, _version_of(x_pos_), _version_of(y_pos_), self._settings(), plan, fl, glue, x2.shape[1], y2.shape[1])
+                    # [10]: the fresh-positions branch of forward() applies (caller-passed positions, not the fixed_x buffer; the extension has it);
+                    # [11]: the flag word without the same-grid bit; [12]: the merge-free kernel may be asked for (p = 1, no cutoff)
+                    self._hot = (x_pos_, y_pos_, _version_of(x_pos_), _version_of(y_pos_), self._settings(), plan, fl, glue, x2.shape[1], y2.shape[1],
+                                 x_pos is not None and y_pos is not None and hasattr(glue, "mean_loss_fresh"), int(flags),
+                                 self.p == 1 and not (flags & (nat.FLAG_LIMIT_Q | nat.FLAG_NO_AREA | nat.FLAG_PRENORMALIZED)))
                 return glue.mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), fl)
             if grad_on and any(t.requires_grad for t in (x2, y2, x_pos_, y_pos_)):
                 return _FusedMeanLoss.apply(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
