@@ -60,7 +60,7 @@ def parse():
                     help="HIP streams the steps alternate over: 1 = one stream; 2 = the mean kernel / all-reduce of a step "
                          "overlaps the next step's forward kernel; 0 (default) = 1 on one GPU (per-kernel times then agree "
                          "with rocprofv3), 2 when there is a collective to hide (N > 1)")
-    ap.add_argument("--cpu-rows", type=int, default=2048)
+    ap.add_argument("--cpu-rows", type=int, default=8192)   # all rows of the headline workload (set 0); ~15 s of CPU work
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads reported under `extras`")
     return ap.parse_args()
 
@@ -232,6 +232,45 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     with torch.no_grad():
         out[f"b{B}n{N}_p1_forward_merge_kernel"] = entry(timed(p1_merge, n), forward_kernel_name(N, "p1", same_grid=False, batch=B), B * (8 * N + 4),
                                                          l3_resident=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
+
+    # (0b) the headline workload THROUGH THE MODULE (the timed step is a pre-bound C call): mod(x, y, x_pos=..., y_pos=...)
+    #      launched from Python under no_grad, forward + batch mean per call -- the hot-call cache and the C++ host path included
+    with torch.no_grad():
+        out[f"b{B}n{N}_p1_module_forward"] = entry(timed(lambda i: p1(sets[i % len(sets)][0], sets[i % len(sets)][1], x_pos=pos_x, y_pos=pos_y), n),
+                                                   forward_kernel_name(N, "p1", batch=B) + " + batch mean, through Wasserstein1D.forward",
+                                                   B * (8 * N + 4), l3_resident=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
+
+    # (0c) the pipeline north_star names literally -- sort of the supports + gather, losses.py:286-290 -- on the headline shape:
+    #      (a) an UNSORTED shared grid (a permuted linspace): planned once, the row kernel gathers through the permutation
+    #          (bytes as for the sorted grid: 4 (n + m) + 4 per row);
+    #      (b) PER-ROW positions (every row its own unsorted grid): the segmented in-LDS bitonic sort with index payload inside the
+    #          row kernel (sot_forward_kernel<..., ROWPOS ...>); algorithmic bytes 8 (n + m) + 4 per row
+    gperm = torch.Generator().manual_seed(99)
+    perm = torch.randperm(N, generator=gperm).to(dev)
+    ux, uy = pos_x[perm].contiguous(), pos_y[perm].contiguous()
+    uplan = nat.PositionPlan(ux, uy)
+    cutflags = 15
+    two = sets[:2]
+
+    def unsorted_shared(i):
+        x2, y2 = two[i % 2]
+        nat.forward_rows(x2, y2, ux, uy, 2.0, cutflags, uplan)
+
+    rows_pr = min(B, 4096)   # per-row positions of the full batch would be another 2 x 67 MB per set; 4096 rows fill the chip 4 x over
+    gpr = torch.Generator(device=dev).manual_seed(5)
+    prx = [torch.rand(rows_pr, N, device=dev, generator=gpr) for _ in range(2)]
+    pry = [torch.rand(rows_pr, N, device=dev, generator=gpr) for _ in range(2)]
+
+    def per_row(i):
+        x2, y2 = two[i % 2]
+        nat.forward_rows(x2[:rows_pr], y2[:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, None)
+
+    with torch.no_grad():
+        out[f"b{B}n{N}_unsorted_shared_forward"] = entry(timed(unsorted_shared, n), forward_kernel_name(N, "cutoff", batch=B) + " (gathers through the plan's permutation)",
+                                                         B * (8 * N + 4), l3_resident=True, note="position plan (sort of the shared grid) made once, outside the timed loop")
+        out[f"b{rows_pr}n{N}_per_row_positions_forward"] = entry(timed(per_row, n), "sot_forward_kernel<ROWPOS> (per-row segmented bitonic sort with index payload in LDS, then the merge pipeline)",
+                                                                 rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
+    del prx, pry
 
     # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
     cut = sot_entries(f"b{B}n{N}", B, N, sets, pos_x, pos_y, l3=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
@@ -435,36 +474,59 @@ def rccl_world1_probe():
         return {"rccl_world1": {"error": repr(exc)[:300]}}
 
 
-def cpu_baseline(mode, n, rows, seed):
+def cpu_baseline(mode, n, rows, seed, budget_s=25.0):
     """The reference's CPU PyTorch path (op-for-op restatement) on this host's cores, bounded sample.
     ATen's intra-op scaling on this problem saturates well below a big host's core count, so a few thread
-    counts are tried (within a ~25 s budget) and the best is reported with the count actually used."""
+    counts are tried (within `budget_s`) and the best is reported with the count actually used.  The SAME inputs as the GPU's set 0
+    (seed 1234, all `rows` rows of the workload when the budget allows: `rows_timed`); a `paper_mode` sibling times the paper's own
+    mode (p = 2, square_dist, dont_normalize, limit_quantile_range) on the same rows at the best thread count, and `per_row_scaling`
+    gives the time of half the rows relative to all of them (0.5 = linear in the row count)."""
     from oracle import torch_restatement as tr   # the ONLY use of oracle/ in this file: the timed CPU baseline
     from sot_amd.bench_inputs import spectrum_pairs
     ncpu = os.cpu_count() or 1
     x, y = spectrum_pairs("uniform", rows, n, n, seed)
     pos = torch.linspace(0, 1, n)
-    c = MODES[mode]
-    kw = dict(p=c.get("p", 1), square_dist=c.get("square_dist", False), dont_normalize=c.get("dont_normalize", False),
-              limit_quantile_range=c.get("limit_quantile_range", False))
+
+    def kwargs_of(m):
+        c = MODES[m]
+        return dict(p=c.get("p", 1), square_dist=c.get("square_dist", False), dont_normalize=c.get("dont_normalize", False),
+                    limit_quantile_range=c.get("limit_quantile_range", False))
+
+    def best_of(xr, yr, kw, threads, calls=2):
+        torch.set_num_threads(threads)
+        best, val = float("inf"), 0.0
+        with torch.no_grad():
+            tr.sot_loss(xr, yr, pos, pos.clone(), **kw)  # warm-up
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                val = tr.sot_loss(xr, yr, pos, pos.clone(), **kw)
+                best = min(best, time.perf_counter() - t0)
+        return best, float(val)
+
+    kw = kwargs_of(mode)
     best, best_threads, val, tried = float("inf"), 1, 0.0, []
-    t_end = time.perf_counter() + 25.0
+    t_end = time.perf_counter() + budget_s
     for threads in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
         if time.perf_counter() > t_end:
             break
-        torch.set_num_threads(threads)
-        with torch.no_grad():
-            tr.sot_loss(x, y, pos, pos.clone(), **kw)  # warm-up
-            for _ in range(2):
-                t0 = time.perf_counter()
-                val = tr.sot_loss(x, y, pos, pos.clone(), **kw)
-                dt = time.perf_counter() - t0
-                if dt < best:
-                    best, best_threads = dt, threads
+        dt, v = best_of(x, y, kw, threads)
+        if dt < best:
+            best, best_threads, val = dt, threads, v
         tried.append(threads)
-    return {"value": rows / best, "unit": f"rows/s ({rows}-row sample)", "cores": best_threads, "kind": "port",
-            "sample": f"{rows} rows x N={n}, mode {mode}: best call of oracle/torch_restatement.sot_loss over thread counts "
-                      f"{tried} on a {ncpu}-cpu host (torch {torch.__version__} CPU)", "scalar": float(val)}
+    rec = {"value": rows / best, "unit": f"rows/s ({rows}-row sample)", "cores": best_threads, "kind": "port", "rows_timed": rows,
+           "sample": f"{rows} rows x N={n}, mode {mode}: best call of oracle/torch_restatement.sot_loss over thread counts "
+                     f"{tried} on a {ncpu}-cpu host (torch {torch.__version__} CPU)", "scalar": float(val)}
+    try:
+        half = max(1, rows // 2)
+        dt_half, _ = best_of(x[:half], y[:half], kw, best_threads)
+        rec["per_row_scaling"] = {"rows": half, "seconds": dt_half, "relative_to_all_rows": dt_half / best}
+        if mode != "cutoff":
+            dt_p, v_p = best_of(x, y, kwargs_of("cutoff"), best_threads)
+            rec["paper_mode"] = {"value": rows / dt_p, "unit": f"rows/s ({rows}-row sample)", "cores": best_threads, "rows_timed": rows,
+                                 "mode": MODES["cutoff"], "scalar": v_p}
+    except Exception as exc:  # noqa: BLE001 -- the siblings must not take the baseline with them
+        rec["paper_mode"] = {"error": repr(exc)[:200]}
+    return rec
 
 
 # Launches of the timed region whose dominant kernel is timed: the library attaches a HIP start / stop event pair to the kernel
@@ -801,6 +863,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": forward_kernel_name(N, args.mode, batch=B), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B,
+                         "headline_is": ("merge-free p=1 kernel (both measures on one sorted grid: no sort, no search, no merge); the merge pipeline "
+                                         "north_star describes: see roofline.merge_p1 / roofline.paper_mode / roofline.training_form")
+                                        if (args.mode == "p1") else "merge pipeline (sort/cumsum/merge-path search/walk)",
                          **side},
             "extras": extras,
         }

@@ -174,6 +174,10 @@ int sot_oracle_forward(const float *x, const float *y, const float *xpos, const 
     if (!(p >= 1.0f)) return 1; /* losses.py:271 assert p >= 1 */
     if (n <= 0 || m <= 0) return 2;
     const int K = n + m;
+    /* Rows are independent (losses.py:273-313 has no cross-row operation): with -fopenmp (oracle/Makefile) they are spread over the
+     * host's cores, every thread with its own scratch; without it the pragmas are ignored.  Results do not depend on the thread count. */
+#pragma omp parallel
+    {
     float *a = (float *)malloc(sizeof(float) * (size_t)n), *b = (float *)malloc(sizeof(float) * (size_t)m);
     float *xs = (float *)malloc(sizeof(float) * (size_t)n), *ys = (float *)malloc(sizeof(float) * (size_t)m);
     float *U = (float *)malloc(sizeof(float) * (size_t)n), *V = (float *)malloc(sizeof(float) * (size_t)m);
@@ -181,6 +185,7 @@ int sot_oracle_forward(const float *x, const float *y, const float *xpos, const 
     float *tmpw = (float *)malloc(sizeof(float) * (size_t)(n > m ? n : m));
     kv_t *kv = (kv_t *)malloc(sizeof(kv_t) * (size_t)(n > m ? n : m));
 
+#pragma omp for schedule(static)
     for (int64_t r = 0; r < B; r++) {
         const float *xr = x + r * (int64_t)n, *yr = y + r * (int64_t)m;
         const float *xp = xpos + r * xpos_stride, *yp = ypos + r * ypos_stride;
@@ -251,6 +256,7 @@ int sot_oracle_forward(const float *x, const float *y, const float *xpos, const 
         }
     }
     free(a); free(b); free(xs); free(ys); free(U); free(V); free(Q); free(term); free(tmpw); free(kv);
+    }   /* omp parallel */
     return 0;
 }
 
@@ -280,6 +286,8 @@ int sot_oracle_backward(const float *x, const float *y, const float *xpos, const
     if (!(p >= 1.0f)) return 1;
     const int K = n + m;
     const int nm = n > m ? n : m;
+#pragma omp parallel
+    {
     float *a = (float *)malloc(sizeof(float) * (size_t)n), *b = (float *)malloc(sizeof(float) * (size_t)m);
     float *w = (float *)malloc(sizeof(float) * (size_t)nm);
     float *xs = (float *)malloc(sizeof(float) * (size_t)n), *ys = (float *)malloc(sizeof(float) * (size_t)m);
@@ -290,6 +298,7 @@ int sot_oracle_backward(const float *x, const float *y, const float *xpos, const
     int *src = (int *)malloc(sizeof(int) * (size_t)K);
     kv_t *kv = (kv_t *)malloc(sizeof(kv_t) * (size_t)nm);
 
+#pragma omp for schedule(static)
     for (int64_t r = 0; r < B; r++) {
         const float *xr = x + r * (int64_t)n, *yr = y + r * (int64_t)m;
         const float *xp = xpos + r * xpos_stride, *yp = ypos + r * ypos_stride;
@@ -361,8 +370,9 @@ int sot_oracle_backward(const float *x, const float *y, const float *xpos, const
             gy[r * (int64_t)m + py[jj]] = (float)(g * gr);
         }
     }
-    (void)w;
+    (void)w;   /* inside the parallel region: every thread's own */
     free(a); free(b); free(w); free(xs); free(ys); free(U); free(V); free(px); free(py);
     free(gU); free(gV); free(dk); free(src); free(kv);
+    }   /* omp parallel */
     return 0;
 }

@@ -109,7 +109,7 @@ def test_config2_full_size_scalars(kind, mode, manifest):
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 def test_full_row_kernel_matches_generic(N, B, flags, p):
     """Rows that fill their launch geometry (n == m == G*CPT) run the fully specialised forward kernel: it must agree
-    bit for bit with the generic kernel (SOT_FLAG_NO_SPECIALIZE) and, on a sample of rows, with the oracle.  (4096 bins:
+    bit for bit with the generic kernel (SOT_FLAG_NO_SPECIALIZE) and, on EVERY row, with the oracle.  (4096 bins:
     the generic kernel runs 256 threads x 16 elements, the specialised one 512 x 8: the same terms, another association of
     the row's final sum, hence a few ulp.)"""
     from oracle.inputs import gen_inputs
@@ -126,7 +126,7 @@ def test_full_row_kernel_matches_generic(N, B, flags, p):
         torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)   # loser-form walk may evaluate |a - b| as |b - a| -> same value
     else:
         assert torch.equal(spec, gen), float((spec - gen).abs().max())
-    k = min(B, 24)
+    k = B   # every row against the oracle (round 4: the oracle runs its rows on all host cores, oracle/Makefile -fopenmp)
     want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
 
@@ -135,7 +135,7 @@ def test_full_row_kernel_matches_generic(N, B, flags, p):
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
     """The specialised backward kernel (rows with n == m == 512 / 2048) gives bit for bit the gradients of the generic
-    kernel, and the oracle's closed form on a sample of rows."""
+    kernel, and the oracle's closed form on every row."""
     from oracle.inputs import gen_inputs
     from oracle import sot_oracle as so
     nat = native()
@@ -154,7 +154,7 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
             assert float(((got - ref).abs() / (ref.abs().amax(dim=1, keepdim=True) + 1e-30)).max()) <= 2e-6
     only_y = nat.backward_rows(x, y, pos, pos2, p, flags, g, need_gx=False, plan=plan, grad_scale=0.25)
     assert only_y[0] is None and torch.equal(only_y[1], sy)
-    k = min(B, 6)
+    k = B   # every row against the oracle
     wx, wy = so.backward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(),
                          (0.25 * g[:k]).cpu().numpy(), p=p, flags=flags & 15)
     for got, want in ((sx[:k].cpu().numpy(), wx), (sy[:k].cpu().numpy(), wy)):
@@ -181,7 +181,7 @@ def test_paper_row_lengths_compile_time_kernel(N, B, flags, p, kind):
     spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
     gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
     torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
-    k = min(B, 40)
+    k = B   # every row against the oracle
     want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
 
@@ -201,7 +201,7 @@ def test_paper_row_lengths_backward(N, B, flags, p):
     g = torch.linspace(0.5, 1.5, B).to(device())
     sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g, plan=plan, grad_scale=0.5)
     gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g, plan=plan, grad_scale=0.5)
-    k = min(B, 8)
+    k = B   # every row against the oracle
     wx, wy = so.backward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(),
                          (0.5 * g[:k]).cpu().numpy(), p=p, flags=flags & 15)
     for got, ref, want in ((sx, gx, wx), (sy, gy, wy)):
@@ -1254,7 +1254,7 @@ def test_runtime_length_forward_matches_generic_and_oracle(N, B, flags, p):
     spec = nat.forward_rows(x, y, pos, pos2, p, flags, plan)
     gen = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, plan)
     torch.testing.assert_close(spec, gen, rtol=2e-6, atol=1e-12)
-    k = min(B, 12)
+    k = B   # every row against the oracle
     want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos2.cpu().numpy(), p=p, flags=flags & 15)
     np.testing.assert_allclose(spec[:k].cpu().numpy(), want, rtol=RTOL)
     if p == 1.0 and not (flags & 4):          # one grid on both sides: the merge-free kernel with a run-time length
@@ -1282,7 +1282,7 @@ def test_runtime_length_backward_and_training_form(N, B, flags, p):
     g = torch.linspace(0.5, 1.5, B).to(dev)
     sx, sy = nat.backward_rows(x, y, pos, pos2, p, flags, g, plan=plan, grad_scale=0.5)
     gx, gy = nat.backward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_SPECIALIZE, g, plan=plan, grad_scale=0.5)
-    k = min(B, 6)
+    k = B   # every row against the oracle
     wx, wy = so.backward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), (0.5 * g[:k]).cpu().numpy(),
                          p=p, flags=flags & 15)
     for got, ref, want in ((sx, gx, wx), (sy, gy, wy)):
@@ -1348,7 +1348,7 @@ def test_large_batches_one_wave_per_row_forward(N, B, flags, p):
     pos2 = pos.clone()
     plan = nat.PositionPlan(pos, pos2) if flags & 8 else None
     big = nat.forward_rows(x, y, pos, pos2, p, flags | nat.FLAG_NO_AREA, plan)
-    k = 64
+    k = B   # every row against the oracle
     want = so.forward(x[:k].cpu().numpy(), y[:k].cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), p=p, flags=flags & 15)
     np.testing.assert_allclose(big[:k].cpu().numpy(), want, rtol=RTOL)
     small = torch.cat([nat.forward_rows(x[i:i + 2000], y[i:i + 2000], pos, pos2, p, flags | nat.FLAG_NO_AREA, plan) for i in range(0, B, 2000)])
@@ -1377,7 +1377,7 @@ def test_one_wave_rows_with_unsorted_positions_strides_and_the_in_kernel_mean():
         torch.testing.assert_close(rows_big, rows_small, rtol=2e-6, atol=1e-12)
         # against the oracle on the same permuted grid (it sorts like the reference)
         from oracle import sot_oracle as so
-        k = 48
+        k = B   # every row against the oracle
         want = so.forward(xs[:k].cpu().numpy(), ys[:k].cpu().numpy(), pos.numpy(), pos.numpy(), p=2.0, flags=1 | 2 | 4 | 8)
         np.testing.assert_allclose(rows_big[:k].cpu().numpy(), want, rtol=RTOL)
         # the same rows on the sorted grid, columns permuted accordingly: the same problem up to the summation order of the row mass
