@@ -456,4 +456,102 @@ __device__ __forceinline__ void bitonic_sort_kv(float* key, int* idx, int npad, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-LDS MERGE sort of (key, index) pairs (round 4): the same result as bitonic_sort_kv -- ascending keys, equal keys in ascending index order
+// when idx starts as 0 .. n-1 with the pads (+inf, INT_MAX) behind: the sort is STABLE -- in O(N log N) instead of O(N log^2 N) and with
+// 1 + 2 log2(npad / 8) barriers instead of log2(npad) (log2(npad) + 1) / 2 (2048 points: 17 instead of 66; ~1700 instead of ~13 000
+// instructions per thread).  Phase 0: every aligned block of 8 elements is sorted in the registers of one thread by odd-even
+// transposition (adjacent exchanges on strict "greater": stable).  Round r: runs of L = 8 * 2^(r-1) are merged pairwise; the thread that
+// owns outputs [8 v, 8 v + 8) of the array finds its split of the pair by bisection on the merge path (left run first on ties: stable),
+// merges eight elements into registers, and after a barrier writes them back IN PLACE (no second LDS buffer).
+// npad: power of two >= 8.  All T threads call it; at most MAXV * T blocks of 8 (npad <= 8 MAXV T).  sync(): barrier over those threads.
+// ---------------------------------------------------------------------------------------------
+template <int MAXV, typename Sync>
+__device__ __forceinline__ void merge_sort_kv(float* key, int* idx, int npad, int t, int T, Sync sync)
+{
+    const int NV = npad >> 3;
+    // phase 0: blocks of 8 in registers
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int v = t + j * T;
+        if (v < NV) {
+            float k[8]; int x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { k[e] = key[8 * v + e]; x[e] = idx[8 * v + e]; }
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+                for (int e = pass & 1; e + 1 < 8; e += 2) {
+                    const bool sw = k[e] > k[e + 1];
+                    const float ka = sw ? k[e + 1] : k[e], kb = sw ? k[e] : k[e + 1];
+                    const int xa = sw ? x[e + 1] : x[e], xb = sw ? x[e] : x[e + 1];
+                    k[e] = ka; k[e + 1] = kb; x[e] = xa; x[e + 1] = xb;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { key[8 * v + e] = k[e]; idx[8 * v + e] = x[e]; }
+        }
+    }
+    sync();
+    int logL = 3;
+    for (int L = 8; L < npad; L <<= 1, ++logL) {
+        float ok[MAXV][8]; int oi[MAXV][8];
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int v = t + j * T;
+            if (v < NV) {
+                const int o = 8 * v;                        // first output position of this thread
+                const int a0 = o & ~(2 * L - 1), b0 = a0 + L;  // the pair of runs it falls into
+                const int d = o - a0;                       // outputs of the pair in front of it
+                int lo = max(0, d - L), hi = min(d, L);
+                for (int it = 0; it <= logL; ++it) {        // bisection: lo = number of left-run elements among the first d merged
+                    if (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const bool take = key[a0 + mid] <= key[b0 + d - 1 - mid];
+                        lo = take ? mid + 1 : lo;
+                        hi = take ? hi : mid;
+                    }
+                }
+                int ia = lo, ib = d - lo;
+                float ka = key[a0 + min(ia, L - 1)], kb = key[b0 + min(ib, L - 1)];
+                int xa = idx[a0 + min(ia, L - 1)], xb = idx[b0 + min(ib, L - 1)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ta = (ia < L) && ((ib >= L) || (ka <= kb));
+                    ok[j][e] = ta ? ka : kb;
+                    oi[j][e] = ta ? xa : xb;
+                    ia += ta ? 1 : 0;
+                    ib += ta ? 0 : 1;
+                    const int nx = ta ? a0 + min(ia, L - 1) : b0 + min(ib, L - 1);
+                    const float kn = key[nx];
+                    const int xn = idx[nx];
+                    ka = ta ? kn : ka; xa = ta ? xn : xa;
+                    kb = ta ? kb : kn; xb = ta ? xb : xn;
+                }
+            }
+        }
+        sync();   // every read of this round is done
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int v = t + j * T;
+            if (v < NV) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { key[8 * v + e] = ok[j][e]; idx[8 * v + e] = oi[j][e]; }
+            }
+        }
+        sync();
+    }
+}
+
+#ifndef SOT_MERGE_SORT
+#define SOT_MERGE_SORT 1   /* 0: the bitonic network of rounds 1-3 everywhere */
+#endif
+// the sort the kernels call: merge sort where its preconditions hold (npad >= 8, npad <= 8 MAXV T), the bitonic network otherwise
+template <int MAXV, typename Sync>
+__device__ __forceinline__ void sort_kv(float* key, int* idx, int npad, int t, int T, Sync sync)
+{
+    if (SOT_MERGE_SORT && npad >= 8 && npad <= 8 * MAXV * T) merge_sort_kv<MAXV>(key, idx, npad, t, T, sync);
+    else bitonic_sort_kv(key, idx, npad, t, T, sync);
+}
+
 }  // namespace sot

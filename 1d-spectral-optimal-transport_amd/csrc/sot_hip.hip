@@ -271,7 +271,9 @@ __device__ __forceinline__ void store_row(float* dst, int len, int t, const floa
 // ---- P0 (ROWPOS): this row's positions -> LDS, sorted with an index payload when REQUIRE_SORT ---------
 // On return ix/iy hold, for the CPT contiguous elements this thread owns in SORTED order, their
 // original column.  Ends with a barrier (U/V may be overwritten by the weights afterwards).
-template <int G, int CPT>
+// MERGE: the stable merge sort of sot_device.hpp (round 4; its two 16-register output arrays cost the register-capped CSR kernel
+// occupancy -- 26.5 -> 34.7 us on config 4's rows, which never need the sort -- so that instantiation keeps the bitonic network)
+template <int G, int CPT, bool MERGE = true>
 __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* xp, const float* yp, int nmax, int mmax,
                                                int (&ix)[CPT], int (&iy)[CPT])
 {
@@ -313,8 +315,13 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
     }
     const bool need_sort = row_any<G / kWave>(unsorted != 0);  // also the barrier after the loads
     if (need_sort) {
-        bitonic_sort_kv(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });
-        bitonic_sort_kv(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
+        if constexpr (MERGE) {
+            sort_kv<2>(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });   // stable merge sort (sot_device.hpp); npx <= 16 G
+            sort_kv<2>(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
+        } else {
+            bitonic_sort_kv(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });
+            bitonic_sort_kv(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
+        }
     }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -589,7 +596,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G), ((CSR && G == 64) ? SOT_CSR_MI
         }
         const int n = c.n, m = c.m, K = c.K;
         int ix[CPT], iy[CPT];
-        if (ROWPOS) rowpos_prepare<G, CPT>(c, xp, yp, a.n, a.m, ix, iy);
+        if (ROWPOS) rowpos_prepare<G, CPT, !CSR>(c, xp, yp, a.n, a.m, ix, iy);
         // ---- P1: registers -> LDS (original column order), then fetch the next row into the registers --
         store_row<G, CPT, VEC>(U, n, t, rx);
         store_row<G, CPT, VEC>(V, m, t, ry);
@@ -1388,7 +1395,7 @@ __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     if (bad) *unsorted_flag = 1;
     __syncthreads();
     const bool need_sort = *unsorted_flag != 0;
-    if (need_sort) bitonic_sort_kv(key, idx, npad, t, T, [] { __syncthreads(); });
+    if (need_sort) sort_kv<4>(key, idx, npad, t, T, [] { __syncthreads(); });
     for (int i = t; i < len; i += T) { spos[i] = key[i]; perm[i] = idx[i]; }
     if (t == 0) ident[which] = need_sort ? 0 : 1;
 }
@@ -1454,7 +1461,7 @@ __global__ __launch_bounds__(256) void sot_scale_inplace_kernel(float* __restric
 // ---------------------------------------------------------------------------------------------
 // Standalone segmented sort (torch.sort(keys, 1) of losses.py:287-288): one workgroup per row.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sot_segmented_sort_kernel(const float* __restrict__ keys, int64_t B, int n, int64_t stride,
+__global__ __launch_bounds__(1024) void sot_segmented_sort_kernel(const float* __restrict__ keys, int64_t B, int n, int64_t stride,
                                                                  float* __restrict__ out_keys, int64_t* __restrict__ out_idx)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1466,7 +1473,7 @@ __global__ __launch_bounds__(256) void sot_segmented_sort_kernel(const float* __
         const float* src = keys + row * stride;
         for (int i = t; i < npad; i += T) { key[i] = (i < n) ? src[i] : INFINITY; idx[i] = (i < n) ? i : INT_MAX; }
         __syncthreads();
-        bitonic_sort_kv(key, idx, npad, t, T, [] { __syncthreads(); });
+        sort_kv<2>(key, idx, npad, t, T, [] { __syncthreads(); });   // the launcher sizes the block so that npad <= 16 T
         for (int i = t; i < n; i += T) {
             if (out_keys) out_keys[row * (int64_t)n + i] = key[i];
             if (out_idx) out_idx[row * (int64_t)n + i] = (int64_t)idx[i];
@@ -1854,7 +1861,9 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
     int64_t cap = (int64_t)sot::device_cu_count() * per_cu;
     const int grid = (int)(B < cap ? B : cap);
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
-    hipLaunchKernelGGL(sot::sot_segmented_sort_kernel, dim3(grid), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), keys, B,
+    int block = 256;                                   // merge sort: at most two blocks of 8 elements per thread
+    while (block < 1024 && sot::next_pow2((int)n) > 16 * block) block <<= 1;
+    hipLaunchKernelGGL(sot::sot_segmented_sort_kernel, dim3(grid), dim3(block), lds, reinterpret_cast<hipStream_t>(stream), keys, B,
                        (int)n, row_stride, sorted_keys, indices);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }

@@ -265,12 +265,21 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         x2, y2 = two[i % 2]
         nat.forward_rows(x2[:rows_pr], y2[:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, None)
 
+    srx = [torch.sort(t_, dim=1).values for t_ in prx]   # the same grids already in ascending order per row: the kernel's sortedness test
+    sry = [torch.sort(t_, dim=1).values for t_ in pry]   # passes and the sort is skipped (per-row positions without the sort)
+
+    def per_row_sorted(i):
+        x2, y2 = two[i % 2]
+        nat.forward_rows(x2[:rows_pr], y2[:rows_pr], srx[i % 2], sry[i % 2], 2.0, cutflags, None)
+
     with torch.no_grad():
         out[f"b{B}n{N}_unsorted_shared_forward"] = entry(timed(unsorted_shared, n), forward_kernel_name(N, "cutoff", batch=B) + " (gathers through the plan's permutation)",
                                                          B * (8 * N + 4), l3_resident=True, note="position plan (sort of the shared grid) made once, outside the timed loop")
-        out[f"b{rows_pr}n{N}_per_row_positions_forward"] = entry(timed(per_row, n), "sot_forward_kernel<ROWPOS> (per-row segmented bitonic sort with index payload in LDS, then the merge pipeline)",
+        out[f"b{rows_pr}n{N}_per_row_positions_forward"] = entry(timed(per_row, n), "sot_forward_kernel<ROWPOS> (per-row segmented stable merge sort with index payload in LDS, then the merge pipeline)",
                                                                  rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
-    del prx, pry
+        out[f"b{rows_pr}n{N}_per_row_sorted_positions_forward"] = entry(timed(per_row_sorted, n), "sot_forward_kernel<ROWPOS> (rows already sorted: sortedness test only)",
+                                                                        rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
+    del prx, pry, srx, sry
 
     # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
     cut = sot_entries(f"b{B}n{N}", B, N, sets, pos_x, pos_y, l3=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
