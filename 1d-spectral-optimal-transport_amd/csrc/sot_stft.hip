@@ -78,7 +78,57 @@ __device__ __forceinline__ void store_spec(float2* sp, int k, int mk, v2f xk, v2
     sp[mk] = make_float2(xm.x, xm.y);
 }
 
-__device__ __forceinline__ v2f cmul(v2f a, v2f b) { return a.xx * b + a.yy * (v2f){-b.y, b.x}; }
+// Complex product on the packed-fp32 unit.  Round 4: the swizzled product a.yy * (-b.y, b.x) is ONE v_pk_mul_f32 whose operand halves
+// are picked by op_sel and negated by neg_lo (hipcc builds the swizzled operand with v_xor + v_mov first: five instructions per product
+// instead of three).  Same three roundings as the vector expression, so every result is bit-identical to rounds 2-3.  (A fused form --
+// v_pk_mul + v_pk_fma, two instructions -- was measured too: its last-bit differences move rows of the SOT stage across the cutoff's
+// knife edge, which the float64 yardstick test of the audio-in chain does not tolerate: 1.2e-5 -> 1.5e-4 of the gradient's peak.)
+#ifndef SOT_STFT_ASM_CMUL
+#define SOT_STFT_ASM_CMUL 1
+#endif
+__device__ __forceinline__ v2f cmul(v2f a, v2f b)
+{
+#if SOT_STFT_ASM_CMUL
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));   // (-a.y b.y, a.y b.x)
+    return a.xx * b + t;
+#else
+    return a.xx * b + a.yy * (v2f){-b.y, b.x};
+#endif
+}
+// a * conj(b) = a.xx * (b.x, -b.y) + a.yy * (b.y, b.x)
+__device__ __forceinline__ v2f cmul_conj(v2f a, v2f b)
+{
+#if SOT_STFT_ASM_CMUL
+    v2f t1, t2;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(a), "v"(b));   // (a.x b.x, -a.x b.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(a), "v"(b));               // (a.y b.y, a.y b.x)
+    return t1 + t2;
+#else
+    return a.xx * (v2f){b.x, -b.y} + a.yy * (v2f){b.y, b.x};
+#endif
+}
+// a + (-i) b = (a.x + b.y, a.y - b.x)   and   a + (+i) b = (a.x - b.y, a.y + b.x): one packed add with swapped / negated halves
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b)
+{
+#if SOT_STFT_ASM_CMUL
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (v2f){a.x + b.y, a.y - b.x};
+#endif
+}
+__device__ __forceinline__ v2f add_pi(v2f a, v2f b)
+{
+#if SOT_STFT_ASM_CMUL
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (v2f){a.x - b.y, a.y + b.x};
+#endif
+}
 __device__ __forceinline__ v2f cconj(v2f a) { return (v2f){a.x, -a.y}; }
 __device__ __forceinline__ v2f mul_i(v2f a) { return (v2f){-a.y, a.x}; }    // a * (+i)
 __device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }   // a * (-i)
@@ -254,6 +304,23 @@ __device__ __forceinline__ float magnitude(v2f x)
     return sqrtf(s);
 #endif
 }
+
+// |x| for a frame whose input amplitude has been checked once (frame_is_plain below): re^2 + im^2 can neither overflow nor lose the bins
+// that matter to underflow, so the per-value range test, the wave vote and the libm sqrtf (range scaling + special cases: ~20 VALU
+// instructions) shrink to v_sqrt_f32, v_rsq_f32 and one Newton step on the residual (8 instructions; the result is within half an ulp of
+// sqrt(s) up to the rounding of s itself, like torch's hypot-based abs(complex)); s == 0 gives 0.
+__device__ __forceinline__ float magnitude_plain(v2f x)
+{
+    const float s = fmaf(x.x, x.x, x.y * x.y);
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
+    const float e = fmaf(-r, r, s);
+    const float v = fmaf(e, h, r);
+    return s == 0.0f ? 0.0f : v;
+}
+// amax = largest |sample * tap| of the frame.  |X_k| <= n amax, so the squares cannot overflow below 1e15; the spectrum's peak is >= amax
+// (Parseval), so with amax > 1e-9 every bin within 1e-10 of the peak keeps a normal square.  An all-zero frame is plain too (every bin 0).
+__device__ __forceinline__ bool frame_is_plain(float amax) { return (amax > 1e-9f && amax < 1e15f) || amax == 0.0f; }
 
 // spectrum bins k and m-k of the real frame from the packed transform (see Geo)
 template <int LOGM>
@@ -538,6 +605,197 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
                 if (sp != nullptr) store_spec(sp, k, m - k, xk, xm);
             }
         }
+        slot_sync<true>();   // the unpack reads are issued before the next frame's exchange writes
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 4: the one-wavefront-per-frame transform again, rebuilt around occupancy (stft_mag_forward_wave2_kernel, n_fft 2048).
+// What the round-2 kernel above paid for: 194 VGPRs (two waves per SIMD) and three quarters of a CU's LDS per four frames.  Here
+//  * ONE 1024-thread workgroup per CU: sixteen waves = sixteen frames in flight per CU share one twiddle table (W_1024^j, 8 KB) and one
+//    copy of the window (8 KB); 159.8 KB of LDS; the 128-VGPR budget of a 1024-thread workgroup is met by doing every radix-4 stage IN
+//    PLACE on the sixteen points a lane holds (no second 16-point array);
+//  * the frame's |.| values take magnitude_plain() after ONE range test per frame on the windowed samples (frame_is_plain) instead of a
+//    range test, a wave vote and libm's sqrtf per value;
+//  * samples and taps are fetched as 8-byte pairs (the clip's row and hop keep frames 8-byte aligned in every reference configuration; a
+//    scalar path covers the rest).
+// No workgroup barrier inside the frame loop: a wave's exchanges through its private LDS buffer need only wave-level ordering.
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INVERSE ? cmul_conj(a, w) : cmul(a, w); }   // a * twiddle (inverse: conjugate twiddle)
+
+template <bool INVERSE>
+__device__ __forceinline__ void bf4_ip(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
+{
+    const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13; a2 = s02 - s13;
+    a1 = INVERSE ? add_pi(d02, d13) : add_mi(d02, d13);   // d02 + (-+i) d13
+    a3 = INVERSE ? add_mi(d02, d13) : add_pi(d02, d13);   // d02 - (-+i) d13
+}
+
+// r[q] = z[64 q + lane] on entry; on return the transform sits in zl[zi(k)], k = 0 .. 1023 (after the caller's slot_sync).  The index
+// algebra is fft1024_wave's (five radix-4 decimation-in-frequency stages, two exchanges), every stage in place.
+template <bool INVERSE>
+__device__ __forceinline__ void fft1024_wave_ip(v2f (&r)[16], v2f* zl, const v2f* tw, int lane)
+{
+    // stage 1 (digit d4; registers 4 p + d3 -> 4 q + d3): twiddle W_1024^{(64 d3 + lane) q}
+#pragma unroll
+    for (int d3 = 0; d3 < 4; ++d3) {
+        const int j = 64 * d3 + lane;
+        const v2f w1 = tw[j & 1023], w2 = tw[(2 * j) & 1023], w3 = tw[(3 * j) & 1023];   // requested ahead of the butterfly
+        bf4_ip<INVERSE>(r[d3], r[4 + d3], r[8 + d3], r[12 + d3]);
+        r[4 + d3] = ctw<INVERSE>(r[4 + d3], w1); r[8 + d3] = ctw<INVERSE>(r[8 + d3], w2); r[12 + d3] = ctw<INVERSE>(r[12 + d3], w3);
+    }
+    // stage 2 (digit d3; registers 4 q4 + p -> 4 q4 + q): twiddle W_256^{lane q} = W_1024^{4 lane q}
+    {
+        const v2f w1 = tw[(4 * lane) & 1023], w2 = tw[(8 * lane) & 1023], w3 = tw[(12 * lane) & 1023];   // the same three for every q4
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            bf4_ip<INVERSE>(r[4 * q4], r[4 * q4 + 1], r[4 * q4 + 2], r[4 * q4 + 3]);
+            r[4 * q4 + 1] = ctw<INVERSE>(r[4 * q4 + 1], w1); r[4 * q4 + 2] = ctw<INVERSE>(r[4 * q4 + 2], w2); r[4 * q4 + 3] = ctw<INVERSE>(r[4 * q4 + 3], w3);
+        }
+    }
+    // exchange 1: register (q4, q3) of lane (d2, d1, d0) -> register (d2, d1) of lane (q4, q3, d0)
+    const int d0 = lane & 3;
+    {
+        const int rr = lane >> 2;   // 4 d2 + d1
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zl[(4 * q + d0) * 17 + rr] = r[q];
+        slot_sync<true>();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = zl[lane * 17 + q];
+        slot_sync<true>();
+    }
+    // stage 3 (digit d2; registers 4 p + d1 -> 4 q + d1): twiddle W_64^{(4 d1 + d0) q} = W_1024^{16 (4 d1 + d0) q}
+#pragma unroll
+    for (int d1 = 0; d1 < 4; ++d1) {
+        const int j = 16 * (4 * d1 + d0);
+        const v2f w1 = tw[j & 1023], w2 = tw[(2 * j) & 1023], w3 = tw[(3 * j) & 1023];
+        bf4_ip<INVERSE>(r[d1], r[4 + d1], r[8 + d1], r[12 + d1]);
+        r[4 + d1] = ctw<INVERSE>(r[4 + d1], w1); r[8 + d1] = ctw<INVERSE>(r[8 + d1], w2); r[12 + d1] = ctw<INVERSE>(r[12 + d1], w3);
+    }
+    // stage 4 (digit d1; registers 4 q2 + p -> 4 q2 + q): twiddle W_16^{d0 q} = W_1024^{64 d0 q}
+    {
+        const v2f w1 = tw[(64 * d0) & 1023], w2 = tw[(128 * d0) & 1023], w3 = tw[(192 * d0) & 1023];   // the same three for every q2
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+            bf4_ip<INVERSE>(r[4 * q2], r[4 * q2 + 1], r[4 * q2 + 2], r[4 * q2 + 3]);
+            r[4 * q2 + 1] = ctw<INVERSE>(r[4 * q2 + 1], w1); r[4 * q2 + 2] = ctw<INVERSE>(r[4 * q2 + 2], w2); r[4 * q2 + 3] = ctw<INVERSE>(r[4 * q2 + 3], w3);
+        }
+    }
+    // exchange 2: register (q2, q1) of lane (q4, q3, d0) -> register (d0, q1) of lane (q4, q3, q2)
+    {
+        const int hi = lane >> 2;   // 4 q4 + q3
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zl[(4 * hi + (q >> 2)) * 17 + 4 * d0 + (q & 3)] = r[q];
+        slot_sync<true>();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = zl[lane * 17 + q];
+        slot_sync<true>();
+    }
+    // stage 5 (digit d0; registers 4 p + q1 -> 4 q0 + q1), no twiddle; result (q4 q3 q2 q1 q0) is frequency k = q4 + 4 q3 + 16 q2 + 64 q1 + 256 q0
+    const int kb = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) {
+        bf4_ip<INVERSE>(r[q1], r[4 + q1], r[8 + q1], r[12 + q1]);
+#pragma unroll
+        for (int q0 = 0; q0 < 4; ++q0) zl[zi(kb + 64 * q1 + 256 * q0)] = r[4 * q0 + q1];
+    }
+}
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+constexpr int kWave2Threads = 1024;
+constexpr int kWave2Waves = kWave2Threads / 64;
+constexpr size_t kWave2LdsBytes = (1024 + 520 + 1024 + (size_t)kWave2Waves * kWaveBuf) * sizeof(float2);
+
+// the frame's bins from the transform in LDS: |.| / sqrt(n) (and the complex spectrum on request); PLAIN: magnitude_plain(), else the careful form
+template <bool PLAIN>
+__device__ __forceinline__ void wave2_unpack_store(const v2f* zl, const v2f* wn, int lane, float scale, float* dst, float2* sp)
+{
+    constexpr int LOGM = 10, m = 1024;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int k = lane + 64 * j;
+        if (j < 8 || k <= m / 2) {
+            v2f xk, xm;
+            unpack_pair<LOGM>(zl, wn, k, xk, xm);
+            store_mag(dst, k, (PLAIN ? magnitude_plain(xk) : magnitude(xk)) * scale);
+            store_mag(dst, m - k, (PLAIN ? magnitude_plain(xm) : magnitude(xm)) * scale);
+            if (sp != nullptr) store_spec(sp, k, m - k, xk, xm);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWave2Threads) void stft_mag_forward_wave2_kernel(const StftArgs a)
+{
+    constexpr int m = 1024, n = 2048, nb = m + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    v2f* const tw = reinterpret_cast<v2f*>(smem_f);          // W_1024^j, j < 1024
+    v2f* const wn = tw + 1024;                                // W_2048^k, k <= 512 (+ pad)
+    v2f* const wl = wn + 520;                                 // window taps (2 i, 2 i + 1), i < 1024
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // the wave number in a scalar register:
+    v2f* const zl = wl + 1024 + wave * kWaveBuf;                                                        // frame, clip and row pointers stay scalar
+    const float2* win = reinterpret_cast<const float2*>(a.window);
+    const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;
+    const unsigned stride = gridDim.x * kWave2Waves;
+    v2f r[16];
+    auto fetch = [&](unsigned fr) {   // raw samples (2 i, 2 i + 1), i = 64 q + lane, of frame fr; zeros past the clip's end (utils.py:252-275)
+        const unsigned b = fr / frames, f = fr - b * frames;
+        const float* src = (a.audio_b != nullptr && (int64_t)b >= a.split) ? a.audio_b + ((int64_t)b - a.split) * a.row_stride_b
+                                                                          : a.audio + (int64_t)b * a.row_stride;
+        const int64_t t0 = (int64_t)f * a.hop;
+        const float* const s0 = src + t0;
+        const bool pairs = t0 + n <= a.samples && (reinterpret_cast<uintptr_t>(s0) & 7u) == 0;   // wave-uniform
+        if (pairs) {
+            const float2* const s2 = reinterpret_cast<const float2*>(s0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const float2 v = s2[64 * q + lane]; r[q] = (v2f){v.x, v.y}; }
+        } else {
+            const int left = (int)min((int64_t)n, a.samples - t0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = 64 * q + lane;
+                r[q] = (v2f){(2 * i < left) ? s0[2 * i] : 0.0f, (2 * i + 1 < left) ? s0[2 * i + 1] : 0.0f};
+            }
+        }
+    };
+    unsigned fr = blockIdx.x * kWave2Waves + wave;
+    if (fr < total) fetch(fr);   // the first frame's samples are in flight while the tables are built
+    for (int j = threadIdx.x; j < 1024; j += kWave2Threads) {   // W_1024^{256 a + b} = W_2048^{2 b} (-i)^a  (exact quarter turns of the committed table)
+        const float2 t = kWn[4 * (j & 255)];
+        v2f w = (v2f){t.x, t.y};
+        const int qa = j >> 8;
+        if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w; else if (qa == 3) w = mul_i(w);
+        tw[j] = w;
+        const float2 tap = win[j];
+        wl[j] = (v2f){tap.x, tap.y};
+    }
+    for (int k = threadIdx.x; k <= 512; k += kWave2Threads) { const float2 t = kWn[2 * k]; wn[k] = (v2f){t.x, t.y}; }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)n);
+    for (; fr < total; fr += stride) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            r[q] = r[q] * wl[64 * q + lane];
+            amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
+        }
+        // one range test per FRAME (NaN samples fail it and take the careful path); a scalar, so the two forms below are two branches
+        const bool plain = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;
+        fft1024_wave_ip<false>(r, zl, tw, lane);
+        if (fr + stride < total) fetch(fr + stride);   // the next frame's samples arrive while this one is unpacked
+        slot_sync<true>();
+        const unsigned b = fr / frames;
+        float* dst = a.mag + (int64_t)fr * nb;
+        float2* sp = (a.spec != nullptr && (int64_t)b >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * nb : nullptr;
+        if (plain) wave2_unpack_store<true>(zl, wn, lane, scale, dst, sp);
+        else wave2_unpack_store<false>(zl, wn, lane, scale, dst, sp);
         slot_sync<true>();   // the unpack reads are issued before the next frame's exchange writes
     }
 }
@@ -891,8 +1149,36 @@ static void launch_forward(int64_t work, hipStream_t st, const StftArgs& a)
 #endif
 // n_fft 2048: the one-wavefront-per-frame kernel, persistent grid (3 workgroups of 4 frames per CU fit the LDS); returns
 // false for other sizes (the caller launches the slot kernel)
+// Measured (round 4, tools/r4/stft_sizes.py, forward of a pair, n_fft 2048 / hop 256, us per call, slot kernel | this kernel;
+// profiles/r4j_stft_wave2.txt): 512 frames 10.6 | 15.0, 1024: 10.6 | 15.3, 2048: 14.4 | 16.1, 4096: 21.6 | 17.3, 8192 (config 5): 37.3 | 28.5,
+// 16384: 64.0 | 48.0 -- a frame is a 28 000-clock dependent chain on one wave (~15 us), so the kernel needs at least one frame per
+// wave slot of the chip (256 CUs x 16) to pay: from 3072 frames.
+#ifndef SOT_STFT_WAVE2_KERNEL
+#define SOT_STFT_WAVE2_KERNEL 1
+#endif
+#ifndef SOT_STFT_WAVE2_MIN_FRAMES
+#define SOT_STFT_WAVE2_MIN_FRAMES 3072
+#endif
+static bool launch_forward_wave2(const StftArgs& a, int64_t frames_total, hipStream_t st)
+{
+    if (!SOT_STFT_WAVE2_KERNEL || a.logm != 10 || frames_total < SOT_STFT_WAVE2_MIN_FRAMES) return false;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {   // idempotent per device; a benign race sets it twice
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_forward_wave2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWave2LdsBytes) != hipSuccess)
+            (void)hipGetLastError();
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int64_t want = (frames_total + kWave2Waves - 1) / kWave2Waves, cap = cu_count();   // one 1024-thread workgroup per CU
+    hipLaunchKernelGGL(stft_mag_forward_wave2_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(kWave2Threads), kWave2LdsBytes, st, a);
+    return true;
+}
+
 static bool launch_forward_wave(const StftArgs& a, int64_t frames_total, hipStream_t st)
 {
+    if (launch_forward_wave2(a, frames_total, st)) return true;
     if (!SOT_STFT_WAVE_KERNEL || a.logm != 10) return false;
     const size_t lds = (1024 + 520 + 4 * (size_t)kWaveBuf) * sizeof(float2);
     static bool attr_done[64] = {};
