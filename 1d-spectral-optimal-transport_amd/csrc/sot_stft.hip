@@ -944,6 +944,118 @@ __global__ __launch_bounds__(kThreads) void stft_mag_backward_partial_kernel(con
 template <int LOGM>
 __global__ __launch_bounds__(kThreads) void stft_mag_backward_spec_kernel(const StftArgs a) { backward_partial_body<LOGM, true>(a); }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the backward from the stored spectrum with ONE WAVEFRONT per frame group (n_fft 2048, hop a multiple of 128; the counterpart
+// of stft_mag_forward_wave2_kernel).  A wave takes the kFramesPerGroup = 2 consecutive frames of its group one after the other: spectrum
+// and upstream gradient of the lane's nine bin pairs (k, m - k) -> Zin -> Hermitian packing G (as backward_partial_body, with
+// 1 / |X| = rsq(re^2 + im^2) after one range test per frame instead of a careful |.| and an IEEE division per value) -> G to the wave's LDS
+// buffer in natural order -> the 16 points 64 q + lane into registers -> fft1024_wave_ip<true> -> windowed, scaled, and overlap-added IN
+// REGISTERS: the second frame starts QS = hop / 128 register slots behind the first (its packed point i sits at point i + hop / 2 of the
+// group's span), same lane.  The group's span leaves as 16 + QS coalesced 8-byte stores into the scratch buffer stft_overlap_add_kernel
+// reads (same layout as the slot kernel's).  512-thread workgroups: 8 frame groups in flight per CU (tables 20 KB + 8 x 8.7 KB of LDS).
+// ---------------------------------------------------------------------------------------------
+constexpr int kBwdWave2Threads = 512;
+constexpr int kBwdWave2Waves = kBwdWave2Threads / 64;
+constexpr size_t kBwdWave2LdsBytes = (1024 + 520 + 1024 + (size_t)kBwdWave2Waves * kWaveBuf) * sizeof(float2);
+
+template <int QS>
+__global__ __launch_bounds__(kBwdWave2Threads) void stft_mag_backward_spec_wave2_kernel(const StftArgs a)
+{
+    static_assert(kFramesPerGroup == 2, "two frames per wave: 16 + QS register slots");
+    constexpr int m = 1024, n = 2048, nb = m + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    v2f* const tw = reinterpret_cast<v2f*>(smem_f);          // W_1024^j, j < 1024
+    v2f* const wn = tw + 1024;                                // W_2048^k, k <= 512 (+ pad)
+    v2f* const wl = wn + 520;                                 // window taps (2 i, 2 i + 1), i < 1024
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    v2f* const zl = wl + 1024 + wave * kWaveBuf;
+    const float2* win = reinterpret_cast<const float2*>(a.window);
+    for (int j = threadIdx.x; j < 1024; j += kBwdWave2Threads) {
+        const float2 t = kWn[4 * (j & 255)];
+        v2f w = (v2f){t.x, t.y};
+        const int qa = j >> 8;
+        if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w; else if (qa == 3) w = mul_i(w);
+        tw[j] = w;
+        const float2 tap = win[j];
+        wl[j] = (v2f){tap.x, tap.y};
+    }
+    for (int k = threadIdx.x; k <= 512; k += kBwdWave2Threads) { const float2 t = kWn[2 * k]; wn[k] = (v2f){t.x, t.y}; }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)n);
+    const float up = a.grad_scale ? *a.grad_scale : 1.0f;
+    const unsigned total = (unsigned)(a.batch * a.groups), groups = (unsigned)a.groups;
+    for (unsigned w = blockIdx.x * kBwdWave2Waves + wave; w < total; w += gridDim.x * kBwdWave2Waves) {
+        const unsigned b = w / groups, grp = w - b * groups;
+        v2f acc[16 + QS];
+#pragma unroll
+        for (int q = 0; q < 16 + QS; ++q) acc[q] = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const int64_t f = (int64_t)grp * 2 + fi;
+            if (f < a.frames) {   // wave-uniform
+                const float* g = a.grad_mag + ((int64_t)b * a.frames + f) * nb;
+                const float2* sp = a.spec_in + ((int64_t)b * a.frames + f) * nb;
+                v2f xk[9], xm[9];
+                float gk_up[9], gm_up[9];
+                float peak = 0.0f, least = INFINITY;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int k = lane + 64 * j;
+                    const bool use = j < 8 || k <= m / 2;
+                    const float2 pk = use ? sp[k] : make_float2(0.0f, 0.0f), pm = use ? sp[m - k] : make_float2(0.0f, 0.0f);
+                    xk[j] = (v2f){pk.x, pk.y}; xm[j] = (v2f){pm.x, pm.y};
+                    gk_up[j] = use ? g[k] : 0.0f; gm_up[j] = use ? g[m - k] : 0.0f;
+                    const float ak = fmaxf(fabsf(pk.x), fabsf(pk.y)), am = fmaxf(fabsf(pm.x), fabsf(pm.y));
+                    peak = fmaxf(peak, fmaxf(ak, am));
+                    least = fminf(least, fminf(ak > 0.0f ? ak : INFINITY, am > 0.0f ? am : INFINITY));
+                }
+                // re^2 + im^2 of every non-zero bin is a normal number that cannot overflow: 1 / |X| = rsq(re^2 + im^2) (NaNs fail the test)
+                const float wpeak = wave_max_f32(peak), wleast = -wave_max_f32(-least);
+                const bool plain = __builtin_amdgcn_readfirstlane((int)(wpeak < 1e15f && wleast > 1e-18f)) != 0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int k = lane + 64 * j;
+                    if (j < 8 || k <= m / 2) {
+                        float ck, cm;
+                        if (plain) {
+                            const float sk2 = fmaf(xk[j].x, xk[j].x, xk[j].y * xk[j].y), sm2 = fmaf(xm[j].x, xm[j].x, xm[j].y * xm[j].y);
+                            ck = sk2 > 0.0f ? (gk_up[j] * up) * __builtin_amdgcn_rsqf(sk2) : 0.0f;      // torch: sgn(0) = 0
+                            cm = sm2 > 0.0f ? (gm_up[j] * up) * __builtin_amdgcn_rsqf(sm2) : 0.0f;
+                        } else {
+                            const float mk = magnitude(xk[j]), mm = magnitude(xm[j]);
+                            ck = mk > 0.0f ? (gk_up[j] * up) / mk : 0.0f;
+                            cm = mm > 0.0f ? (gm_up[j] * up) / mm : 0.0f;
+                        }
+                        v2f hk = (0.5f * ck) * xk[j], hm = (0.5f * cm) * xm[j];
+                        if (k == 0) { hk = (v2f){ck * xk[j].x, 0.0f}; hm = (v2f){cm * xm[j].x, 0.0f}; }   // H_0, H_m are real
+                        const v2f sk = hk + cconj(hm);      // H_k + conj(H_{m-k})
+                        const v2f dk = hk - cconj(hm);      // H_k - conj(H_{m-k})
+                        const v2f wk = wn[k];
+                        zl[k] = sk + mul_i(cmul(cconj(wk), dk));                                   // G_k = s + i conj(W) d
+                        if (k > 0 && k < m - k) zl[m - k] = cconj(sk) + mul_i(cmul(wk, cconj(dk)));   // G_{m-k} = conj(s) + i W conj(d)
+                    }
+                }
+                slot_sync<true>();
+                v2f r[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) r[q] = zl[64 * q + lane];
+                slot_sync<true>();   // every lane holds its points before the transform's exchanges reuse the buffer
+                fft1024_wave_ip<true>(r, zl, tw, lane);
+                slot_sync<true>();
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const v2f v = zl[zi(64 * q + lane)], tap = wl[64 * q + lane];
+                    acc[q + QS * fi] += (v2f){tap.x * v.x * scale, tap.y * v.y * scale};
+                }
+                slot_sync<true>();   // the reads are issued before the next frame writes its G
+            }
+        }
+        float2* dst = reinterpret_cast<float2*>(a.partial + (int64_t)w * a.span);
+#pragma unroll
+        for (int q = 0; q < 16 + QS; ++q) dst[64 * q + lane] = make_float2(acc[q].x, acc[q].y);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftArgs a)
 {
     // clips over blockIdx.y; 32-bit arithmetic inside a clip (samples < 2^31 is checked by the host)
@@ -1176,6 +1288,33 @@ static bool launch_forward_wave2(const StftArgs& a, int64_t frames_total, hipStr
     return true;
 }
 
+#ifndef SOT_STFT_BWD_WAVE2_KERNEL
+#define SOT_STFT_BWD_WAVE2_KERNEL 1
+#endif
+#ifndef SOT_STFT_BWD_WAVE2_MIN_GROUPS
+#define SOT_STFT_BWD_WAVE2_MIN_GROUPS 1024
+#endif
+// the backward from the stored spectrum, one wavefront per group of two frames: n_fft 2048, hop 256 or 512, scratch rows on 8-byte boundaries
+static bool launch_backward_spec_wave2(const StftArgs& a, int64_t groups_total, hipStream_t st)
+{
+    if (!SOT_STFT_BWD_WAVE2_KERNEL || a.logm != 10 || groups_total < SOT_STFT_BWD_WAVE2_MIN_GROUPS || (a.hop != 256 && a.hop != 512) ||
+        (reinterpret_cast<uintptr_t>(a.partial) & 7u) != 0 || (a.span & 1) != 0)
+        return false;
+    void (*kern)(const StftArgs) = a.hop == 256 ? stft_mag_backward_spec_wave2_kernel<2> : stft_mag_backward_spec_wave2_kernel<4>;
+    static bool attr_done[64][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const int which = a.hop == 256 ? 0 : 1;
+    if (dev < 0 || dev >= 64 || !attr_done[dev][which]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdWave2LdsBytes) != hipSuccess)
+            (void)hipGetLastError();
+        if (dev >= 0 && dev < 64) attr_done[dev][which] = true;
+    }
+    const int64_t want = (groups_total + kBwdWave2Waves - 1) / kBwdWave2Waves, cap = cu_count();   // one 512-thread workgroup per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)(want < cap ? want : cap)), dim3(kBwdWave2Threads), kBwdWave2LdsBytes, st, a);
+    return true;
+}
+
 static bool launch_forward_wave(const StftArgs& a, int64_t frames_total, hipStream_t st)
 {
     if (launch_forward_wave2(a, frames_total, st)) return true;
@@ -1293,7 +1432,8 @@ int sot_stft_mag_backward_spec(const float* audio, const float* spec, int64_t ba
     a.span = (int)span;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    if (spec != nullptr) SOT_STFT_LAUNCH(stft_mag_backward_spec_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
+    if (spec != nullptr && launch_backward_spec_wave2(a, batch * a.groups, st)) { /* one wavefront per frame group */ }
+    else if (spec != nullptr) SOT_STFT_LAUNCH(stft_mag_backward_spec_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     else SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
     const int64_t per_clip = (samples + kThreads - 1) / kThreads;

@@ -571,3 +571,51 @@ def test_eval_metric_wasserstein_distance_gpu_matches_cpu():
         got = spectra.wasserstein_distance(x.to(dev), xh.to(dev), p=p, n_fft=n_fft)
         want = spectra.wasserstein_distance(x, xh, p=p, n_fft=n_fft)
         assert got.is_cuda and abs(float(got) - float(want)) <= 1e-5 * abs(float(want)), (p, n_fft, float(got), float(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,clips", [(256, 256), (512, 400)])
+def test_one_wave_per_frame_kernels_of_large_batches(hop, clips):
+    """Round 4: from 3072 frames of n_fft 2048 the forward runs with one wavefront per frame (stft_mag_forward_wave2_kernel), from 1024
+    frame groups the backward from the stored spectrum with one wavefront per group of two frames (stft_mag_backward_spec_wave2_kernel).
+    Both are other factorisations of the same transform than the slot kernels (which small batches keep): magnitudes and spectra agree
+    with the slot kernels' (the same clips in small batches) and with torch.stft to a few ulp of the spectrum's peak, the gradient with
+    the recomputing slot kernel's to 2e-5 of its peak -- also with an upstream scalar, accumulation, and on clips whose last frames
+    are end-padded."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    nat = native()
+    dev = device()
+    n_fft, samples = 2048, 4096 + 77                  # the tail frames run into the end padding
+    g = torch.Generator(device=dev).manual_seed(hop + clips)
+    a = torch.rand(clips, samples, device=dev, generator=g) - 0.5
+    a[3] = 0.0                                        # an all-zero clip: every bin exactly 0, gradient 0 (torch's sgn(0))
+    a[5] *= 1e-21                                     # a clip below the plain range: the careful |.| path
+    win = spectra._cached_window("flattop", n_fft, dev)
+    frames = -(-samples // hop)
+    assert clips * frames >= 3072 and clips * ((frames + 1) // 2) >= 1024
+    mag, spec = nat.stft_mag_forward(a, win, n_fft, hop, want_spec=True)
+    small = [nat.stft_mag_forward(a[i:i + 8], win, n_fft, hop, want_spec=True) for i in range(0, clips, 8)]   # 8 clips: the slot kernel
+    mag_s, spec_s = torch.cat([m for m, _ in small]), torch.cat([s_ for _, s_ in small])
+    peak = float(mag_s.max())
+    assert float((mag - mag_s).abs().max()) <= 1e-6 * peak
+    assert float((spec - spec_s).abs().max()) <= 1e-6 * float(spec_s.abs().max())
+    assert float(mag[3].abs().max()) == 0.0
+    rel5 = float((mag[5] - mag_s[5]).abs().max() / mag_s[5].max())
+    assert rel5 <= 1e-5, rel5
+    ref = torch.stft(spectra.end_padded(a, n_fft, hop), n_fft=n_fft, hop_length=hop, win_length=n_fft, window=win, center=False,
+                     normalized=True, return_complex=True).abs().permute(0, 2, 1)
+    assert float((mag - ref).abs().max()) <= 2e-6 * peak
+    gm = torch.rand(mag.shape, device=dev, generator=g)
+    want = nat.stft_mag_backward(a, win, n_fft, hop, gm)                        # recomputing slot kernel
+    got = nat.stft_mag_backward(a, win, n_fft, hop, gm, spec=spec)              # one wave per frame group
+    gpeak = float(want.abs().max())
+    err = float((got - want).abs().max()) / gpeak
+    print(f"one-wave backward vs recomputing slot kernel, hop {hop}: max difference {err:.2e} of the gradient's peak")
+    assert err <= 2e-5, err    # (two factorisations of the transform: the phase X / |X| of bins near the noise floor amplifies last-bit differences)
+    assert float(got[3].abs().max()) == 0.0
+    up = torch.full((1,), 0.37, device=dev)
+    base = torch.rand(clips, samples, device=dev, generator=g)
+    want2 = nat.stft_mag_backward(a, win, n_fft, hop, gm, grad_scale=up, accumulate_into=base.clone())
+    got2 = nat.stft_mag_backward(a, win, n_fft, hop, gm, grad_scale=up, accumulate_into=base.clone(), spec=spec)
+    assert float((got2 - want2).abs().max()) <= 2e-5 * max(gpeak, 1.0)
