@@ -621,6 +621,9 @@ __global__ __launch_bounds__(kThreads) void stft_mag_forward_wave_kernel(const S
 //    scalar path covers the rest).
 // No workgroup barrier inside the frame loop: a wave's exchanges through its private LDS buffer need only wave-level ordering.
 // ---------------------------------------------------------------------------------------------
+#ifndef SOT_STFT_XCHG_SWZ
+#define SOT_STFT_XCHG_SWZ 1
+#endif
 template <bool INVERSE>
 __device__ __forceinline__ v2f ctw(v2f a, v2f w) { return INVERSE ? cmul_conj(a, w) : cmul(a, w); }   // a * twiddle (inverse: conjugate twiddle)
 
@@ -655,15 +658,19 @@ __device__ __forceinline__ void fft1024_wave_ip(v2f (&r)[16], v2f* zl, const v2f
             r[4 * q4 + 1] = ctw<INVERSE>(r[4 * q4 + 1], w1); r[4 * q4 + 2] = ctw<INVERSE>(r[4 * q4 + 2], w2); r[4 * q4 + 3] = ctw<INVERSE>(r[4 * q4 + 3], w3);
         }
     }
-    // exchange 1: register (q4, q3) of lane (d2, d1, d0) -> register (d2, d1) of lane (q4, q3, d0)
+    // exchange 1: register (q4, q3) of lane (d2, d1, d0) -> register (d2, d1) of lane (q4, q3, d0): logical element (column 4 q + d0, row rr)
+    // written by lane (rr, d0), row q of column L read by lane L.  Storage [column ^ g(row)][17]: the reader's lanes still sweep 64 different
+    // columns per instruction (conflict-free as before), the writer's 16-lane groups no longer pile four lanes on one bank pair
+    // (SQ_LDS_BANK_CONFLICT was 49 % of the kernel's LDS cycles, all of it these stores): g(row) = 4 (row & 3) here (two-way left),
+    // g(row) = row >> 2 in exchange 2 (conflict-free).  SOT_STFT_XCHG_SWZ=0: the plain [column][17] image.
     const int d0 = lane & 3;
     {
         const int rr = lane >> 2;   // 4 d2 + d1
 #pragma unroll
-        for (int q = 0; q < 16; ++q) zl[(4 * q + d0) * 17 + rr] = r[q];
+        for (int q = 0; q < 16; ++q) zl[((4 * q + d0) ^ (SOT_STFT_XCHG_SWZ ? 4 * (rr & 3) : 0)) * 17 + rr] = r[q];
         slot_sync<true>();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) r[q] = zl[lane * 17 + q];
+        for (int q = 0; q < 16; ++q) r[q] = zl[(lane ^ (SOT_STFT_XCHG_SWZ ? 4 * (q & 3) : 0)) * 17 + q];
         slot_sync<true>();
     }
     // stage 3 (digit d2; registers 4 p + d1 -> 4 q + d1): twiddle W_64^{(4 d1 + d0) q} = W_1024^{16 (4 d1 + d0) q}
@@ -687,10 +694,10 @@ __device__ __forceinline__ void fft1024_wave_ip(v2f (&r)[16], v2f* zl, const v2f
     {
         const int hi = lane >> 2;   // 4 q4 + q3
 #pragma unroll
-        for (int q = 0; q < 16; ++q) zl[(4 * hi + (q >> 2)) * 17 + 4 * d0 + (q & 3)] = r[q];
+        for (int q = 0; q < 16; ++q) zl[((4 * hi + (q >> 2)) ^ (SOT_STFT_XCHG_SWZ ? d0 : 0)) * 17 + 4 * d0 + (q & 3)] = r[q];   // row 4 d0 + (q & 3): g = d0
         slot_sync<true>();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) r[q] = zl[lane * 17 + q];
+        for (int q = 0; q < 16; ++q) r[q] = zl[(lane ^ (SOT_STFT_XCHG_SWZ ? (q >> 2) : 0)) * 17 + q];
         slot_sync<true>();
     }
     // stage 5 (digit d0; registers 4 p + q1 -> 4 q0 + q1), no twiddle; result (q4 q3 q2 q1 q0) is frequency k = q4 + 4 q3 + 16 q2 + 64 q1 + 256 q0
@@ -780,22 +787,26 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_forward_wave2_kernel(c
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)n);
     for (; fr < total; fr += stride) {
+        // the lane number as an opaque value per frame: hipcc otherwise hoists every lane-derived LDS address out of this (two-trip) loop
+        // and pays for the ~40 live registers with spills (23 dwords at the 128-register budget of a 1024-thread workgroup)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         float amax = 0.0f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            r[q] = r[q] * wl[64 * q + lane];
+            r[q] = r[q] * wl[64 * q + ln];
             amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
         }
         // one range test per FRAME (NaN samples fail it and take the careful path); a scalar, so the two forms below are two branches
         const bool plain = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;
-        fft1024_wave_ip<false>(r, zl, tw, lane);
+        fft1024_wave_ip<false>(r, zl, tw, ln);
         if (fr + stride < total) fetch(fr + stride);   // the next frame's samples arrive while this one is unpacked
         slot_sync<true>();
         const unsigned b = fr / frames;
         float* dst = a.mag + (int64_t)fr * nb;
         float2* sp = (a.spec != nullptr && (int64_t)b >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * nb : nullptr;
-        if (plain) wave2_unpack_store<true>(zl, wn, lane, scale, dst, sp);
-        else wave2_unpack_store<false>(zl, wn, lane, scale, dst, sp);
+        if (plain) wave2_unpack_store<true>(zl, wn, ln, scale, dst, sp);
+        else wave2_unpack_store<false>(zl, wn, ln, scale, dst, sp);
         slot_sync<true>();   // the unpack reads are issued before the next frame's exchange writes
     }
 }
