@@ -969,19 +969,12 @@ constexpr int kBwdWave2Threads = 512;
 constexpr int kBwdWave2Waves = kBwdWave2Threads / 64;
 constexpr size_t kBwdWave2LdsBytes = (1024 + 520 + 1024 + (size_t)kBwdWave2Waves * kWaveBuf) * sizeof(float2);
 
-template <int QS>
-__global__ __launch_bounds__(kBwdWave2Threads) void stft_mag_backward_spec_wave2_kernel(const StftArgs a)
+// tables of the one-wave kernels: W_1024^j, W_2048^k (k <= 512), the window as tap pairs; all threads of the workgroup, then a barrier
+template <int THREADS>
+__device__ __forceinline__ void wave2_load_tables(const StftArgs& a, v2f* tw, v2f* wn, v2f* wl)
 {
-    static_assert(kFramesPerGroup == 2, "two frames per wave: 16 + QS register slots");
-    constexpr int m = 1024, n = 2048, nb = m + 1;
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    v2f* const tw = reinterpret_cast<v2f*>(smem_f);          // W_1024^j, j < 1024
-    v2f* const wn = tw + 1024;                                // W_2048^k, k <= 512 (+ pad)
-    v2f* const wl = wn + 520;                                 // window taps (2 i, 2 i + 1), i < 1024
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    v2f* const zl = wl + 1024 + wave * kWaveBuf;
     const float2* win = reinterpret_cast<const float2*>(a.window);
-    for (int j = threadIdx.x; j < 1024; j += kBwdWave2Threads) {
+    for (int j = threadIdx.x; j < 1024; j += THREADS) {   // W_1024^{256 a + b} = W_2048^{2 b} (-i)^a  (exact quarter turns of the committed table)
         const float2 t = kWn[4 * (j & 255)];
         v2f w = (v2f){t.x, t.y};
         const int qa = j >> 8;
@@ -990,8 +983,93 @@ __global__ __launch_bounds__(kBwdWave2Threads) void stft_mag_backward_spec_wave2
         const float2 tap = win[j];
         wl[j] = (v2f){tap.x, tap.y};
     }
-    for (int k = threadIdx.x; k <= 512; k += kBwdWave2Threads) { const float2 t = kWn[2 * k]; wn[k] = (v2f){t.x, t.y}; }
+    for (int k = threadIdx.x; k <= 512; k += THREADS) { const float2 t = kWn[2 * k]; wn[k] = (v2f){t.x, t.y}; }
     __syncthreads();
+}
+
+// The Hermitian packing G of one frame's Zin_k = g_k X_k / |X_k| into the wave's LDS buffer (natural order), pair by pair -- nothing is held
+// across pairs.  PLAIN: 1 / |X| = rsq(re^2 + im^2); the pass also returns the frame's largest and smallest non-zero component magnitude,
+// from which the caller decides whether PLAIN was legitimate (and repeats the pass in the careful form if not: rare).
+template <bool PLAIN>
+__device__ __forceinline__ void wave2_pack_gradient(const float2* __restrict__ sp, const float* __restrict__ g, float up, v2f* zl, const v2f* wn,
+                                                    int lane, float& peak, float& least)
+{
+    constexpr int m = 1024;
+    peak = 0.0f; least = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int k = lane + 64 * j;
+        if (j < 8 || k <= m / 2) {
+            const float2 pk = sp[k], pm = sp[m - k];
+            const v2f xk = (v2f){pk.x, pk.y}, xm = (v2f){pm.x, pm.y};
+            const float gk_up = g[k], gm_up = g[m - k];
+            float ck, cm;
+            if (PLAIN) {
+                const float ak = fmaxf(fabsf(pk.x), fabsf(pk.y)), am = fmaxf(fabsf(pm.x), fabsf(pm.y));
+                peak = fmaxf(peak, fmaxf(ak, am));
+                least = fminf(least, fminf(ak > 0.0f ? ak : INFINITY, am > 0.0f ? am : INFINITY));
+                const float sk2 = fmaf(xk.x, xk.x, xk.y * xk.y), sm2 = fmaf(xm.x, xm.x, xm.y * xm.y);
+                ck = sk2 > 0.0f ? (gk_up * up) * __builtin_amdgcn_rsqf(sk2) : 0.0f;      // torch: sgn(0) = 0
+                cm = sm2 > 0.0f ? (gm_up * up) * __builtin_amdgcn_rsqf(sm2) : 0.0f;
+            } else {
+                const float mk = magnitude(xk), mm = magnitude(xm);
+                ck = mk > 0.0f ? (gk_up * up) / mk : 0.0f;
+                cm = mm > 0.0f ? (gm_up * up) / mm : 0.0f;
+            }
+            v2f hk = (0.5f * ck) * xk, hm = (0.5f * cm) * xm;
+            if (k == 0) { hk = (v2f){ck * xk.x, 0.0f}; hm = (v2f){cm * xm.x, 0.0f}; }   // H_0, H_m are real
+            const v2f sk = hk + cconj(hm);      // H_k + conj(H_{m-k})
+            const v2f dk = hk - cconj(hm);      // H_k - conj(H_{m-k})
+            const v2f wk = wn[k];
+            zl[k] = sk + mul_i(cmul(cconj(wk), dk));                                   // G_k = s + i conj(W) d
+            if (k > 0 && k < m - k) zl[m - k] = cconj(sk) + mul_i(cmul(wk, cconj(dk)));   // G_{m-k} = conj(s) + i W conj(d)
+        }
+    }
+}
+
+// One frame of the backward from the stored spectrum on one wavefront: out[q] = tap * (inverse transform of the Hermitian packing of
+// Zin_k = g_k X_k / |X_k|) * scale at the packed points 64 q + lane, i.e. the frame's windowed audio gradient (samples 2 i, 2 i + 1).
+// sp / g: the frame's spectrum and upstream gradient rows.  Ends with a wave-level ordering point (zl may be reused).
+__device__ __forceinline__ void wave2_frame_gradient(const float2* __restrict__ sp, const float* __restrict__ g, float up, float scale, v2f* zl,
+                                                     const v2f* tw, const v2f* wn, const v2f* wl, int lane_in, v2f (&out)[16])
+{
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));   // lane-derived LDS addresses are recomputed per frame instead of living in registers across frames
+    float peak, least;
+    wave2_pack_gradient<true>(sp, g, up, zl, wn, lane, peak, least);
+    // re^2 + im^2 of every non-zero bin must be a normal number that cannot overflow (NaNs fail the test): else the careful form
+    const float wpeak = wave_max_f32(peak), wleast = -wave_max_f32(-least);
+    if (__builtin_amdgcn_readfirstlane((int)(wpeak < 1e15f && wleast > 1e-18f)) == 0) {
+        slot_sync<true>();
+        wave2_pack_gradient<false>(sp, g, up, zl, wn, lane, peak, least);
+    }
+    slot_sync<true>();
+    v2f r[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r[q] = zl[64 * q + lane];
+    slot_sync<true>();   // every lane holds its points before the transform's exchanges reuse the buffer
+    fft1024_wave_ip<true>(r, zl, tw, lane);
+    slot_sync<true>();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const v2f v = zl[zi(64 * q + lane)], tap = wl[64 * q + lane];
+        out[q] = (v2f){tap.x * v.x * scale, tap.y * v.y * scale};
+    }
+    slot_sync<true>();   // the reads are issued before the buffer is written again
+}
+
+template <int QS>
+__global__ __launch_bounds__(kBwdWave2Threads) void stft_mag_backward_spec_wave2_kernel(const StftArgs a)
+{
+    static_assert(kFramesPerGroup == 2, "two frames per wave: 16 + QS register slots");
+    constexpr int n = 2048, nb = 1025;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    v2f* const tw = reinterpret_cast<v2f*>(smem_f);          // W_1024^j, j < 1024
+    v2f* const wn = tw + 1024;                                // W_2048^k, k <= 512 (+ pad)
+    v2f* const wl = wn + 520;                                 // window taps (2 i, 2 i + 1), i < 1024
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    v2f* const zl = wl + 1024 + wave * kWaveBuf;
+    wave2_load_tables<kBwdWave2Threads>(a, tw, wn, wl);
     const float scale = 1.0f / sqrtf((float)n);
     const float up = a.grad_scale ? *a.grad_scale : 1.0f;
     const unsigned total = (unsigned)(a.batch * a.groups), groups = (unsigned)a.groups;
@@ -1004,66 +1082,70 @@ __global__ __launch_bounds__(kBwdWave2Threads) void stft_mag_backward_spec_wave2
         for (int fi = 0; fi < 2; ++fi) {
             const int64_t f = (int64_t)grp * 2 + fi;
             if (f < a.frames) {   // wave-uniform
-                const float* g = a.grad_mag + ((int64_t)b * a.frames + f) * nb;
-                const float2* sp = a.spec_in + ((int64_t)b * a.frames + f) * nb;
-                v2f xk[9], xm[9];
-                float gk_up[9], gm_up[9];
-                float peak = 0.0f, least = INFINITY;
+                v2f out[16];
+                wave2_frame_gradient(a.spec_in + ((int64_t)b * a.frames + f) * nb, a.grad_mag + ((int64_t)b * a.frames + f) * nb, up, scale, zl, tw, wn,
+                                     wl, lane, out);
 #pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const int k = lane + 64 * j;
-                    const bool use = j < 8 || k <= m / 2;
-                    const float2 pk = use ? sp[k] : make_float2(0.0f, 0.0f), pm = use ? sp[m - k] : make_float2(0.0f, 0.0f);
-                    xk[j] = (v2f){pk.x, pk.y}; xm[j] = (v2f){pm.x, pm.y};
-                    gk_up[j] = use ? g[k] : 0.0f; gm_up[j] = use ? g[m - k] : 0.0f;
-                    const float ak = fmaxf(fabsf(pk.x), fabsf(pk.y)), am = fmaxf(fabsf(pm.x), fabsf(pm.y));
-                    peak = fmaxf(peak, fmaxf(ak, am));
-                    least = fminf(least, fminf(ak > 0.0f ? ak : INFINITY, am > 0.0f ? am : INFINITY));
-                }
-                // re^2 + im^2 of every non-zero bin is a normal number that cannot overflow: 1 / |X| = rsq(re^2 + im^2) (NaNs fail the test)
-                const float wpeak = wave_max_f32(peak), wleast = -wave_max_f32(-least);
-                const bool plain = __builtin_amdgcn_readfirstlane((int)(wpeak < 1e15f && wleast > 1e-18f)) != 0;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const int k = lane + 64 * j;
-                    if (j < 8 || k <= m / 2) {
-                        float ck, cm;
-                        if (plain) {
-                            const float sk2 = fmaf(xk[j].x, xk[j].x, xk[j].y * xk[j].y), sm2 = fmaf(xm[j].x, xm[j].x, xm[j].y * xm[j].y);
-                            ck = sk2 > 0.0f ? (gk_up[j] * up) * __builtin_amdgcn_rsqf(sk2) : 0.0f;      // torch: sgn(0) = 0
-                            cm = sm2 > 0.0f ? (gm_up[j] * up) * __builtin_amdgcn_rsqf(sm2) : 0.0f;
-                        } else {
-                            const float mk = magnitude(xk[j]), mm = magnitude(xm[j]);
-                            ck = mk > 0.0f ? (gk_up[j] * up) / mk : 0.0f;
-                            cm = mm > 0.0f ? (gm_up[j] * up) / mm : 0.0f;
-                        }
-                        v2f hk = (0.5f * ck) * xk[j], hm = (0.5f * cm) * xm[j];
-                        if (k == 0) { hk = (v2f){ck * xk[j].x, 0.0f}; hm = (v2f){cm * xm[j].x, 0.0f}; }   // H_0, H_m are real
-                        const v2f sk = hk + cconj(hm);      // H_k + conj(H_{m-k})
-                        const v2f dk = hk - cconj(hm);      // H_k - conj(H_{m-k})
-                        const v2f wk = wn[k];
-                        zl[k] = sk + mul_i(cmul(cconj(wk), dk));                                   // G_k = s + i conj(W) d
-                        if (k > 0 && k < m - k) zl[m - k] = cconj(sk) + mul_i(cmul(wk, cconj(dk)));   // G_{m-k} = conj(s) + i W conj(d)
-                    }
-                }
-                slot_sync<true>();
-                v2f r[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) r[q] = zl[64 * q + lane];
-                slot_sync<true>();   // every lane holds its points before the transform's exchanges reuse the buffer
-                fft1024_wave_ip<true>(r, zl, tw, lane);
-                slot_sync<true>();
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const v2f v = zl[zi(64 * q + lane)], tap = wl[64 * q + lane];
-                    acc[q + QS * fi] += (v2f){tap.x * v.x * scale, tap.y * v.y * scale};
-                }
-                slot_sync<true>();   // the reads are issued before the next frame writes its G
+                for (int q = 0; q < 16; ++q) acc[q + QS * fi] += out[q];
             }
         }
         float2* dst = reinterpret_cast<float2*>(a.partial + (int64_t)w * a.span);
 #pragma unroll
         for (int q = 0; q < 16 + QS; ++q) dst[64 * q + lane] = make_float2(acc[q].x, acc[q].y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same with the overlap-add INSIDE the kernel, for clips of at most 16 frames (config 5 and the paper's step: 4096 samples, hop 256):
+// one 1024-thread workgroup per clip, wave f transforms frame f and leaves the windowed frame gradient in its own LDS buffer; after ONE
+// workgroup barrier every thread adds, for its two packed points of the clip, the frames that cover them in ascending frame order
+// (deterministic) and stores the clip's gradient: no scratch buffer, no second kernel (stft_overlap_add_kernel: 7 us at 256 clips).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clip_kernel(const StftArgs a)
+{
+    constexpr int n = 2048, nb = 1025, m = 1024;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    v2f* const tw = reinterpret_cast<v2f*>(smem_f);
+    v2f* const wn = tw + 1024;
+    v2f* const wl = wn + 520;
+    v2f* const bufs = wl + 1024;                              // 16 frame buffers of kWaveBuf points
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    v2f* const zl = bufs + wave * kWaveBuf;
+    wave2_load_tables<kWave2Threads>(a, tw, wn, wl);
+    const float scale = 1.0f / sqrtf((float)n);
+    const float up = a.grad_scale ? *a.grad_scale : 1.0f;
+    const int frames = (int)a.frames, hp = a.hop >> 1;        // hop in packed points (hop is even: host)
+    const int samples = (int)a.samples;
+    for (int64_t b = blockIdx.x; b < a.batch; b += gridDim.x) {
+        if (wave < frames) {
+            v2f out[16];
+            wave2_frame_gradient(a.spec_in + (b * a.frames + wave) * nb, a.grad_mag + (b * a.frames + wave) * nb, up, scale, zl, tw, wn, wl, lane, out);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zl[zi(64 * q + lane)] = out[q];
+        }
+        __syncthreads();
+        float* const dst = a.grad_audio + b * a.samples;
+        for (int p = threadIdx.x; 2 * p < samples; p += kWave2Threads) {   // packed point p of the clip = samples 2 p, 2 p + 1
+            const int f_hi = min(p / hp, frames - 1);
+            int f_lo = (p - (m - 1) + hp - 1) / hp;
+            if (p - (m - 1) <= 0) f_lo = 0;
+            v2f sum = (v2f){0.0f, 0.0f};
+            for (int f = f_lo; f <= f_hi; ++f) sum += bufs[f * kWaveBuf + zi(p - f * hp)];
+            if (2 * p + 1 < samples) {
+                float2* d2 = reinterpret_cast<float2*>(dst + 2 * p);
+                if ((reinterpret_cast<uintptr_t>(d2) & 7u) == 0) {
+                    float2 o = make_float2(sum.x, sum.y);
+                    if (a.accumulate) { const float2 old = *d2; o.x += old.x; o.y += old.y; }
+                    *d2 = o;
+                } else {
+                    dst[2 * p] = a.accumulate ? dst[2 * p] + sum.x : sum.x;
+                    dst[2 * p + 1] = a.accumulate ? dst[2 * p + 1] + sum.y : sum.y;
+                }
+            } else {
+                dst[2 * p] = a.accumulate ? dst[2 * p] + sum.x : sum.x;
+            }
+        }
+        __syncthreads();   // the frame buffers are read before the next clip overwrites them
     }
 }
 
@@ -1305,6 +1387,33 @@ static bool launch_forward_wave2(const StftArgs& a, int64_t frames_total, hipStr
 #ifndef SOT_STFT_BWD_WAVE2_MIN_GROUPS
 #define SOT_STFT_BWD_WAVE2_MIN_GROUPS 1024
 #endif
+#ifndef SOT_STFT_BWD_CLIP_KERNEL
+#define SOT_STFT_BWD_CLIP_KERNEL 1
+#endif
+#ifndef SOT_STFT_BWD_CLIP_MIN_CLIPS
+#define SOT_STFT_BWD_CLIP_MIN_CLIPS 64
+#endif
+// the backward from the stored spectrum with the overlap-add inside: clips of at most 16 frames of 2048, one workgroup per clip.  Returns true
+// when it has launched the WHOLE backward (the caller then skips stft_overlap_add_kernel).
+static bool launch_backward_spec_clip(const StftArgs& a, hipStream_t st)
+{
+    if (!SOT_STFT_BWD_CLIP_KERNEL || a.logm != 10 || a.spec_in == nullptr || a.frames > kWave2Waves || a.frames < 1 || (a.hop & 1) != 0 ||
+        a.batch < SOT_STFT_BWD_CLIP_MIN_CLIPS)
+        return false;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_spec_clip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWave2LdsBytes) != hipSuccess)
+            (void)hipGetLastError();
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int64_t cap = cu_count();
+    hipLaunchKernelGGL(stft_mag_backward_spec_clip_kernel, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(kWave2Threads), kWave2LdsBytes, st, a);
+    return true;
+}
+
 // the backward from the stored spectrum, one wavefront per group of two frames: n_fft 2048, hop 256 or 512, scratch rows on 8-byte boundaries
 static bool launch_backward_spec_wave2(const StftArgs& a, int64_t groups_total, hipStream_t st)
 {
@@ -1443,6 +1552,7 @@ int sot_stft_mag_backward_spec(const float* audio, const float* spec, int64_t ba
     a.span = (int)span;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
+    if (spec != nullptr && launch_backward_spec_clip(a, st)) return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;   // overlap-add inside
     if (spec != nullptr && launch_backward_spec_wave2(a, batch * a.groups, st)) { /* one wavefront per frame group */ }
     else if (spec != nullptr) SOT_STFT_LAUNCH(stft_mag_backward_spec_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
     else SOT_STFT_LAUNCH(stft_mag_backward_partial_kernel, batch * a.groups, sizeof(float) * (size_t)span, st, a);
