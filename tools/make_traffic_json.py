@@ -24,7 +24,7 @@ def mean_counter(sub, counter, kernel_substr):
 fetch_kib, nf = mean_counter("pmc_fetch", "FETCH_SIZE", KERNEL)
 write_kib, nw = mean_counter("pmc_write", "WRITE_SIZE", KERNEL)
 rec = {"workload": workload, "kernel": KERNEL, "fetch_size_kib_raw": fetch_kib, "write_size_kib": write_kib,
-       "dispatches": [nf, nw], "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B on 16-B/lane streams)",
+       "dispatches": [nf, nw], "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B on wide coalesced streams; round 4 fetches whole 128-B lines with dword loads: the raw counter again reads half of the bytes the kernel provably loads)",
        "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), {os.path.basename(prof_dir)}"}
 json.dump(rec, open(out, "w"), indent=1)
