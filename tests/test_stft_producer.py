@@ -86,7 +86,10 @@ def test_hip_stft_backward_matches_reference_autograd(tag):
     ones = torch.ones(audio.shape[0], frames, n_fft // 2 + 1, device=device())
     got = nat.stft_mag_backward(audio, win, n_fft, hop, ones).cpu().numpy()
     want = fx[f"{tag}_grad_sum_mag"]
-    assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max()   # noise-floor bins, see the docstring (observed up to 4e-3)
+    # Loose ON PURPOSE against the reference's FLOAT32 fixture: both sides carry the float32 error of X / |X| at noise-floor bins (observed up
+    # to 4e-3).  The sharp statement is test_hip_gradients_are_as_close_to_float64_as_the_reference_float32 below: against the reference
+    # evaluated in float64 the HIP gradient's error is <= 1.5 x the reference's own float32 error (this chain: 5.8e-4 | 6.5e-4 of the peak).
+    assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max()
     g = torch.Generator(device=device()).manual_seed(5)
     up = torch.randn(audio.shape[0], frames, n_fft // 2 + 1, device=device(), generator=g)
     up = up * spectra.stft_magnitude_torch(audio, n_fft, hop)   # weights vanish where the phase is noise
@@ -261,6 +264,9 @@ def test_mssloss_hip_matches_reference(tag):
     want, gwant = float(fx[f"mss_{tag}_loss"]), fx[f"mss_{tag}_grad_y"]
     assert abs(float(val) - want) <= 1e-5 * abs(want)
     got = ay.grad.cpu().numpy()
+    # (5e-3 / 6e-2 are the reference's OWN float32 errors on these ill-conditioned gradients -- sign() kinks, 1 / v of the log-magnitude
+    # term -- not slack of the kernels: against float64 the HIP result is held to 1.5 x the reference's float32 error by
+    # test_hip_gradients_are_as_close_to_float64_as_the_reference_float32 (observed 2.5e-3 | 2.5e-3, with log-magnitude 3.4e-2 | 4.7e-2))
     if MSS_CASES[tag]["logmag_weight"] == 0:
         assert np.abs(got - gwant).max() <= 5e-3 * np.abs(gwant).max()
     else:
