@@ -24,7 +24,13 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True):
         hop = max(1, hop)
         samples = int(rng.choice([1, hop, n_fft - 1, n_fft, n_fft + 1, int(rng.integers(1, 6 * n_fft + 2)), int(rng.integers(1, 20000))]))
         batch = int(rng.integers(1, 9))
-        if not spectra.hip_stft_supported(n_fft, hop, samples) or batch * (-(-samples // hop)) * n_fft > 6_000_000:
+        large = rng.random() < 0.15   # round 4: batches big enough for the one-wave-per-frame kernels of n_fft 2048 (forward >= 3072 frames,
+        if large:                     # backward >= 1024 frame groups or >= 64 clips of <= 16 frames)
+            n_fft = 2048
+            hop = int(rng.choice([256, 512, 128, 300, 1024]))
+            samples = int(rng.choice([4096, 4001, 3000, int(rng.integers(2048, 6000))]))
+            batch = int(rng.integers(64, 321))
+        if not spectra.hip_stft_supported(n_fft, hop, samples) or (not large and batch * (-(-samples // hop)) * n_fft > 6_000_000):
             continue
         window = str(rng.choice(["flattop", "hann", "blackman"]))
         seed = int(rng.integers(0, 2 ** 31 - 1))
@@ -36,7 +42,7 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True):
             audio = torch.sin(2 * np.pi * 440.0 * t)[None].repeat(batch, 1) + 0.01 * audio
         elif kind == "sparse":
             audio = audio * (torch.rand(batch, samples, device=dev, generator=g) < 0.05)
-        desc = dict(seed=seed, n_fft=n_fft, hop=hop, samples=samples, batch=batch, window=window, kind=kind)
+        desc = dict(seed=seed, n_fft=n_fft, hop=hop, samples=samples, batch=batch, window=window, kind=kind, large=bool(large))
         a1 = audio.clone().requires_grad_(True)
         a2 = audio.clone().requires_grad_(True)
         a3 = audio.clone().requires_grad_(True)
@@ -60,6 +66,8 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True):
         gscale = float(a2.grad.abs().max()) + 1e-30
         eb = float((a1.grad - a2.grad).abs().max()) / gscale
         same = bool(torch.equal(a1.grad, a3.grad))
+        if large:   # two factorisations of the transform at these sizes: agreement to rounding, not bit for bit
+            same = float((a1.grad - a3.grad).abs().max()) <= 2e-5 * gscale
         worst_f, worst_b = max(worst_f, ef), max(worst_b, eb)
         cases += 1
         if not (ef <= 2e-5 and eb <= 2e-3 and same and bool(torch.isfinite(a1.grad).all())):
