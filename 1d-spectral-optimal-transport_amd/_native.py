@@ -30,7 +30,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 5                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 6                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -60,6 +60,9 @@ EXPORTS = {
                                            _vp, _vp, _vp]),
     "sot_w1d_backward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, _vp,
                                         ctypes.c_size_t, _vp]),
+    "sot_w1d_position_grad": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_int64, ctypes.c_float, _vp, _vp, _vp,
+                                             ctypes.c_size_t, _vp]),
+    "sot_column_sum": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, _vp, _vp]),
     "sot_w1d_loss": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, ctypes.c_double, ctypes.c_int, ctypes.c_float, _vp, _vp,
                                     _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_quantiles": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, _vp, _vp, _vp, _vp,
@@ -515,6 +518,37 @@ def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=Tr
                                   ws.numel() if ws is not None else 0, stream_ptr(dev))
     check(rc, p)
     return gx, gy
+
+
+def position_grads(x, y, xpos, ypos, p, flags, grad_row, need_x=True, need_y=True, plan=None, grad_scale=1.0):
+    """Gradients w.r.t. the support positions (sot_w1d_position_grad): per-row [B, n] / [B, m] for per-row positions; for a shared
+    position row the batch sum [n] / [m] (sot_column_sum), which is what autograd's expand backward returns (losses.py:167-170)."""
+    lib = load()
+    dev = x.device
+    B, n = x.shape
+    m = y.shape[1]
+    gxp = torch.empty(B, n, dtype=torch.float32, device=dev) if need_x else None
+    gyp = torch.empty(B, m, dtype=torch.float32, device=dev) if need_y else None
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    ws = workspace(pr, dev) if need_ws else None
+    g = grad_row.contiguous()
+    stride = 0 if g.numel() == 1 else 1
+    if stride == 1 and g.numel() != B:
+        raise RuntimeError(f"grad_row has {g.numel()} elements for {B} rows")
+    out = []
+    with _on_device(dev):
+        rc = lib.sot_w1d_position_grad(ctypes.byref(pr), g.data_ptr(), stride, float(grad_scale), _ptr(gxp), _ptr(gyp), _ptr(ws),
+                                       ws.numel() if ws is not None else 0, stream_ptr(dev))
+        check(rc, p)
+        for rows, pos, width in ((gxp, xpos, n), (gyp, ypos, m)):
+            if rows is None or pos.ndim == 2:
+                out.append(rows)
+                continue
+            tot = torch.empty(width, dtype=torch.float32, device=dev)
+            check(lib.sot_column_sum(rows.data_ptr(), B, width, width, tot.data_ptr(), stream_ptr(dev)), p)
+            out.append(tot)
+    return out
 
 
 def quantiles(x, y, xpos, ypos, p, flags, plan=None):

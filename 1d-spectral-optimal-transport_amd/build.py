@@ -23,8 +23,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # sot_hip.hip is compiled in parts (-DSOT_PART=<bit>) in parallel and linked into one shared library:
 # compile-time-length forward and backward kernels, forward/shared positions (no cutoff, cutoff), forward/per-row positions,
-# backward/shared, backward/per-row, everything else, CSR forward.
-PARTS = (128, 256, 512, 1024, 1, 64, 2, 4, 8, 16, 32)   # the longest first (bits 7-10: compile-time-geometry kernels)
+# backward/shared, backward/per-row, everything else, CSR forward, position gradients.
+PARTS = (128, 256, 512, 1024, 1, 64, 2, 4, 8, 16, 32, 2048)   # the longest first (bits 7-10: compile-time-geometry kernels)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "obj")
 
 

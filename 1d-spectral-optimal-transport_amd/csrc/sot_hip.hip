@@ -24,9 +24,10 @@
 // kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
 // positions, bit 2 backward/shared, bit 3 backward/per-row, bit 4 everything else (small kernels, host glue, C ABI),
 // bit 5 the CSR (ragged) forward, bit 6 the cutoff (limit_quantile_range) family of forward/shared positions (bit 0 then
-// holds the no-cutoff family), bit 7 the compile-time-length forward kernels, bit 8 the compile-time-length backward kernels.
+// holds the no-cutoff family), bit 7 the compile-time-length forward kernels, bit 8 the compile-time-length backward kernels,
+// bits 9 / 10 their run-time-length forms, bit 11 the position-gradient kernel.
 #ifndef SOT_PART
-#define SOT_PART 2047
+#define SOT_PART 4095
 #endif
 // Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
 // search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
@@ -1160,6 +1161,9 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 int run_forward_csr(const float* xw, const float* xp, const int64_t* xoff, int64_t x_nnz, const float* yw, const float* yp,
                     const int64_t* yoff, int64_t y_nnz, int64_t B, int max_n, int max_m, float p, uint32_t flags, float* row_loss,
                     void* stream);
+int run_position_grad(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gxp, float* gyp,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int run_column_sum(const float* rows, int64_t B, int n, int64_t stride, float* out, void* stream);
 
 #ifdef SOT_STUB_MISSING_PARTS
 // diagnostic single-file builds (stamps / ablation) compile a subset of the parts: resolve the rest with stubs
@@ -1193,6 +1197,10 @@ hipError_t dispatch_backward_full_rt(int, const BwdArgs&, hipStream_t) { return 
 #if !(SOT_PART & 32)
 int run_forward_csr(const float*, const float*, const int64_t*, int64_t, const float*, const float*, const int64_t*, int64_t, int64_t, int,
                     int, float, uint32_t, float*, void*) { return SOT_ERR_LAUNCH; }
+#endif
+#if !(SOT_PART & 2048)
+int run_position_grad(const sot_problem*, const float*, int64_t, float, float*, float*, void*, size_t, void*) { return SOT_ERR_LAUNCH; }
+int run_column_sum(const float*, int64_t, int, int64_t, float*, void*) { return SOT_ERR_LAUNCH; }
 #endif
 #endif  // SOT_STUB_MISSING_PARTS
 
@@ -1362,6 +1370,248 @@ template hipError_t dispatch_backward<false>(const LaunchCfg&, int, bool, const 
 template hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, const BwdArgs&, size_t, int64_t, int, hipStream_t);
 #endif
 #endif  // backward parts
+
+#if SOT_PART & 2048
+// ---------------------------------------------------------------------------------------------
+// Gradients w.r.t. the SUPPORT POSITIONS (round 4; losses.py:287-298, 214-220: the positions enter the loss through torch.sort and
+// take_along_dim, both differentiable -- no reference call site asks for this gradient, but the reference's autograd supplies it).
+// With delta_k the width of merged level k and (i_k, j_k) the searchsorted ranks of Q_k in U and V (clamped to n-1 / m-1),
+//     d row_loss / d xs[i] =  sum_{k : i_k = i} delta_k * p |xs[i_k] - ys[j_k]|^(p-1) sign(xs[i_k] - ys[j_k]),   ys[j]: minus the same.
+// The ranks of level k are the numbers of U / V levels consumed before step k of the merge walk (losses.py:219 `searchsorted` is
+// side='left'; a level whose rank that misstates -- the second member of a tie -- has zero width), so the terms of xs[i] are the
+// walk steps between the consumption of U[i-1] and of U[i], the latter included: a contiguous range of steps that may span several
+// threads.  Deterministic, no atomics: the thread that consumes U[i] ASSIGNS the sum of its own steps since the start of its segment
+// (or since its previous U) to slot i; every thread leaves the sum behind its last U as a (slot, value) TAIL; after a barrier the
+// first thread of each run of equal tail slots adds the run's values, in thread order, to the slot.  Same for V.  Levels past the
+// last U level rank n and are clamped to n-1 (losses.py:220): slot n collects them and is folded into slot n-1.
+// One kernel for every p and for the cutoff (run-time switches: this is not a hot path).  Output: per-row gradients in the
+// caller's ORIGINAL column order (through the sort permutation), already multiplied by the upstream gradient of the row.
+// ---------------------------------------------------------------------------------------------
+struct PosGradArgs {
+    FwdArgs f;
+    const float* grad_row; int64_t grad_row_stride; float grad_scale;
+    float* gxp; float* gyp;   // [B, n] / [B, m], either may be null
+};
+
+__device__ __forceinline__ float cost_slope(float d, int pm, float p)
+{
+    if (pm == 1) return (float)(d > 0.0f) - (float)(d < 0.0f);   // d |d| / dd, 0 at 0 (torch.abs backward)
+    if (pm == 2) return 2.0f * d;                                   // pow(2) backward: 2 |d| sign(d)
+    return copysignf(p * pow_nonneg(fabsf(d), p - 1.0f), d);        // pow_nonneg(0, .) = 0
+}
+
+template <int G, int CPT, bool ROWPOS>
+__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_position_grad_kernel(const PosGradArgs b)
+{
+    constexpr int BLOCK = (G < 256 ? 256 : G);
+    constexpr int RPW = BLOCK / G;
+    constexpr int NW = G / kWave;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdArgs& a = b.f;
+    const RowCtx<G> c = make_ctx<G, ROWPOS>(a, smem, true);
+    // The per-thread tails (value, slot) x 2 of the Ga walking threads: in the row's own CDF region when it is large enough (long rows:
+    // 4 Ga <= n + m; the CDFs are dead once every thread has finished its walk), otherwise behind the row regions (posgrad_tail_floats)
+    const int rg = threadIdx.x / G;
+    const bool tails_in_cdfs = 4 * c.Ga <= c.n + c.m;
+    const int tstride = tails_in_cdfs ? c.Ga : G;
+    float* const tail_x = tails_in_cdfs ? c.U : smem + RPW * c.L.row_floats + rg * 4 * G;   // value behind the thread's last U
+    int* const tail_i = reinterpret_cast<int*>(tail_x + tstride);                             // its slot (index into Uw)
+    float* const tail_y = tail_x + 2 * tstride;
+    int* const tail_j = reinterpret_cast<int*>(tail_x + 3 * tstride);
+    const int n = c.n, m = c.m, t = c.t;
+    float* const U = c.U; float* const V = c.V; float* const PX = c.PX; float* const PY = c.PY;
+    const int pm = (a.p == 1.0f) ? 1 : ((a.p == 2.0f) ? 2 : 0);
+    const bool lim = c.lim;
+
+    const int64_t row_step = (int64_t)gridDim.x * RPW;
+    int64_t row0 = (int64_t)blockIdx.x * RPW;
+    float rx[CPT], ry[CPT];
+    if (row0 < a.B) {
+        const int64_t r = min(row0 + rg, a.B - 1);
+        load_row<G, CPT, false>(a.x + r * a.xs, n, t, rx);
+        load_row<G, CPT, false>(a.y + r * a.ys, m, t, ry);
+    }
+    for (; row0 < a.B; row0 += row_step) {
+        const int64_t row = row0 + rg;
+        const bool valid = row < a.B;
+        const int64_t rowc = valid ? row : a.B - 1;
+        int ix[CPT], iy[CPT];
+        if (ROWPOS) rowpos_prepare<G, CPT>(c, a.xpos + rowc * a.xps, a.ypos + rowc * a.yps, a.n, a.m, ix, iy);
+        store_row<G, CPT, false>(U, n, t, rx);
+        store_row<G, CPT, false>(V, m, t, ry);
+        if (row0 + row_step < a.B) {
+            const int64_t r = min(row0 + row_step + rg, a.B - 1);
+            load_row<G, CPT, false>(a.x + r * a.xs, n, t, rx);
+            load_row<G, CPT, false>(a.y + r * a.ys, m, t, ry);
+        }
+        row_sync<NW>();
+        float wx[CPT], wy[CPT];
+        float Sx, Sy;
+        build_cdfs<G, CPT, ROWPOS>(a, c, ix, iy, wx, wy, Sx, Sy);
+
+        float* const GUw = c.GU - c.pad;   // slot of Uw[i]; GUw[n + pad] = GU[n]: the levels past the last U level
+        if (t == 0) { c.GU[n] = 0.0f; c.GV[m] = 0.0f; }   // nobody consumes the sentinels: these two slots only receive tails
+        float tx = 0.0f, ty = 0.0f;
+        int ti = -1, tj = -1;
+        if (t < c.Ga) {
+            const float* const Uw = U - c.pad;
+            const float* const PXw = PX - c.pad;
+            const int nw = n + c.pad;
+            const int D0 = t * c.E;
+            const uint32_t ub1 = lds_addr(Uw) - 4u;
+            const int i0 = (int)((merge_path_steps32(ub1, lds_addr(V) + 4u * (uint32_t)D0 + ub1, nw, m, D0, c.topk) - ub1) >> 2);
+            const int j0 = D0 - i0;
+            float qprev = 0.0f;   // Q_0 := 0 (the pad of losses.py:301)
+            if (i0 > 0) qprev = Uw[i0 - 1];
+            if (j0 > 0) qprev = fmaxf(qprev, V[j0 - 1]);
+            float ua = Uw[i0], vb = V[j0], xa = PXw[i0], yb = PY[j0];
+            char* const lb = reinterpret_cast<char*>(const_cast<float*>(Uw));
+            const uint32_t poff4 = 4u * (uint32_t)c.L.poff;
+            const uint32_t goff4 = 4u * (uint32_t)c.L.grad;
+            const int voff = (int)(V - Uw);
+            uint32_t iu = (uint32_t)i0;
+            float accx = 0.0f, accy = 0.0f;   // sums of the x-run / y-run that is open at this step
+            for (int s = 0; s < c.E; ++s) {
+                const bool tu = ua <= vb;   // canonical stable order: U before V on ties
+                const float q = tu ? ua : vb;
+                float delta = q - qprev;
+                if (lim && q > 1.0f) delta = 0.0f;
+                const float g = delta * cost_slope(xa - yb, pm, c.p);
+                accx += g;
+                accy += g;
+                qprev = q;
+                const uint32_t vk = (uint32_t)(voff + D0 + s);
+                const uint32_t off = 4u * (tu ? iu : (vk - iu));   // the element consumed now closes its side's run
+                *reinterpret_cast<float*>(lb + off + goff4) = tu ? accx : accy;
+                accx = tu ? 0.0f : accx;
+                accy = tu ? accy : 0.0f;
+                iu += tu ? 1u : 0u;
+                const float nv = *reinterpret_cast<const float*>(lb + off + 4u);
+                const float np = *reinterpret_cast<const float*>(lb + off + 4u + poff4);
+                ua = tu ? nv : ua;
+                xa = tu ? np : xa;
+                vb = tu ? vb : nv;
+                yb = tu ? yb : np;
+            }
+            tx = accx; ty = accy;
+            ti = (int)iu;                 // slot (in Uw) of the U level that is the head when this segment ends; nw = past the end
+            tj = D0 + c.E - (int)iu;      // likewise in V; m = past the end
+        }
+        row_sync<NW>();   // every walk is done: the CDFs may be overwritten by the tails
+        if (t < c.Ga) { tail_x[t] = tx; tail_i[t] = ti; tail_y[t] = ty; tail_j[t] = tj; }
+        row_sync<NW>();
+        if (t < c.Ga) {
+            if (t == 0 || tail_i[t - 1] != ti) {   // first thread of a run of equal tail slots: one writer per slot
+                float sum = tx;
+                for (int u = t + 1; u < c.Ga && tail_i[u] == ti; ++u) sum += tail_x[u];
+                GUw[ti] = sum + GUw[ti];
+            }
+            if (t == 0 || tail_j[t - 1] != tj) {
+                float sum = ty;
+                for (int u = t + 1; u < c.Ga && tail_j[u] == tj; ++u) sum += tail_y[u];
+                c.GV[tj] = sum + c.GV[tj];
+            }
+        }
+        row_sync<NW>();
+        if (t == 0) { c.GU[n - 1] += c.GU[n]; c.GV[m - 1] += c.GV[m]; }   // clamp of losses.py:220
+        row_sync<NW>();
+        if (valid) {
+            const float gr = (b.grad_row ? b.grad_row[rowc * b.grad_row_stride] : 1.0f) * b.grad_scale;
+            const bool x_perm = ROWPOS ? c.do_sort : !c.x_ident;
+            const bool y_perm = ROWPOS ? c.do_sort : !c.y_ident;
+            const int e0 = t * CPT;
+            if (b.gxp) {
+                float* dst = b.gxp + row * (int64_t)n;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int e = e0 + k;
+                    if (e < n) dst[ROWPOS ? (x_perm ? ix[k] : e) : (x_perm ? a.xperm[e] : e)] = c.GU[e] * gr;
+                }
+            }
+            if (b.gyp) {
+                float* dst = b.gyp + row * (int64_t)m;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int e = e0 + k;
+                    if (e < m) dst[ROWPOS ? (y_perm ? iy[k] : e) : (y_perm ? a.yperm[e] : e)] = -(c.GV[e] * gr);
+                }
+            }
+        }
+        if (t == 0) { U[n] = INFINITY; V[m] = INFINITY; }   // the sentinels (make_ctx sets them once) may lie under the tails
+        row_sync<NW>();   // slot reads done before the next row reuses LDS
+    }
+}
+
+template <int G, int CPT, bool ROWPOS>
+static hipError_t launch_position_grad(const PosGradArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    auto kern = sot_position_grad_kernel<G, CPT, ROWPOS>;
+    static GridCache cache;
+    const int grid_cap = cached_resident_grid(cache, kern, block, lds);
+    const int grid = balanced_grid(want, grid_cap);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, b);
+    return hipGetLastError();
+}
+
+template <bool ROWPOS>
+static hipError_t dispatch_position_grad(const LaunchCfg& c, const PosGradArgs& b, size_t lds, int64_t want, int block, hipStream_t s)
+{
+    if (c.CPT == 16) return launch_position_grad<1024, 16, ROWPOS>(b, lds, want, block, s);
+    switch (c.G) {
+        case 64: return launch_position_grad<64, 8, ROWPOS>(b, lds, want, block, s);
+        case 128: return launch_position_grad<128, 12, ROWPOS>(b, lds, want, block, s);
+        case 256: return launch_position_grad<256, 8, ROWPOS>(b, lds, want, block, s);
+        default: return launch_position_grad<1024, 8, ROWPOS>(b, lds, want, block, s);
+    }
+}
+
+int run_position_grad(const sot_problem* pr, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* gxp, float* gyp,
+                      void* workspace, size_t workspace_bytes, void* stream)
+{
+    Launch l;
+    int rc = setup_launch(pr, true, workspace, workspace_bytes, stream, &l);
+    if (rc != SOT_OK) return rc;
+    if (pr->B == 0 || (gxp == nullptr && gyp == nullptr)) return SOT_OK;
+    // the per-thread tails: behind the row regions unless the rows are long enough to hold them in their dead CDFs (see the kernel)
+    const int E = merge_steps(pr->n + pr->m, l.cfg.G), Ga = (pr->n + pr->m + E - 1) / E;
+    const size_t lds = l.lds + ((4 * Ga <= pr->n + pr->m) ? 0 : 4 * sizeof(float) * (size_t)l.block);
+    if (lds > kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
+    PosGradArgs b{};
+    b.f = l.a; b.grad_row = grad_row; b.grad_row_stride = grad_row_stride; b.grad_scale = grad_scale; b.gxp = gxp; b.gyp = gyp;
+    const hipError_t e = l.rowpos ? dispatch_position_grad<true>(l.cfg, b, lds, l.want, l.block, l.s)
+                                  : dispatch_position_grad<false>(l.cfg, b, lds, l.want, l.block, l.s);
+    return e == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+// out[c] = sum_r rows[r * stride + c] in a fixed order (the sum over the batch that autograd attaches to a position row shared by
+// every batch row, losses.py:167-170 `expand`): 16 columns per workgroup, 64 row lanes each accumulating rows r = lane, lane + 64, ...
+// in fp64, then the 64 partial sums of a column in lane order.
+__global__ __launch_bounds__(1024) void sot_column_sum_kernel(const float* __restrict__ rows, int64_t B, int n, int64_t stride,
+                                                              float* __restrict__ out)
+{
+    __shared__ double part[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    double acc = 0.0;
+    if (col < n)
+        for (int64_t r = rl; r < B; r += 64) acc += (double)rows[r * stride + col];
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        double tot = 0.0;
+        for (int k = 0; k < 64; ++k) tot += part[k][cl];
+        out[col] = (float)tot;
+    }
+}
+
+int run_column_sum(const float* rows, int64_t B, int n, int64_t stride, float* out, void* stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(sot_column_sum_kernel, dim3((n + 15) / 16), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), rows, B, n, stride, out);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+#endif  // position-gradient part
 
 #if SOT_PART & 16
 // ---------------------------------------------------------------------------------------------
@@ -1844,6 +2094,20 @@ int sot_w1d_loss(const sot_problem* prob, float* row_loss, double denom, int app
                                     stream, completion_counters ? &mt : nullptr);
     if (rc != SOT_OK || completion_counters != nullptr) return rc;
     return sot_w1d_reduce_mean(row_loss, prob->B, denom, apply_hinge, hinge_threshold, mean_out, sum_out, stream);
+}
+
+int sot_w1d_position_grad(const sot_problem* prob, const float* grad_row, int64_t grad_row_stride, float grad_scale, float* grad_xpos,
+                          float* grad_ypos, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (grad_row_stride != 0 && grad_row_stride != 1) return SOT_ERR_BAD_SHAPE;
+    return sot::run_position_grad(prob, grad_row, grad_row_stride, grad_scale, grad_xpos, grad_ypos, workspace, workspace_bytes, stream);
+}
+
+int sot_column_sum(const float* rows, int64_t B, int32_t n, int64_t row_stride, float* out, void* stream)
+{
+    if (B < 0 || n < 1 || row_stride < n) return SOT_ERR_BAD_SHAPE;
+    if (out == nullptr || (B > 0 && rows == nullptr)) return SOT_ERR_NULL_POINTER;
+    return sot::run_column_sum(rows, B, (int)n, row_stride, out, stream);
 }
 
 int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stride, float* sorted_keys, int64_t* indices,

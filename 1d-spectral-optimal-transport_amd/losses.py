@@ -70,6 +70,9 @@ def _beyond_one_cu(x, y, *positions) -> bool:
     """Rows too long for the LDS-resident kernels (n_fft >= 32768): the reference has no size limit (losses.py:223-313), so such GPU
     tensors run the package's torch-op composition -- said once -- instead of failing.  No paper configuration comes near."""
     n, m = x.shape[-1], y.shape[-1]
+    if any(t is not None and t.ndim >= 2 and not (t.shape[0] > 1 and t.stride(0) == 0) for t in positions):
+        # per-row positions are sorted in LDS on power-of-two arrays (csrc/sot_hip.hip make_layout, rowpos)
+        n, m = 1 << max(n - 1, 0).bit_length(), 1 << max(m - 1, 0).bit_length()
     wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, y) + tuple(positions))
     limit = ROW_POINT_LIMIT if not wants_grad else 12000
     if n + m <= limit and max(n, m) <= ROW_SIDE_LIMIT:   # the kernels also cap each side (pick_cfg: 1024 threads x 16 points)
@@ -93,10 +96,22 @@ def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, pren
 
 def _position_grads(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, need_y):
     """d sum_r grad_rows[r] * loss_r / d positions (losses.py:287-313: the positions enter through torch.sort and
-    take_along_dim, both differentiable).  No reference call site asks for it, so there is no kernel of its own:
-    the quantile kernel (sot_w1d_quantiles) supplies the merged levels and both inverse CDFs, and
+    take_along_dim, both differentiable).  No reference call site asks for it; autograd supplies it, and so does
+    this package: ONE deterministic HIP kernel (sot_w1d_position_grad: the merge walk accumulates
         d loss / d xs[i] = sum over the merged levels k whose x-rank is i of  delta_k * p |uq_k - vq_k|^(p-1) sign(uq_k - vq_k)
-    (minus that for ys) is scattered with torch ops (atomic adds: the one gradient of this package whose last bits may vary)."""
+    and minus that for ys, no atomics) plus the fixed-order batch sum for a position row shared by all rows (sot_column_sum)."""
+    try:
+        return nat.position_grads(x, y, xpos, ypos, p, flags, grad_rows, need_x, need_y, plan)
+    except nat.SotError as err:   # rows whose gradient layout + per-thread tails exceed one CU's LDS (n + m beyond ~12 000)
+        if err.status != nat.SOT_ERR_UNSUPPORTED_SIZE:
+            raise
+        warn_once("posgrad-too-long", "sot_amd: position gradients of rows this long run as torch ops (atomic adds)")
+        return _position_grads_torch(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, need_y)
+
+
+def _position_grads_torch(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, need_y):
+    """The same gradient from the quantile kernel's outputs with torch ops (searchsorted + scatter_add_): only for rows beyond the
+    position-gradient kernel's LDS budget."""
     uq, vq, levels, cdf_x, cdf_y = nat.quantiles(x, y, xpos, ypos, p, flags, plan)
     rows, n = x.shape
     m = y.shape[1]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 5   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 6   /* bumped on every change of a signature below; the binding checks it */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -200,6 +200,23 @@ int sot_w1d_forward_csr(const float *x_weights, const float *x_positions, const 
  */
 int sot_w1d_quantiles(const sot_problem *prob, float *uq, float *vq, float *Q, float *U, float *V,
                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Gradient of sum_r grad_scale * grad_row[r] * row_loss[r] w.r.t. the SUPPORT POSITIONS (losses.py:287-298 and 214-220: the positions
+ * enter through torch.sort and take_along_dim, both differentiable; no reference call site asks for it, autograd supplies it):
+ *     d row_loss / d xs[i] = sum over the merged levels k whose searchsorted rank in U (clamped to n-1) is i of
+ *                            delta_k * p |xs[i_k] - ys[j_k]|^(p-1) sign(xs[i_k] - ys[j_k]);    ys[j]: minus the same.
+ * One kernel, deterministic (no atomics).  Outputs are PER ROW, [B, n] / [B, m] dense, in the caller's original column order (the
+ * sort of losses.py:287-288 is undone); either may be NULL.  For a position row shared by all batch rows (xpos_row_stride == 0)
+ * the caller sums the rows -- sot_column_sum below -- which is what autograd's `expand` backward does (losses.py:167-170).
+ * grad_row / grad_row_stride / grad_scale as in sot_w1d_backward.
+ */
+int sot_w1d_position_grad(const sot_problem *prob, const float *grad_row, int64_t grad_row_stride, float grad_scale,
+                          float *grad_xpos /* [B,n] or NULL */, float *grad_ypos /* [B,m] or NULL */,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[c] = sum_r rows[r * row_stride + c], c < n, in a fixed order with fp64 accumulation. */
+int sot_column_sum(const float *rows, int64_t B, int32_t n, int64_t row_stride, float *out /* [n] */, void *stream);
 
 /*
  * Segmented (per-row) stable ascending sort with index payload: what torch.sort(keys, 1)

@@ -180,6 +180,80 @@ def test_position_gradients_match_the_reference_autograd(case):
         assert float((got.cpu() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-6), case
 
 
+@pytest.mark.parametrize("shape", [(5, 67, 67), (7, 700, 700), (6, 1025, 300), (5, 2048, 2048), (3, 5000, 4100), (9, 1, 40), (4, 3, 1)])
+@pytest.mark.parametrize("mode", ["p1", "p2_cutoff_dn", "p1.5_sparse", "p3_unsorted"])
+@pytest.mark.parametrize("shared", [True, False])
+def test_position_gradient_kernel_all_geometries(shape, mode, shared):
+    """sot_w1d_position_grad (round 4: the HIP kernel behind gradients w.r.t. the support positions, losses.py:287-298 + 214-220)
+    on every thread geometry of the generic kernels (64 / 128 / 256 / 1024 threads per row, 8 / 12 / 16 points per thread), n != m,
+    one-point measures, sparse rows (runs of tied levels), un-normalised rows (levels past the other side's last level: the clamp of
+    losses.py:220), the cutoff and unsorted positions (the gradient goes back through the sort permutation) -- against autograd of
+    the op-for-op restatement on the CPU in float32 (same CDF bits, hence the same ties), entry by entry at 2e-5 of the largest
+    entry; and bit-identical between two launches (no atomics)."""
+    from oracle import torch_restatement as tr
+    from sot_amd import losses as L
+    nat = native()
+    dev = device()
+    B, n, m = shape
+    if not shared and n == 5000:
+        n, m = 3000, 2500   # per-row positions are sorted on power-of-two arrays: 4096 + 4096 with gradient slots is what one CU holds
+    g = torch.Generator().manual_seed(1000 * n + m + len(mode) + int(shared))
+    kw = dict(p1=dict(p=1), p2_cutoff_dn=dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True),
+              **{"p1.5_sparse": dict(p=1.5), "p3_unsorted": dict(p=3, dont_normalize=True)})[mode]
+    x, y = torch.rand(B, n, generator=g) + 0.01, torch.rand(B, m, generator=g) + 0.01
+    if mode == "p1.5_sparse":
+        x = x * (torch.rand(B, n, generator=g) < 0.3)
+        y = y * (torch.rand(B, m, generator=g) < 0.3)
+    unsorted = mode == "p3_unsorted"
+    def positions(width):   # distinct positions: between EQUAL positions torch.sort's (unstable) order decides which one gets the gradient
+        rows = 1 if shared else B
+        pos = (torch.arange(width)[None, :] + 0.9 * torch.rand(rows, width, generator=g)) / width
+        if unsorted:
+            pos = torch.stack([r[torch.randperm(width, generator=g)] for r in pos])
+        return pos[0].clone() if shared else pos
+    xp, yp = positions(n), positions(m)
+    up = torch.rand(B, generator=g) + 0.5
+    xpr, ypr = xp.clone().requires_grad_(True), yp.clone().requires_grad_(True)
+    (tr.sot_loss(x, y, xpr, ypr, reduce=False, **kw) * up).sum().backward()
+    ctor = {k: v for k, v in kw.items() if k != "p"}
+    mod = L.Wasserstein1D(p=kw["p"], **ctor).to(dev)
+    grads = []
+    for _ in range(2):
+        xpd, ypd = xp.to(dev).requires_grad_(True), yp.to(dev).requires_grad_(True)
+        (mod.row_losses(x.to(dev), y.to(dev), xpd, ypd) * up.to(dev)).sum().backward()
+        grads.append((xpd.grad.clone(), ypd.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1]), "position gradients must be deterministic"
+    for got, want in ((grads[0][0], xpr.grad), (grads[0][1], ypr.grad)):
+        assert got.shape == want.shape
+        scale = max(float(want.abs().max()), 1e-6)
+        assert float((got.cpu() - want).abs().max()) <= 2e-5 * scale, (shape, mode, shared)
+
+
+@pytest.mark.gpu
+def test_position_gradient_kernel_matches_the_torch_op_route_and_column_sum():
+    """The kernel against the package's own torch-op composition of the same gradient (quantile kernel + searchsorted + scatter_add_,
+    kept for rows beyond the kernel's LDS budget) on a full-size batch, and sot_column_sum against a float64 torch sum."""
+    from sot_amd import losses as L
+    nat = native()
+    dev = device()
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, n = 512, 2048
+    x, y = torch.rand(B, n, device=dev, generator=g), torch.rand(B, n, device=dev, generator=g)
+    pos = torch.sort(torch.rand(B, n, device=dev, generator=g), dim=1)[0]
+    pos2 = torch.sort(torch.rand(B, n, device=dev, generator=g), dim=1)[0]
+    up = torch.rand(B, device=dev, generator=g)
+    flags = L._flags(True, True, True, True)
+    a = nat.position_grads(x, y, pos, pos2, 2.0, flags, up)
+    b = L._position_grads_torch(x, y, pos, pos2, 2.0, flags, None, up, True, True)
+    for got, want in zip(a, b):
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    rows = torch.randn(1000, 1025, device=dev, generator=g)
+    out = torch.empty(1025, device=dev)
+    lib = nat.load()
+    nat.check(lib.sot_column_sum(rows.data_ptr(), 1000, 1025, 1025, out.data_ptr(), nat.stream_ptr(dev)))
+    torch.testing.assert_close(out, rows.double().sum(0).float(), rtol=1e-6, atol=1e-6)   # both sums are fp64-accumulated
+
+
 @pytest.mark.gpu
 def test_cpp_host_path_equals_the_python_binding():
     """The module's default call goes through the C++ host path (csrc/sot_torch_glue.cpp: one pybind11 call, C++ autograd node); it
