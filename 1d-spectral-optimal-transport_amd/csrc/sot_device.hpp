@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
 
 namespace sot {
 
@@ -537,6 +538,183 @@ __device__ __forceinline__ void merge_sort_kv(float* key, int* idx, int npad, in
             if (v < NV) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { key[8 * v + e] = ok[j][e]; idx[8 * v + e] = oi[j][e]; }
+            }
+        }
+        sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merge sort with SIXTEEN elements per thread on a skewed LDS image (round 4, second form).  Measured on the 8-per-thread form
+// above (4096 x 2048 keys, rocprofv3 PMC): the LDS array busy 80 % of the time with 74 % of its cycles bank conflicts (blocks of 8
+// dwords at a lane stride of 8 dwords: 8 lanes per bank), 2774 VALU instructions per wave and row of which the bisections are 30 %.
+// This form:
+//  * keys as ORDER-PRESERVING unsigned integers (float_order_bits), so that a run's end can carry a sentinel above every key;
+//  * a block of 16 elements per thread, sorted in registers by Batcher's odd-even merge network (63 compare-exchanges on (key, index):
+//    a total order, hence the stable result), then log2(npad / 16) merge rounds: half the bisections per element, one round less;
+//  * the image is SKEWED: element i lives at i + (i >> 4), i.e. every block of 16 is followed by one spare slot and a thread's block
+//    starts 17 dwords behind its neighbour's: block reads and writes touch 32 different banks;
+//  * the spare slot behind a block holds the run's SENTINEL (0xFFFFFFFF) when the block ends a run, otherwise a COPY of the next
+//    block's first element: the sequential merge reads "the element after the one just consumed", element g >= 1 of the same run, at
+//    g + ((g - 1) >> 4) -- the real slot inside a block, the copy at a block boundary, the sentinel at the run's end -- with no
+//    bounds test and no clamp (14 VALU per merged element instead of ~20);
+//  * TWO arrays at once (a row's x and y positions): one barrier sequence for both.
+// Entry: job.key holds the float keys in natural order on [0, npad) (+inf behind the n real ones); job.idx is scratch.  Exit: sorted
+// float keys and their original indices (INT_MAX for the pads) in natural order.  Both arrays need sort16_capacity(npad) dwords.
+// tests/test_merge_sort_model.py models this index algebra on the CPU.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int sort16_npad(int n) { int p = 16; while (p < n) p <<= 1; return p; }
+__host__ __device__ constexpr int sort16_capacity(int npad) { return npad + (npad >> 4); }
+
+__device__ __forceinline__ uint32_t float_order_bits(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    u = (u == 0x80000000u) ? 0u : u;   // -0.0 sorts with +0.0 (torch.sort compares values)
+    return u ^ ((u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float order_bits_float(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o); }
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_ld_u32(uint32_t addr) { return *reinterpret_cast<const lds_u32*>((uintptr_t)addr); }
+__device__ __forceinline__ void lds_st_u32(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u32*>((uintptr_t)addr) = v; }
+
+struct SortJob { float* key; int* idx; int n; int npad; };   // npad = sort16_npad(n), or 0 for "no array"
+
+// Batcher's odd-even merge sort for 16 inputs
+__device__ constexpr signed char kNet16[63][2] = {
+    {0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}, {4, 5}, {6, 7}, {4, 6}, {5, 7}, {5, 6}, {0, 4}, {2, 6}, {2, 4}, {1, 5}, {3, 7}, {3, 5},
+    {1, 2}, {3, 4}, {5, 6}, {8, 9}, {10, 11}, {8, 10}, {9, 11}, {9, 10}, {12, 13}, {14, 15}, {12, 14}, {13, 15}, {13, 14}, {8, 12},
+    {10, 14}, {10, 12}, {9, 13}, {11, 15}, {11, 13}, {9, 10}, {11, 12}, {13, 14}, {0, 8}, {4, 12}, {4, 8}, {2, 10}, {6, 14}, {6, 10},
+    {2, 4}, {6, 8}, {10, 12}, {1, 9}, {5, 13}, {5, 9}, {3, 11}, {7, 15}, {7, 11}, {3, 5}, {7, 9}, {11, 13}, {1, 2}, {3, 4}, {5, 6},
+    {7, 8}, {9, 10}, {11, 12}, {13, 14}};
+
+template <int MAXB, typename Sync>
+__device__ __forceinline__ void merge_sort16_kv2(const SortJob& jx, const SortJob& jy, int t, int T, Sync sync)
+{
+    const int NBx = jx.npad >> 4, NB = NBx + (jy.npad >> 4);
+    const int maxpad = jx.npad > jy.npad ? jx.npad : jy.npad;
+    uint32_t ok[MAXB][16]; int oi[MAXB][16];
+    // ---- phase 0: blocks of 16 in registers
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) {
+        const int vb = t + j * T;
+        if (vb < NB) {
+            const SortJob& job = vb < NBx ? jx : jy;
+            const int b = vb < NBx ? vb : vb - NBx;
+            const float4* src = reinterpret_cast<const float4*>(job.key + 16 * b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = src[q];
+                ok[j][4 * q] = float_order_bits(v.x); ok[j][4 * q + 1] = float_order_bits(v.y);
+                ok[j][4 * q + 2] = float_order_bits(v.z); ok[j][4 * q + 3] = float_order_bits(v.w);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oi[j][e] = (16 * b + e < job.n) ? 16 * b + e : INT_MAX;
+#pragma unroll
+            for (int c = 0; c < 63; ++c) {
+                const int p = kNet16[c][0], q = kNet16[c][1];
+                // (key, index) as one 64-bit integer: a single v_cmp_gt_u64 (and no short-circuit control flow: 63 nested ||/&& sent
+                // the compiler into a path explosion)
+                const bool sw = (((unsigned long long)ok[j][p] << 32) | (uint32_t)oi[j][p]) > (((unsigned long long)ok[j][q] << 32) | (uint32_t)oi[j][q]);
+                const uint32_t k0 = sw ? ok[j][q] : ok[j][p], k1 = sw ? ok[j][p] : ok[j][q];
+                const int x0 = sw ? oi[j][q] : oi[j][p], x1 = sw ? oi[j][p] : oi[j][q];
+                ok[j][p] = k0; ok[j][q] = k1; oi[j][p] = x0; oi[j][q] = x1;
+            }
+        }
+    }
+    sync();   // every natural-order read is done: the skewed image may overwrite it
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) {
+        const int vb = t + j * T;
+        if (vb < NB) {
+            const SortJob& job = vb < NBx ? jx : jy;
+            const int b = vb < NBx ? vb : vb - NBx;
+            if (job.npad == 16) {   // a single block: done; natural order, float keys
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { job.key[e] = order_bits_float(ok[j][e]); job.idx[e] = oi[j][e]; }
+            } else {
+                const uint32_t ka = lds_addr(job.key) + 68u * (uint32_t)b, xa = lds_addr(job.idx) + 68u * (uint32_t)b;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { lds_st_u32(ka + 4u * e, ok[j][e]); lds_st_u32(xa + 4u * e, (uint32_t)oi[j][e]); }
+                lds_st_u32(ka + 64u, 0xFFFFFFFFu);   // every block is a run of its own: the sentinel
+            }
+        }
+    }
+    sync();
+    // ---- merge rounds: runs of L -> runs of 2 L
+    int logL = 4;
+    for (int L = 16; L < maxpad; L <<= 1, ++logL) {
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j) {
+            const int vb = t + j * T;
+            const SortJob& job = vb < NBx ? jx : jy;
+            if (vb < NB && L < job.npad) {
+                const int b = vb < NBx ? vb : vb - NBx;
+                const uint32_t kbase = lds_addr(job.key), xbase = lds_addr(job.idx);
+                const int o = 16 * b;                          // first output of this block
+                const int a0 = o & ~(2 * L - 1), b0 = a0 + L;  // the pair of runs it falls into
+                const int d = o - a0;                          // outputs of the pair in front of it
+                int lo = max(0, d - L), hi = min(d, L);
+                for (int it = 0; it <= logL; ++it) {           // bisection on the merge path (left run first on ties: stable)
+                    if (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const int ga = a0 + mid, gb = b0 + d - 1 - mid;
+                        const bool take = lds_ld_u32(kbase + 4u * (uint32_t)(ga + (ga >> 4))) <= lds_ld_u32(kbase + 4u * (uint32_t)(gb + (gb >> 4)));
+                        lo = take ? mid + 1 : lo;
+                        hi = take ? hi : mid;
+                    }
+                }
+                int ia = a0 + lo;                              // the two heads (element numbers of the array): ia, and ib = ctot + e - ia
+                const int ib = b0 + d - lo, ctot = ia + ib;
+                // a head behind a consumed element of its run reads like every later one (copy / sentinel aware); the first element of a
+                // run is read at its real slot (the slot in front of it is the PREVIOUS run's sentinel)
+                const int pa = ia + ((ia - (lo > 0 ? 1 : 0)) >> 4), pb = ib + ((ib - (d - lo > 0 ? 1 : 0)) >> 4);
+                uint32_t ka = lds_ld_u32(kbase + 4u * (uint32_t)pa), kb = lds_ld_u32(kbase + 4u * (uint32_t)pb);
+                int xa = (int)lds_ld_u32(xbase + 4u * (uint32_t)pa), xb = (int)lds_ld_u32(xbase + 4u * (uint32_t)pb);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool ta = ka <= kb;                  // an exhausted run shows its sentinel and never wins
+                    ok[j][e] = ta ? ka : kb;
+                    oi[j][e] = ta ? xa : xb;
+                    if (e < 15) {
+                        const int gb = ctot + (e + 1) - ia;    // B's next element if B's head is the one consumed
+                        ia += ta ? 1 : 0;
+                        const int g = ta ? ia : gb;
+                        const uint32_t ph = 4u * (uint32_t)(g + ((g - 1) >> 4));
+                        const uint32_t kn = lds_ld_u32(kbase + ph);
+                        const int xn = (int)lds_ld_u32(xbase + ph);
+                        ka = ta ? kn : ka; xa = ta ? xn : xa;
+                        kb = ta ? kb : kn; xb = ta ? xb : xn;
+                    }
+                }
+            }
+        }
+        sync();   // every read of this round is done
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j) {
+            const int vb = t + j * T;
+            const SortJob& job = vb < NBx ? jx : jy;
+            if (vb < NB && L < job.npad) {
+                const int b = vb < NBx ? vb : vb - NBx;
+                if (2 * L == job.npad) {   // the last round of this array: natural order, float keys
+                    float4* dk = reinterpret_cast<float4*>(job.key + 16 * b);
+                    int4* dx = reinterpret_cast<int4*>(job.idx + 16 * b);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dk[q] = make_float4(order_bits_float(ok[j][4 * q]), order_bits_float(ok[j][4 * q + 1]),
+                                            order_bits_float(ok[j][4 * q + 2]), order_bits_float(ok[j][4 * q + 3]));
+                        dx[q] = make_int4(oi[j][4 * q], oi[j][4 * q + 1], oi[j][4 * q + 2], oi[j][4 * q + 3]);
+                    }
+                } else {
+                    const uint32_t ka = lds_addr(job.key) + 68u * (uint32_t)b, xa = lds_addr(job.idx) + 68u * (uint32_t)b;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { lds_st_u32(ka + 4u * e, ok[j][e]); lds_st_u32(xa + 4u * e, (uint32_t)oi[j][e]); }
+                    const int o = 16 * b;
+                    if ((o & (2 * L - 1)) != 0) {              // not the first block of its new run: the copy for the block in front
+                        lds_st_u32(ka - 4u, ok[j][0]); lds_st_u32(xa - 4u, (uint32_t)oi[j][0]);
+                    }
+                    if (((o + 16) & (2 * L - 1)) == 0) lds_st_u32(ka + 64u, 0xFFFFFFFFu);   // the last one: the sentinel
+                }
             }
         }
         sync();

@@ -89,9 +89,9 @@ __host__ __device__ constexpr RowLayout make_layout(int n, int m, int G, bool ro
     L.padcap = align4(merge_steps(n + m, G));
     L.nU = L.padcap + align4(n + 1);
     L.nV = align4(m + 1);
-    if (rowpos) {  // per-row position sort needs power-of-two scratch for the bitonic network
-        L.nU = imax(L.nU, L.padcap + next_pow2(n));
-        L.nV = imax(L.nV, next_pow2(m));
+    if (rowpos) {  // the per-row position sort works on power-of-two arrays in a skewed image (sot_device.hpp: sort16_capacity)
+        L.nU = imax(L.nU, L.padcap + align4(sort16_capacity(sort16_npad(n))));
+        L.nV = imax(L.nV, align4(sort16_capacity(sort16_npad(m))));
     }
     L.poff = L.nU + L.nV;
     const int nchx = (((n >= 8) ? (n >> 5) : 0) + 15) >> 4;
@@ -283,7 +283,7 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
     int* const IY = reinterpret_cast<int*>(c.V);
     // barriers are workgroup-wide, so the sort network is sized by the maximum lengths (identical for every
     // row group of the workgroup); rows whose positions are already sorted skip it altogether
-    const int npx = next_pow2(nmax), npy = next_pow2(mmax);
+    const int npx = MERGE ? sort16_npad(nmax) : next_pow2(nmax), npy = MERGE ? sort16_npad(mmax) : next_pow2(mmax);
     int unsorted = 0;
     // The thread's CPT slots (elements t + k G) are fetched with a compile-time trip count: all loads of a row are in flight together
     // (a runtime loop waits for each element before it requests the next: sixteen L2 round trips per row at 8 elements per thread).
@@ -317,8 +317,9 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
     const bool need_sort = row_any<G / kWave>(unsorted != 0);  // also the barrier after the loads
     if (need_sort) {
         if constexpr (MERGE) {
-            sort_kv<2>(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });   // stable merge sort (sot_device.hpp); npx <= 16 G
-            sort_kv<2>(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
+            // both arrays in one barrier sequence, 16 elements per thread (sot_device.hpp: merge_sort16_kv2); npx + npy <= 32 G
+            const SortJob jx{c.PX, IX, n, npx}, jy{c.PY, IY, m, npy};
+            merge_sort16_kv2<2>(jx, jy, t, G, [] { row_sync<G / kWave>(); });
         } else {
             bitonic_sort_kv(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });
             bitonic_sort_kv(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
@@ -1629,10 +1630,10 @@ __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     const int len = which ? m : n;
     float* spos = which ? sy : sx;
     int* perm = which ? py : px;
-    const int npad = next_pow2(len);
+    const int npad = sort16_npad(len), cap = (sort16_capacity(npad) + 3) & ~3;
     float* key = smem;
-    int* idx = reinterpret_cast<int*>(smem + npad);
-    int* const unsorted_flag = reinterpret_cast<int*>(smem + 2 * npad);  // all LDS is dynamic (16-B aligned carve)
+    int* idx = reinterpret_cast<int*>(smem + cap);
+    int* const unsorted_flag = reinterpret_cast<int*>(smem + 2 * cap);  // all LDS is dynamic (16-B aligned carve)
     const int t = threadIdx.x, T = blockDim.x;
     if (t == 0) *unsorted_flag = 0;
     for (int i = t; i < npad; i += T) {
@@ -1645,8 +1646,11 @@ __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     if (bad) *unsorted_flag = 1;
     __syncthreads();
     const bool need_sort = *unsorted_flag != 0;
-    if (need_sort) sort_kv<4>(key, idx, npad, t, T, [] { __syncthreads(); });
-    for (int i = t; i < len; i += T) { spos[i] = key[i]; perm[i] = idx[i]; }
+    if (need_sort) {   // npad <= 16384 = 16 x 1024 threads: one block of 16 per thread
+        const SortJob job{key, idx, len, npad}, none{nullptr, nullptr, 0, 0};
+        merge_sort16_kv2<1>(job, none, t, T, [] { __syncthreads(); });
+    }
+    for (int i = t; i < len; i += T) { spos[i] = key[i]; perm[i] = need_sort ? idx[i] : i; }
     if (t == 0) ident[which] = need_sort ? 0 : 1;
 }
 
@@ -1715,15 +1719,16 @@ __global__ __launch_bounds__(1024) void sot_segmented_sort_kernel(const float* _
                                                                  float* __restrict__ out_keys, int64_t* __restrict__ out_idx)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int npad = next_pow2(n);
+    const int npad = sort16_npad(n), cap = (sort16_capacity(npad) + 3) & ~3;
     float* key = smem;
-    int* idx = reinterpret_cast<int*>(smem + npad);
+    int* idx = reinterpret_cast<int*>(smem + cap);
     const int t = threadIdx.x, T = blockDim.x;
+    const SortJob job{key, idx, n, npad}, none{nullptr, nullptr, 0, 0};
     for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
         const float* src = keys + row * stride;
-        for (int i = t; i < npad; i += T) { key[i] = (i < n) ? src[i] : INFINITY; idx[i] = (i < n) ? i : INT_MAX; }
+        for (int i = t; i < npad; i += T) key[i] = (i < n) ? src[i] : INFINITY;
         __syncthreads();
-        sort_kv<2>(key, idx, npad, t, T, [] { __syncthreads(); });   // the launcher sizes the block so that npad <= 16 T
+        merge_sort16_kv2<1>(job, none, t, T, [] { __syncthreads(); });   // the launcher sizes the block so that npad <= 16 T
         for (int i = t; i < n; i += T) {
             if (out_keys) out_keys[row * (int64_t)n + i] = key[i];
             if (out_idx) out_idx[row * (int64_t)n + i] = (int64_t)idx[i];
@@ -1735,8 +1740,9 @@ __global__ __launch_bounds__(1024) void sot_segmented_sort_kernel(const float* _
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                           hipStream_t s)
 {
-    const int npad = next_pow2(n > m ? n : m);
-    const size_t prep_lds = (size_t)npad * 8 + 16;
+    const int npad = sort16_npad(n > m ? n : m);
+    if (npad > 16 * 1024) return SOT_ERR_UNSUPPORTED_SIZE;
+    const size_t prep_lds = (size_t)((sort16_capacity(npad) + 3) & ~3) * 8 + 16;
     if (prep_lds > kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
     static GridCache cache;
     allow_full_lds_once(cache, reinterpret_cast<const void*>(sot_prepare_positions_kernel));
@@ -2116,17 +2122,21 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
     if (B < 0 || n < 1 || row_stride < n) return SOT_ERR_BAD_SHAPE;
     if (B == 0) return SOT_OK;
     if (keys == nullptr) return SOT_ERR_NULL_POINTER;
-    const size_t lds = (size_t)sot::next_pow2(n) * 8;
+    const int npad = sot::sort16_npad((int)n);
+    if (npad > 16 * 1024) return SOT_ERR_UNSUPPORTED_SIZE;   // one block of 16 elements per thread
+    const size_t lds = (size_t)((sot::sort16_capacity(npad) + 3) & ~3) * 8;
     if (lds > sot::kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
     static sot::GridCache cache;
     sot::allow_full_lds_once(cache, reinterpret_cast<const void*>(sot::sot_segmented_sort_kernel));
+    int block = 64;                                    // one thread per block of 16 elements (whole wavefronts)
+    while (block < 1024 && npad > 16 * block) block <<= 1;
     int per_cu = (int)(sot::kLdsLimit / lds);
-    if (per_cu > 8) per_cu = 8;
+    const int wave_cap = 32 / (block / 64);            // at most 8 wavefronts per SIMD
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu > 16) per_cu = 16;
     int64_t cap = (int64_t)sot::device_cu_count() * per_cu;
     const int grid = (int)(B < cap ? B : cap);
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
-    int block = 256;                                   // merge sort: at most two blocks of 8 elements per thread
-    while (block < 1024 && sot::next_pow2((int)n) > 16 * block) block <<= 1;
     hipLaunchKernelGGL(sot::sot_segmented_sort_kernel, dim3(grid), dim3(block), lds, reinterpret_cast<hipStream_t>(stream), keys, B,
                        (int)n, row_stride, sorted_keys, indices);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;

@@ -279,6 +279,38 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
                                                                  rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
         out[f"b{rows_pr}n{N}_per_row_sorted_positions_forward"] = entry(timed(per_row_sorted, n), "sot_forward_kernel<ROWPOS> (rows already sorted: sortedness test only)",
                                                                         rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
+
+    # (0d) THE REFERENCE'S OWN OP SEQUENCE ON THIS GPU: losses.py:129-313 is ~25 ATen calls and device-agnostic, so a user of the
+    #      reference on an MI355X runs exactly this composition (the package's torch-op route, sot_amd/_torch_path.py: the same ops in the
+    #      same order; it is product code for CPU / float64 tensors, not the oracle).  Same inputs, same GPU, HIP events around a few
+    #      calls: the figure the HIP kernels are to be compared with on this hardware, next to the CPU baseline.
+    from sot_amd import _torch_path as tpath
+
+    def torch_ops(mode, rows, xpos, ypos, grad=False):
+        kw = MODES[mode]
+        args = dict(p=kw.get("p", 1), square_dist=kw.get("square_dist", False), dont_normalize=kw.get("dont_normalize", False),
+                    limit_quantile_range=kw.get("limit_quantile_range", False), require_sort=True, hinge_on=False)
+
+        def call(i):
+            x2, y2 = two[i % 2]
+            x2, y2 = x2[:rows], y2[:rows]
+            if not grad:
+                return tpath.module_forward(x2, y2, xpos[i % 2] if isinstance(xpos, list) else xpos, ypos[i % 2] if isinstance(ypos, list) else ypos, **args)
+            yv = y2.detach().requires_grad_(True)
+            tpath.module_forward(x2, yv, xpos, ypos, **args).backward()
+        return call
+
+    ref = {}
+    with torch.no_grad():
+        ref["p1_forward_ms"] = timed(torch_ops("p1", B, pos_x, pos_y), 6)
+        ref["paper_mode_forward_ms"] = timed(torch_ops("cutoff", B, pos_x, pos_y), 6)
+        ref[f"per_row_positions_{rows_pr}_rows_forward_ms"] = timed(torch_ops("cutoff", rows_pr, prx, pry), 6)
+    ref["paper_mode_forward_backward_ms"] = timed(torch_ops("cutoff", B, pos_x, pos_y, grad=True), 4)
+    ref["what"] = ("the reference's ATen op sequence (losses.py:129-313 via sot_amd/_torch_path.py) on the same GPU and inputs, B = %d rows "
+                   "x %d bins; compare: value's ms_per_step (p = 1), extras.b%dn%d_cutoff_forward, _cutoff_module_forward_backward, "
+                   "b%dn%d_per_row_positions_forward" % (B, N, B, N, rows_pr, N))
+    out["reference_ops_on_this_gpu"] = ref
+    torch.cuda.empty_cache()
     del prx, pry, srx, sry
 
     # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
