@@ -52,8 +52,17 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True, grad_tol=2e-3):
         else:
             pos_args = dict(x_pos=torch.rand(lead + (N,), generator=g), y_pos=torch.rand(lead + (N,), generator=g))
         gx, gy = bool(rng.random() < 0.3), bool(rng.random() < 0.7)
+        gp = bool(pos_kind != "fixed" and rng.random() < 0.35)   # round 4: gradients w.r.t. the positions (sot_w1d_position_grad)
+        if gp:   # DISTINCT positions: between equal positions torch.sort's (unstable) order decides which of them receives the gradient
+            def distinct(shape):
+                base = (torch.arange(N)[None, :] + 0.9 * torch.rand((int(np.prod(shape[:-1])) if len(shape) > 1 else 1, N), generator=g)) / N
+                if pos_kind != "shared":
+                    base = torch.stack([r[torch.randperm(N, generator=g)] for r in base])
+                return base.reshape(shape)
+            shape = (N,) if pos_kind != "rows" else lead + (N,)
+            pos_args = dict(x_pos=distinct(shape), y_pos=distinct(shape))
         want_grad = (gx or gy) and not cutoff          # (dyadic rows tie exactly: the gradient's tie order is a convention)
-        desc = dict(seed=seed, N=N, lead=lead, ctor=ctor, kwargs=kwargs, pos=pos_kind, gx=gx, gy=gy)
+        desc = dict(seed=seed, N=N, lead=lead, ctor=ctor, kwargs=kwargs, pos=pos_kind, gx=gx, gy=gy, gp=gp)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             cpu_mod, gpu_mod = Wasserstein1D(**ctor), Wasserstein1D(**ctor).to(dev)
@@ -63,7 +72,11 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True, grad_tol=2e-3):
                 xc, yc = x.clone().requires_grad_(gx and want_grad), y.clone().requires_grad_(gy and want_grad)
                 xg, yg = x.to(dev).requires_grad_(gx and want_grad), y.to(dev).requires_grad_(gy and want_grad)
                 pos_gpu = {k: v.to(dev) for k, v in pos_args.items()} if rep == 0 or rng.random() < 0.5 else pos_gpu
-                want = cpu_mod(xc, yc, **pos_args, **kwargs)
+                pos_cpu = pos_args
+                if gp:   # fresh leaves on both sides (a level tie moves no position gradient: the second member of a tie has zero width)
+                    pos_cpu = {k: v.clone().requires_grad_(True) for k, v in pos_args.items()}
+                    pos_gpu = {k: v.to(dev).requires_grad_(True) for k, v in pos_args.items()}
+                want = cpu_mod(xc, yc, **pos_cpu, **kwargs)
                 got = gpu_mod(xg, yg, **pos_gpu, **kwargs)
                 if got.shape != want.shape:
                     failures.append(("SHAPE", desc)); verbose and print("SHAPE", desc, tuple(got.shape), tuple(want.shape)); ok = False; break
@@ -72,10 +85,18 @@ def run(budget=60.0, seed0=0, max_cases=None, verbose=True, grad_tol=2e-3):
                 worst_l = max(worst_l, el)
                 if not el <= 3e-5:
                     failures.append(("LOSS", desc, el)); verbose and print("LOSS", desc, "rep", rep, "err", el); ok = False; break
-                if want_grad and want.requires_grad:
+                if (want_grad or gp) and want.requires_grad:
                     w = torch.rand(want.shape, generator=g)
                     (want * w).sum().backward()
                     (got * w.to(dev)).sum().backward()
+                    if gp:
+                        for name in ("x_pos", "y_pos"):
+                            a, b = pos_gpu[name].grad, pos_cpu[name].grad
+                            gs = float(b.abs().max()) + 1e-30
+                            eg = float((a.cpu() - b).abs().max()) / gs
+                            worst_g = max(worst_g, eg) if eg <= grad_tol else worst_g
+                            if not eg <= 2e-4:
+                                failures.append(("PGRAD", desc, name, eg)); verbose and print("PGRAD", name, desc, "rep", rep, "err / max", eg); ok = False
                     for name, a, b in (("x", xg, xc), ("y", yg, yc)):
                         if b.grad is None:
                             continue
