@@ -30,7 +30,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 6                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 7                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -94,6 +94,10 @@ EXPORTS = {
                                                  _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "sot_spec_distance_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                   ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp]),
+    "sot_spec_distance_rows_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                      ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "sot_spec_distance_rows_backward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                       ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp]),
     "sot_stft_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "sot_stft_mag_forward_pair": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int,
                                                  ctypes.c_int, _vp, _vp]),
@@ -693,14 +697,25 @@ def stft_mag_backward(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop
 
 
 def spec_distance_forward(target: torch.Tensor, value: torch.Tensor, mag_weight: float, logmag_weight: float, eps: float = 1e-5,
-                          l2: bool = False, accumulate_into: torch.Tensor = None) -> torch.Tensor:
+                          l2: bool = False, accumulate_into: torch.Tensor = None, per_row: bool = False) -> torch.Tensor:
     """0-d fp32: mag_weight * mean D(t - v) + logmag_weight * mean D(slog t - slog v) (sot_spec_distance_forward);
-    accumulate_into: an existing 0-d fp32 device tensor the distance is added to (and that is returned)."""
+    accumulate_into: an existing 0-d fp32 device tensor the distance is added to (and that is returned).
+    per_row: one value per leading index instead ([rows] fp32; sot_spec_distance_rows_forward)."""
     require_hip(target, value)
     lib = load()
     target, value = target.contiguous(), value.contiguous()
     if target.shape != value.shape or target.numel() == 0:
         raise RuntimeError("spec_distance_forward expects two non-empty tensors of the same shape")
+    if per_row:
+        rows = target.shape[0]
+        out = accumulate_into if accumulate_into is not None else torch.empty(rows, dtype=torch.float32, device=target.device)
+        if out.numel() != rows or not out.is_contiguous():
+            raise RuntimeError("spec_distance_forward: accumulate_into must hold one contiguous element per row")
+        with _on_device(target.device):
+            check(lib.sot_spec_distance_rows_forward(target.data_ptr(), value.data_ptr(), rows, target.numel() // rows, float(mag_weight),
+                                                     float(logmag_weight), float(eps), int(bool(l2)), out.data_ptr(),
+                                                     0 if accumulate_into is None else 1, stream_ptr(target.device)))
+        return out
     if accumulate_into is not None:
         require_hip(accumulate_into)
         if accumulate_into.numel() != 1:
@@ -715,12 +730,22 @@ def spec_distance_forward(target: torch.Tensor, value: torch.Tensor, mag_weight:
 
 
 def spec_distance_backward(target, value, mag_weight, logmag_weight, upstream, grad_scale=1.0, eps=1e-5, l2=False, need_target=False,
-                           need_value=True):
+                           need_value=True, per_row=False):
     require_hip(target, value, upstream)
     lib = load()
     target, value = target.contiguous(), value.contiguous()
     gt = torch.empty_like(target) if need_target else None
     gv = torch.empty_like(value) if need_value else None
+    if per_row:
+        rows = target.shape[0]
+        up = upstream.contiguous()
+        if up.numel() != rows:
+            raise RuntimeError("spec_distance_backward: one upstream gradient per row")
+        with _on_device(target.device):
+            check(lib.sot_spec_distance_rows_backward(target.data_ptr(), value.data_ptr(), rows, target.numel() // rows, float(mag_weight),
+                                                      float(logmag_weight), float(eps), int(bool(l2)), up.data_ptr(), float(grad_scale), _ptr(gt),
+                                                      _ptr(gv), stream_ptr(target.device)))
+        return gt, gv
     with _on_device(target.device):
         check(lib.sot_spec_distance_backward(target.data_ptr(), value.data_ptr(), target.numel(), float(mag_weight), float(logmag_weight),
                                              float(eps), int(bool(l2)), upstream.contiguous().data_ptr(), float(grad_scale), _ptr(gt), _ptr(gv),

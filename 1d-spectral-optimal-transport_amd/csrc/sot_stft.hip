@@ -1246,6 +1246,56 @@ __global__ __launch_bounds__(kThreads) void spec_distance_backward_kernel(const 
     }
 }
 
+// The same distance PER ROW (MSSLoss called with dims = the two spectrogram axes: one value per clip, losses.py:406-425 with
+// mean_difference's `dims`): row r owns `count` consecutive magnitudes; one workgroup per row, thread t adds elements t, t + 1024, ...
+// in fp64, then a fixed tree: deterministic.  Backward: elementwise with the row's own upstream gradient.
+constexpr int kRowDistThreads = 1024;
+__global__ __launch_bounds__(kRowDistThreads) void spec_distance_rows_kernel(const DistArgs a)
+{
+    __shared__ double red[kRowDistThreads];
+    const float* t_ = a.target + (int64_t)blockIdx.x * a.count;
+    const float* v_ = a.value + (int64_t)blockIdx.x * a.count;
+    double acc_m = 0.0, acc_l = 0.0;
+    for (int64_t i = threadIdx.x; i < a.count; i += kRowDistThreads) {
+        const float t = t_[i], v = v_[i];
+        if (a.mag_weight > 0.0f) { const float d = t - v; acc_m += a.l2 ? (double)(d * d) : (double)fabsf(d); }
+        if (a.logmag_weight > 0.0f) { const float d = safe_logf(t, a.eps) - safe_logf(v, a.eps); acc_l += a.l2 ? (double)(d * d) : (double)fabsf(d); }
+    }
+    red[threadIdx.x] = (double)a.mag_weight * acc_m + (double)a.logmag_weight * acc_l;
+    __syncthreads();
+    for (int off = kRowDistThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float d = (float)(red[0] / (double)a.count);
+        a.out[blockIdx.x] = a.accumulate ? a.out[blockIdx.x] + d : d;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void spec_distance_rows_backward_kernel(const DistArgs a, int64_t rows)
+{
+    const int64_t total = rows * a.count;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const float gs = a.upstream[i / a.count] * a.grad_scale / (float)a.count;
+        const float t = a.target[i], v = a.value[i];
+        float gt = 0.0f, gv = 0.0f;
+        if (a.mag_weight > 0.0f) {
+            const float d = t - v;
+            const float g = a.l2 ? 2.0f * d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+            gt += a.mag_weight * g; gv -= a.mag_weight * g;
+        }
+        if (a.logmag_weight > 0.0f) {
+            const float d = safe_logf(t, a.eps) - safe_logf(v, a.eps);
+            const float g = a.l2 ? 2.0f * d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+            gt += (t <= a.eps) ? 0.0f : a.logmag_weight * g / t;
+            gv -= (v <= a.eps) ? 0.0f : a.logmag_weight * g / v;
+        }
+        if (a.grad_target) a.grad_target[i] = gs * gt;
+        if (a.grad_value) a.grad_value[i] = gs * gv;
+    }
+}
+
 constexpr int kDistBlocks = 1024;
 
 static int ilog2_exact(int v)
@@ -1598,6 +1648,38 @@ int sot_spec_distance_backward(const float* target, const float* value, int64_t 
     const int grid = (int)(need < 256 * 32 ? need : 256 * 32);
     (void)hipGetLastError();
     hipLaunchKernelGGL(spec_distance_backward_kernel, dim3(grid), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+int sot_spec_distance_rows_forward(const float* target, const float* value, int64_t rows, int64_t count_per_row, float mag_weight,
+                                   float logmag_weight, float eps, int l2, float* out, int accumulate, void* stream)
+{
+    using namespace sot_stft;
+    if (rows < 1 || count_per_row < 1 || rows > 0x7fffffff) return SOT_ERR_BAD_SHAPE;
+    if (target == nullptr || value == nullptr || out == nullptr) return SOT_ERR_NULL_POINTER;
+    DistArgs a{};
+    a.target = target; a.value = value; a.count = count_per_row; a.mag_weight = mag_weight; a.logmag_weight = logmag_weight; a.eps = eps;
+    a.l2 = l2; a.out = out; a.accumulate = accumulate;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(spec_distance_rows_kernel, dim3((unsigned)rows), dim3(kRowDistThreads), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
+int sot_spec_distance_rows_backward(const float* target, const float* value, int64_t rows, int64_t count_per_row, float mag_weight,
+                                    float logmag_weight, float eps, int l2, const float* upstream, float grad_scale, float* grad_target,
+                                    float* grad_value, void* stream)
+{
+    using namespace sot_stft;
+    if (rows < 1 || count_per_row < 1) return SOT_ERR_BAD_SHAPE;
+    if (target == nullptr || value == nullptr || upstream == nullptr) return SOT_ERR_NULL_POINTER;
+    if (grad_target == nullptr && grad_value == nullptr) return SOT_OK;
+    DistArgs a{};
+    a.target = target; a.value = value; a.count = count_per_row; a.mag_weight = mag_weight; a.logmag_weight = logmag_weight; a.eps = eps;
+    a.l2 = l2; a.upstream = upstream; a.grad_scale = grad_scale; a.grad_target = grad_target; a.grad_value = grad_value;
+    const int64_t need = (rows * count_per_row + kThreads - 1) / kThreads;
+    const int grid = (int)(need < 256 * 32 ? need : 256 * 32);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(spec_distance_rows_backward_kernel, dim3(grid), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), a, rows);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

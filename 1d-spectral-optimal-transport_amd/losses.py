@@ -521,8 +521,9 @@ class _MultiScaleSpectral(torch.autograd.Function):
     STFT backward) and accumulates the audio gradients."""
 
     @staticmethod
-    def forward(ctx, target_audio, audio, fft_sizes, mag_weight, logmag_weight, l2):
+    def forward(ctx, target_audio, audio, fft_sizes, mag_weight, logmag_weight, l2, per_item=False):
         from . import spectra
+        ctx.per_item = per_item   # one value per clip (`dims` = the two spectrogram axes) instead of the scalar
         target_audio, audio = target_audio.contiguous(), audio.contiguous()
         total = None
         saved, specs = [], []
@@ -537,7 +538,7 @@ class _MultiScaleSpectral(torch.autograd.Function):
                     t, v = nat.stft_mag_forward_pair(target_audio, audio, win, size, hop)   # one launch for both signals
             else:
                 t, v = nat.stft_mag_forward(target_audio, win, size, hop), nat.stft_mag_forward(audio, win, size, hop)
-            total = nat.spec_distance_forward(t, v, mag_weight, logmag_weight, 1e-5, l2, accumulate_into=total)   # total += d
+            total = nat.spec_distance_forward(t, v, mag_weight, logmag_weight, 1e-5, l2, accumulate_into=total, per_row=per_item)   # total += d
             saved += [t, v]
             specs.append(cplx)
         have = [c is not None for c in specs]
@@ -554,26 +555,27 @@ class _MultiScaleSpectral(torch.autograd.Function):
         cplx_iter = iter(cplx_list)
         cplx = [next(cplx_iter) if h else None for h in have]
         need_t, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g = g.float().reshape(1)
+        g = g.float().reshape(-1).contiguous()   # one element, or one per clip
         grad_t = grad_v = None   # the first scale's kernel writes the gradient, the later ones add to it
         for i, size in enumerate(fft_sizes):
             hop = int(size * (1.0 - 0.75))
             win = spectra._cached_window(None, size, audio.device)
             t, v = saved[2 * i], saved[2 * i + 1]
-            gt, gv = nat.spec_distance_backward(t, v, mag_weight, logmag_weight, g, 1.0, 1e-5, l2, need_target=need_t, need_value=need_v)
+            gt, gv = nat.spec_distance_backward(t, v, mag_weight, logmag_weight, g, 1.0, 1e-5, l2, need_target=need_t, need_value=need_v,
+                                                per_row=ctx.per_item)
             if need_v:
                 grad_v = nat.stft_mag_backward(audio, win, size, hop, gv, accumulate_into=grad_v, spec=cplx[i])
             if need_t:
                 grad_t = nat.stft_mag_backward(target_audio, win, size, hop, gt, accumulate_into=grad_t)
-        return grad_t, grad_v, None, None, None, None
+        return grad_t, grad_v, None, None, None, None, None
 
 
 class MSSLoss(torch.nn.Module):
     """Multi-scale spectrogram loss, the reference's `losses.MSSLoss` (losses.py:365-425): for each FFT
     size the magnitude STFT (hann window, 75 % overlap, end-padded, normalized: features.compute_mag) of target and estimate,
     `mag_weight * mean D(t - v) + logmag_weight * mean D(safe_log t - safe_log v)` with D = |.| ('L1') or (.)^2 ('L2'),
-    summed over the sizes.  On the GPU everything runs in HIP kernels behind one autograd node; `dims` other than None, FFT
-    sizes the kernels do not cover and CPU tensors take the same composition on torch ops."""
+    summed over the sizes.  On the GPU everything runs in HIP kernels behind one autograd node (also with `dims` = the two spectrogram
+    axes: one value per clip); any other `dims`, FFT sizes the kernels do not cover and CPU tensors take the same composition on torch ops."""
 
     def __init__(self, fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type="L1", mag_weight=0.0, logmag_weight=0.0):
         super().__init__()
@@ -588,16 +590,19 @@ class MSSLoss(torch.nn.Module):
         if kind not in ("L1", "L2"):
             raise ValueError("Loss type ({}), must be " '"L1", "L2" '.format(kind))   # losses.py:36
         dims = kwargs.get("dims", None)
-        native_ok = (audio.is_cuda and target_audio.is_cuda and dims is None and audio.ndim == 2 and audio.shape == target_audio.shape and
+        # `dims` = the two spectrogram axes of [batch, freq, frames] (one value per clip): the per-row distance kernels.  (Any other
+        # subset keeps an axis whose length differs from scale to scale -- with more than one FFT size the reference's `loss +=` fails.)
+        per_item = dims is not None and not isinstance(dims, int) and sorted(d % 3 for d in dims) == [1, 2]
+        native_ok = (audio.is_cuda and target_audio.is_cuda and (dims is None or per_item) and audio.ndim == 2 and audio.shape == target_audio.shape and
                      (self.mag_weight > 0 or self.logmag_weight > 0) and
                      all(spectra.hip_stft_supported(s, int(s * 0.25), audio.shape[1]) for s in self.fft_sizes))
         if audio.is_cuda and not native_ok:
             warn_once(("mss", dims is not None, self.fft_sizes),
-                      "MSSLoss: this call runs the torch composition instead of the HIP kernels (`dims` given, FFT sizes outside "
+                      "MSSLoss: this call runs the torch composition instead of the HIP kernels (`dims` other than the two spectrogram axes, FFT sizes outside "
                       "64..4096, shapes that differ, or both weights zero)")
         if native_ok:
             return _MultiScaleSpectral.apply(target_audio.float(), audio.float(), self.fft_sizes, float(self.mag_weight),
-                                             float(self.logmag_weight), kind == "L2")
+                                             float(self.logmag_weight), kind == "L2", per_item)
         loss = 0.0
         for size in self.fft_sizes:
             hop = int(size * (1.0 - 0.75))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 6   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 7   /* bumped on every change of a signature below; the binding checks it */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -338,6 +338,16 @@ int sot_spec_distance_forward(const float *target, const float *value, int64_t c
 int sot_spec_distance_backward(const float *target, const float *value, int64_t count, float mag_weight,
                                float logmag_weight, float eps, int l2, const float *upstream, float grad_scale,
                                float *grad_target, float *grad_value, void *stream);
+/* The same distance PER ROW: out[r] for r < rows over the `count_per_row` consecutive magnitudes of row r -- MSSLoss called with
+ * `dims` = the two spectrogram axes (one value per clip; losses.py:406-425 hands `dims` to mean_difference, losses.py:7-36).
+ * One workgroup per row, fixed-order fp64 sums; upstream: [rows]. */
+int sot_spec_distance_rows_forward(const float *target, const float *value, int64_t rows, int64_t count_per_row,
+                                   float mag_weight, float logmag_weight, float eps, int l2, float *out /* [rows] */,
+                                   int accumulate, void *stream);
+int sot_spec_distance_rows_backward(const float *target, const float *value, int64_t rows, int64_t count_per_row,
+                                    float mag_weight, float logmag_weight, float eps, int l2,
+                                    const float *upstream /* [rows] */, float grad_scale,
+                                    float *grad_target, float *grad_value, void *stream);
 
 #ifdef __cplusplus
 }

@@ -285,6 +285,45 @@ def test_mssloss_hip_matches_reference(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(MSS_CASES))
+def test_mssloss_per_clip_dims_runs_the_hip_kernels(tag):
+    """MSSLoss(..., dims=(1, 2)) -- one value per clip, the only `dims` that works with more than one FFT size in the reference
+    (losses.py:406-425: `loss +=` over scales of different spectrogram shapes) -- runs the per-row distance kernels
+    (sot_spec_distance_rows_*): values against the same module on CPU tensors (torch composition = the reference's ops), gradients
+    against it with the tolerances of test_mssloss_hip_matches_reference, no warning about a torch route, deterministic."""
+    import warnings
+    from gpu_util import device, native
+    from sot_amd.losses import MSSLoss
+    native()
+    fx = _fx()
+    ax = torch.as_tensor(fx["mss_audio_x"])
+    ay = torch.as_tensor(fx["mss_audio_y"])
+    mod = MSSLoss(**MSS_CASES[tag])
+    w = torch.linspace(0.5, 1.5, ax.shape[0])
+    yc = ay.clone().requires_grad_(True)
+    want = mod(ax, yc, dims=(1, 2))
+    (want * w).sum().backward()
+    yd = ay.to(device()).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = mod(ax.to(device()), yd, dims=[-1, -2])
+    assert got.shape == want.shape == (ax.shape[0],)
+    (got * w.to(device())).sum().backward()
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * float(want.detach().abs().max())
+    a, b = yd.grad.cpu().numpy(), yc.grad.numpy()
+    if MSS_CASES[tag]["logmag_weight"] == 0:
+        assert np.abs(a - b).max() <= 5e-3 * np.abs(b).max()
+    else:
+        assert np.linalg.norm(a - b) <= 6e-2 * np.linalg.norm(b)
+    yd2 = ay.to(device()).requires_grad_(True)
+    got2 = mod(ax.to(device()), yd2, dims=(1, 2))
+    (got2 * w.to(device())).sum().backward()
+    assert torch.equal(got2, got) and torch.equal(yd2.grad, yd.grad)
+    # the scalar form is the mean of the per-clip values (equal clip sizes)
+    assert abs(float(mod(ax.to(device()), ay.to(device()))) - float(got.mean())) <= 2e-6 * abs(float(got.mean()))
+
+
+@pytest.mark.gpu
 def test_spec_distance_kernels_against_torch():
     from gpu_util import device, native
     nat = native()
