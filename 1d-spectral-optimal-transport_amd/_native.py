@@ -22,6 +22,7 @@ FLAG_PRENORMALIZED = 16    # weights are used as given (the functional form wass
 FLAG_NO_SPECIALIZE = 32  # diagnostic: generic forward kernel only (include/sot_hip.h)
 FLAG_SAME_GRID = 64      # both measures live on one grid: the p = 1 forward runs the merge-free kernel (include/sot_hip.h)
 FLAG_NO_AREA = 128       # diagnostic: ignore FLAG_SAME_GRID
+FLAG_TIE_FREE_GRADIENT = 256   # opt-in: merge-free p = 1 training form (include/sot_hip.h: SOT_FLAG_TIE_FREE_GRADIENT)
 
 SOT_OK = 0
 SOT_ERR_INVALID_P = -1
@@ -30,7 +31,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 7                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 8                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p

@@ -1145,6 +1145,8 @@ hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs
 hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
 hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, hipStream_t s);
 hipError_t dispatch_area_full(const FwdArgs& a, hipStream_t s);
+hipError_t dispatch_area_train(const BwdArgs& b, hipStream_t s);
+bool area_train_supports(int n);
 bool forward_full_supports(int n, bool aligned16);
 bool backward_full_supports(int n, bool aligned16);
 int full_rt_capacity(int n);   // capacity of the compile-time geometry that takes a run-time row length n (0: none)
@@ -1184,6 +1186,8 @@ template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, cons
 hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_area_full(const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+hipError_t dispatch_area_train(const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+bool area_train_supports(int) { return false; }
 bool forward_full_supports(int, bool) { return false; }
 bool backward_full_supports(int, bool) { return false; }
 int full_rt_capacity(int) { return 0; }
@@ -1859,7 +1863,13 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
         if (mean_tail != nullptr) b.f.mt = *mean_tail;
         if (fused) *fused = true;
     }
-    const hipError_t e = full       ? dispatch_backward_full(l.cfg, l.pm, b, l.s)
+    // p = 1 on one grid, gradient w.r.t. y alone, no cutoff: the merge-free training form (sot_forward_full.inc: sot_area_train_kernel)
+    // -- OPT-IN (SOT_FLAG_TIE_FREE_GRADIENT): at exactly tied levels it returns the derivative in the CDF values, not the reference's
+    // float32 tie-order artefact
+    const bool area = full && gx == nullptr && l.pm == 1 && area_train_supports(pr->n) && (pr->flags & SOT_FLAG_SAME_GRID) && (pr->flags & SOT_FLAG_TIE_FREE_GRADIENT) &&
+                      !(pr->flags & (SOT_FLAG_LIMIT_Q | SOT_FLAG_NO_AREA));
+    const hipError_t e = area       ? dispatch_area_train(b, l.s)
+                         : full     ? dispatch_backward_full(l.cfg, l.pm, b, l.s)
                          : full_rt  ? dispatch_backward_full_rt(l.pm, b, l.s)
                          : l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s)
                                     : dispatch_backward<false>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s);

@@ -365,6 +365,10 @@ class Wasserstein1D(torch.nn.Module):
         self.limit_quantile_range = kwargs.get("limit_quantile_range", False)
         self.hinge = kwargs.get("hinge", False)
         self.square_dist = kwargs.get("square_dist", False)
+        # NOT a reference argument (default: the reference's behaviour).  True: for p = 1 on one grid the gradient w.r.t. y comes from the
+        # merge-free training form -- the derivative of the loss in the CDF values, which is what float64 autograd of the reference
+        # returns; at exactly tied float32 levels the reference's float32 autograd returns a tie-order artefact instead
+        self.tie_free_gradient = bool(kwargs.get("tie_free_gradient", False))
         # unknown kwargs (e.g. cumsum_only from the paper YAMLs) are accepted and ignored, losses.py:96
         if fixed_x is not None:
             self.register_buffer("fixed_x", torch.linspace(0, 1, fixed_x))
@@ -408,6 +412,8 @@ class Wasserstein1D(torch.nn.Module):
         dont_normalize = bool(kwargs.get("dont_normalize", False) or self.dont_normalize)
         limit_q = bool(kwargs.get("limit_quantile_range", False) or self.limit_quantile_range)
         flags = _flags(self.square_dist, dont_normalize, limit_q, self.require_sort)
+        if getattr(self, "tie_free_gradient", False):
+            flags |= nat.FLAG_TIE_FREE_GRADIENT
 
         x, y, x_pos_, y_pos_ = _prepare(x, y, x_pos_, y_pos_, checked=True)
         plan = self._plans.get(x_pos_, y_pos_) if (self.require_sort and x_pos_.ndim == 1) else None
@@ -439,7 +445,8 @@ class Wasserstein1D(torch.nn.Module):
         return loss
 
     def _settings(self):
-        return (self.p, self.square_dist, self.dont_normalize, self.limit_quantile_range, self.require_sort, self.hinge)
+        return (self.p, self.square_dist, self.dont_normalize, self.limit_quantile_range, self.require_sort, self.hinge,
+                getattr(self, "tie_free_gradient", False))
 
     def forward(self, x, y, x_pos=None, y_pos=None, **kwargs):
         # The hot call, recognised before anything else is looked at: the SAME position tensors as last time (a persistent grid or the

@@ -233,6 +233,22 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         out[f"b{B}n{N}_p1_forward_merge_kernel"] = entry(timed(p1_merge, n), forward_kernel_name(N, "p1", same_grid=False, batch=B), B * (8 * N + 4),
                                                          l3_resident=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
 
+    # (0a') the p = 1 TRAINING FORM (loss, batch mean and d mean / d y in one call) on the headline shape: the default runs the merge walk (the
+    #       reference's float32 tie order); with the opt-in SOT_FLAG_TIE_FREE_GRADIENT (Wasserstein1D(..., tie_free_gradient=True)) it is merge-free
+    def p1_train(extra):
+        def call(i):
+            x2, y2, xp, yp, flags, plan, _ = pm[i % len(pm)]
+            nat.loss_and_grad(x2, y2, xp, yp, 1.0, flags | extra, plan)
+        return call
+
+    with torch.no_grad():
+        l3p = False if len(sets) * 2 * B * N * 4 > 2**28 else True
+        out[f"b{B}n{N}_p1_loss_and_grad"] = entry(timed(p1_train(0), n), forward_kernel_name(N, "p1", backward=True, batch=B) + " + batch mean (merge walk: the reference's tie order)",
+                                                  B * (12 * N + 4), l3_resident=l3p)
+        out[f"b{B}n{N}_p1_loss_and_grad_tie_free"] = entry(timed(p1_train(nat.FLAG_TIE_FREE_GRADIENT), n),
+                                                           "sot_area_train_kernel<256, 8, 1, false, 0> + batch mean (opt-in: merge-free, derivative in the CDF values at tied levels)"
+                                                           if N == 2048 else "sot_area_train_kernel (opt-in)", B * (12 * N + 4), l3_resident=l3p)
+
     # (0b) the headline workload THROUGH THE MODULE (the timed step is a pre-bound C call): mod(x, y, x_pos=..., y_pos=...)
     #      launched from Python under no_grad, forward + batch mean per call -- the hot-call cache and the C++ host path included
     with torch.no_grad():

@@ -162,6 +162,90 @@ def test_full_row_backward_matches_generic_and_oracle(N, B, flags, p):
         assert np.max(np.abs(got - want) / scale) <= 1e-5
 
 
+@pytest.mark.parametrize("N,B", [(512, 530), (1024, 301), (2048, 200), (4096, 67), (129, 700), (257, 531), (513, 300)])
+@pytest.mark.parametrize("flags", [8, 8 | 1, 8 | 2, 8 | 1 | 2])
+@pytest.mark.parametrize("kind", ["peaky", "uniform", "permuted"])
+def test_merge_free_training_form_p1(N, B, flags, kind):
+    """OPT-IN (SOT_FLAG_TIE_FREE_GRADIENT; Wasserstein1D(..., tie_free_gradient=True)): p = 1 on one grid, gradient w.r.t. y alone, from
+    sot_area_train_kernel (round 4) -- no merge, one compare per element and an fp64 suffix scan.  It returns the derivative of
+    loss = sum_i |U_i - V_i| (x_{i+1} - x_i) in the float32 CDF values, i.e. what autograd gives for that formula on the reference's own
+    CDFs (checked on every row at 1e-5 of the row's largest entry) and what float64 autograd of the reference gives; the reference's
+    float32 autograd (and the oracle, and the merge backward kernel, which reproduce its stable tie order) differs from it only on rows
+    with exactly tied levels -- checked: on rows WITHOUT any tie all three agree.  The row losses are the merge-free forward kernel's bit
+    for bit; without the flag the call runs the merge backward as before."""
+    from oracle.inputs import gen_inputs
+    from oracle import sot_oracle as so
+    nat = native()
+    x, y = gen_inputs("peaky" if kind != "uniform" else "uniform", B, N, N, 1977 + N)
+    x, y = x.to(device()), y.to(device())
+    pos = torch.linspace(0, 1, N)
+    if kind == "permuted":
+        pos = pos[torch.randperm(N, generator=torch.Generator().manual_seed(N))]
+    pos = pos.to(device()); pos2 = pos.clone()
+    plan = nat.PositionPlan(pos, pos2)
+    assert plan.same_grid()
+    TF = nat.FLAG_TIE_FREE_GRADIENT
+    g = torch.linspace(0.5, 1.5, B).to(device())
+    _, gy = nat.backward_rows(x, y, pos, pos2, 1.0, flags | TF, g, need_gx=False, plan=plan, grad_scale=0.25)   # merge-free
+    _, gm = nat.backward_rows(x, y, pos, pos2, 1.0, flags, g, need_gx=False, plan=plan, grad_scale=0.25)        # merge walk (default)
+    _, wy = so.backward(x.cpu().numpy(), y.cpu().numpy(), pos.cpu().numpy(), pos.cpu().numpy(), (0.25 * g).cpu().numpy(), p=1.0, flags=flags & 15)
+    scale = np.abs(wy).max(axis=1, keepdims=True) + 1e-30
+    assert np.max(np.abs(gm.cpu().numpy() - wy) / scale) <= 1e-5, "the default (merge backward) keeps the reference's tie order"
+    # autograd of the area formula on the reference's own float32 CDFs (torch CPU: the same bits as the kernel's)
+    xc, yc = x.cpu(), y.cpu().requires_grad_(True)
+    ps, order = torch.sort(pos.cpu())
+    sq, dn = bool(flags & 1), bool(flags & 2)
+    xa, ya = (xc ** 2, yc ** 2) if sq else (xc, yc)
+    mass_x = xa.sum(1, keepdim=True)
+    eps = torch.tensor(1e-7)
+    a = xa / torch.where(mass_x <= 1e-7, eps, mass_x)
+    mass_y = mass_x if dn else ya.sum(1, keepdim=True)
+    bb = ya / torch.where(mass_y <= 1e-7, eps, mass_y)
+    U, V = torch.cumsum(a[:, order], 1), torch.cumsum(bb[:, order], 1)
+    loss = ((U - V).abs()[:, :-1] * (ps[1:] - ps[:-1])).sum(1)
+    (loss * 0.25 * g.cpu()).sum().backward()
+    want = yc.grad.numpy()
+    wscale = np.abs(want).max(axis=1, keepdims=True) + 1e-30
+    assert np.max(np.abs(gy.cpu().numpy() - want) / wscale) <= 1e-5, "merge-free training form vs autograd of the area formula"
+    # rows without any tied level (within U, within V, across): every convention gives the same gradient
+    lv = torch.sort(torch.cat((U, V), 1).detach(), dim=1)[0]
+    clean = (lv[:, 1:-1] != lv[:, :-2]).all(dim=1).numpy()   # (the last two levels, U_last and V_last, often are both 1.0: cell width 0 there)
+    if clean.any():   # (exact coincidences U_i == V_j grow like N^2 / 2^24 per row, squares push small weights below the CDF's resolution)
+        assert np.max((np.abs(gy.cpu().numpy() - wy) / scale)[clean]) <= 2e-5, "tie-free rows: merge-free form == oracle"
+    mean, rows, gy2 = nat.loss_and_grad(x, y, pos, pos2, 1.0, flags | TF, plan)
+    fwd = nat.forward_rows(x, y, pos, pos2, 1.0, flags, plan)
+    if N == 129:   # the forward runs two rows per wave there (sot_area_half_kernel: another grouping of the thread-local sums)
+        torch.testing.assert_close(rows, fwd, rtol=2e-6, atol=1e-12)
+    else:
+        assert torch.equal(rows, fwd)
+    _, gy3 = nat.backward_rows(x, y, pos, pos2, 1.0, flags | TF, torch.ones(1, device=device()), need_gx=False, plan=plan, grad_scale=1.0 / B)
+    assert torch.equal(gy2, gy3)
+    assert abs(float(mean) - float(rows.double().mean())) <= 1e-6 * abs(float(mean)) + 1e-12
+
+
+@pytest.mark.gpu
+def test_module_tie_free_gradient_option():
+    """Wasserstein1D(p=1, tie_free_gradient=True): same loss as the default module bit for bit, gradients equal on rows without ties, the
+    training step runs sot_area_train_kernel (timing is in bench.py); the default module is untouched."""
+    from sot_amd.losses import Wasserstein1D
+    native()
+    g = torch.Generator(device=device()).manual_seed(9)
+    x = torch.rand(64, 2048, device=device(), generator=g) + 0.05
+    y0 = torch.rand(64, 2048, device=device(), generator=g) + 0.05
+    pos = torch.linspace(0, 1, 2048, device=device()); pos2 = pos.clone()
+    outs = []
+    for opt in (False, True):
+        mod = Wasserstein1D(p=1, tie_free_gradient=opt).to(device())
+        y = y0.clone().requires_grad_(True)
+        loss = mod(x, y, x_pos=pos, y_pos=pos2)
+        loss.backward()
+        outs.append((loss.detach(), y.grad))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-6, atol=0)   # the default training step accumulates the loss on the merge walk
+    d = (outs[0][1] - outs[1][1]).abs().amax(dim=1) / outs[0][1].abs().amax(dim=1)
+    assert float(d.median()) <= 1e-5   # most rows of bounded-away-from-zero weights have no exact tie
+    assert float(d.max()) <= 5e-2
+
+
 @pytest.mark.parametrize("N,B", [(129, 1500), (257, 1031), (513, 300), (1025, 261), (2049, 133)])
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 2 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 @pytest.mark.parametrize("kind", ["peaky", "uniform"])
