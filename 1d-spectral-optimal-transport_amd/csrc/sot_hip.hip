@@ -317,9 +317,12 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
     const bool need_sort = row_any<G / kWave>(unsorted != 0);  // also the barrier after the loads
     if (need_sort) {
         if constexpr (MERGE) {
-            // both arrays in one barrier sequence, 16 elements per thread (sot_device.hpp: merge_sort16_kv2); npx + npy <= 32 G
+            // both arrays in one barrier sequence, 16 elements per thread (sot_device.hpp: merge_sort16_kv2): npx + npy <= 2 next_pow2(G CPT), i.e.
+            // one block of 16 per thread for the 8-element geometries, two for 12 / 16 elements per thread (a second, never used block
+            // costs the 256 x 8 kernel 32 registers)
+            constexpr int MAXB = (CPT > 8) ? 2 : 1;
             const SortJob jx{c.PX, IX, n, npx}, jy{c.PY, IY, m, npy};
-            merge_sort16_kv2<2>(jx, jy, t, G, [] { row_sync<G / kWave>(); });
+            merge_sort16_kv2<MAXB>(jx, jy, t, G, [] { row_sync<G / kWave>(); });
         } else {
             bitonic_sort_kv(c.PX, IX, npx, t, G, [] { row_sync<G / kWave>(); });
             bitonic_sort_kv(c.PY, IY, npy, t, G, [] { row_sync<G / kWave>(); });
@@ -544,8 +547,14 @@ __device__ __forceinline__ int lower_rank(const float* A, int len, float q)
 #ifndef SOT_CSR_MIN_WAVES
 #define SOT_CSR_MIN_WAVES 4
 #endif
+// Register cap of the per-row-position FORWARD kernels on 256-thread workgroups (the in-register block sort of merge_sort16_kv2 pushes them
+// to 168 ... 212 VGPRs = two waves per SIMD, i.e. two of the four workgroups the LDS would hold): SOT_ROWPOS_MIN_WAVES waves per SIMD (7 dwords
+// spilled).  Measured 4096 x 2048 paper mode: unsorted rows 246 -> 192 us, sorted rows 77 -> 63 us (one sort block per thread + the cap).
+#ifndef SOT_ROWPOS_MIN_WAVES
+#define SOT_ROWPOS_MIN_WAVES 3
+#endif
 template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, bool CSR = false, int SQM = 2>
-__global__ __launch_bounds__((G < 256 ? 256 : G), ((CSR && G == 64) ? SOT_CSR_MIN_WAVES : 1)) void sot_forward_kernel(const FwdArgs a)
+__global__ __launch_bounds__((G < 256 ? 256 : G), ((CSR && G == 64) ? SOT_CSR_MIN_WAVES : (ROWPOS && !CSR && G <= 256 && CPT == 8) ? SOT_ROWPOS_MIN_WAVES : 1)) void sot_forward_kernel(const FwdArgs a)
 {
     static_assert(!CSR || (ROWPOS && !VEC && !QUANT), "the CSR form has per-row positions and unaligned rows");
     constexpr int BLOCK = (G < 256 ? 256 : G);
@@ -755,7 +764,7 @@ struct BwdArgs {
 };
 
 template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
-__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const BwdArgs b)
+__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const BwdArgs b)   // (capped at three waves per SIMD like the per-row forward: 76 dwords spilled, 290 -> 449 us)
 {
     constexpr int BLOCK = (G < 256 ? 256 : G);
     constexpr int RPW = BLOCK / G;
@@ -1406,7 +1415,7 @@ __device__ __forceinline__ float cost_slope(float d, int pm, float p)
 }
 
 template <int G, int CPT, bool ROWPOS>
-__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_position_grad_kernel(const PosGradArgs b)
+__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_position_grad_kernel(const PosGradArgs b)   // (capped at three waves per SIMD: 28 dwords spilled, 279 -> 347 us)
 {
     constexpr int BLOCK = (G < 256 ? 256 : G);
     constexpr int RPW = BLOCK / G;
