@@ -553,6 +553,8 @@ __device__ __forceinline__ int lower_rank(const float* A, int len, float q)
 #ifndef SOT_ROWPOS_MIN_WAVES
 #define SOT_ROWPOS_MIN_WAVES 3
 #endif
+// (The generic shared-position kernels of the 2048-point geometry also sit just above a register step in some instantiations -- forward 129 ... 140
+// VGPRs, backward 176 -- but holding them to the step changes nothing: forward 52.8 vs 52.8 us, both-gradient backward 120.1 vs 119.7 us at 8192 x 2048.)
 template <int G, int CPT, bool ROWPOS, bool QUANT, int PM, bool LIM, bool VEC, bool CSR = false, int SQM = 2>
 __global__ __launch_bounds__((G < 256 ? 256 : G), ((CSR && G == 64) ? SOT_CSR_MIN_WAVES : (ROWPOS && !CSR && G <= 256 && CPT == 8) ? SOT_ROWPOS_MIN_WAVES : 1)) void sot_forward_kernel(const FwdArgs a)
 {
@@ -764,7 +766,7 @@ struct BwdArgs {
 };
 
 template <int G, int CPT, bool ROWPOS, int PM, bool LIM, bool VEC>
-__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const BwdArgs b)   // (capped at three waves per SIMD like the per-row forward: 76 dwords spilled, 290 -> 449 us)
+__global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const BwdArgs b)   // (per-row positions capped at three waves per SIMD like the per-row forward: 76 dwords spilled, 290 -> 449 us)
 {
     constexpr int BLOCK = (G < 256 ? 256 : G);
     constexpr int RPW = BLOCK / G;
