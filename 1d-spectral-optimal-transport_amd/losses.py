@@ -599,7 +599,8 @@ class MSSLoss(torch.nn.Module):
         dims = kwargs.get("dims", None)
         # `dims` = the two spectrogram axes of [batch, freq, frames] (one value per clip): the per-row distance kernels.  (Any other
         # subset keeps an axis whose length differs from scale to scale -- with more than one FFT size the reference's `loss +=` fails.)
-        per_item = dims is not None and not isinstance(dims, int) and sorted(d % 3 for d in dims) == [1, 2]
+        per_item = (dims is not None and not isinstance(dims, int) and all(isinstance(d, int) and -3 <= d < 3 for d in dims)
+                    and sorted(d % 3 for d in dims) == [1, 2])
         native_ok = (audio.is_cuda and target_audio.is_cuda and (dims is None or per_item) and audio.ndim == 2 and audio.shape == target_audio.shape and
                      (self.mag_weight > 0 or self.logmag_weight > 0) and
                      all(spectra.hip_stft_supported(s, int(s * 0.25), audio.shape[1]) for s in self.fft_sizes))
