@@ -316,6 +316,14 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
             tpath.module_forward(x2, yv, xpos, ypos, **args).backward()
         return call
 
+    # (0c') the segmented sort on its own (sot_segmented_sort = torch.sort(keys, 1) of losses.py:287-288: values + int64 indices, stable) and the
+    #       gradients w.r.t. per-row positions (sot_w1d_position_grad: one deterministic kernel; no reference call site asks for them)
+    one_pg = torch.ones(1, device=dev)
+    with torch.no_grad():
+        out[f"b{rows_pr}n{N}_segmented_sort"] = entry(timed(lambda i: nat.segmented_sort(prx[i % 2]), n), "sot_segmented_sort_kernel (16 keys per thread, skewed LDS image with sentinels)",
+                                                      rows_pr * 16 * N, l3_resident=True, rows=rows_pr, note="4 B in, 4 + 8 B out per key")
+        out[f"b{rows_pr}n{N}_per_row_position_gradients"] = entry(timed(lambda i: nat.position_grads(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg), n),
+                                                                  "sot_position_grad_kernel<256, 8, true> (sort + CDFs + walk + tails)", rows_pr * (24 * N + 4), l3_resident=True, rows=rows_pr)
     ref = {}
     with torch.no_grad():
         ref["p1_forward_ms"] = timed(torch_ops("p1", B, pos_x, pos_y), 6)
