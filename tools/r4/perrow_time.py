@@ -22,8 +22,12 @@ print("per-row positions forward 4096x2048 (paper mode): %.1f us" % timed(lambda
 sx, sy = torch.sort(px, 1).values, torch.sort(py, 1).values
 print("  rows already sorted: %.1f us" % timed(lambda: nat.forward_rows(x, y, sx, sy, 2.0, 15, None)))
 one = torch.ones(1, device=dev)
-print("per-row positions backward (both gradients): %.1f us" % timed(lambda: nat.backward_rows(x, y, px, py, 2.0, 15, one)))
-print("per-row position gradients: %.1f us" % timed(lambda: nat.position_grads(x, y, px, py, 2.0, 15, one)))
-print("sot_segmented_sort 4096x2048: %.1f us" % timed(lambda: nat.segmented_sort(px)))
+for label, fn in (("per-row positions backward (both gradients)", lambda: nat.backward_rows(x, y, px, py, 2.0, 15, one)),
+                  ("per-row position gradients", lambda: nat.position_grads(x, y, px, py, 2.0, 15, one)),
+                  ("sot_segmented_sort 4096x2048", lambda: nat.segmented_sort(px))):
+    try:
+        print("%s: %.1f us" % (label, timed(fn)))
+    except Exception as exc:   # diagnostic library variants hold a subset of the kernels
+        print("%s: not in this library (%s)" % (label, type(exc).__name__))
 x5, y5, p5a, p5b = x[:, :512].contiguous(), y[:, :512].contiguous(), px[:, :512].contiguous(), py[:, :512].contiguous()
 print("per-row positions forward 4096x512: %.1f us" % timed(lambda: nat.forward_rows(x5, y5, p5a, p5b, 2.0, 15, None)))
