@@ -64,7 +64,8 @@ typedef enum sot_status {
                                       tie-order artefact of the reference's float32 autograd (losses.py:295-298: ranks are constants
                                       to autograd, so a run of equal levels hands its whole gradient to one member).  With it, p == 1
                                       with SOT_FLAG_SAME_GRID and no cutoff gets a MERGE-FREE training form (gradient w.r.t. y alone):
-                                      8192 x 2048 rows 72.7 -> 47.5 us, 16384 x 1025 rows 76 -> 69 us.  Entries away from ties are unchanged; the loss value is      */
+                                      8192 x 2048 rows 72.7 -> 47.5 us, 16384 x 1025 rows 76 -> 69 us.  Gradient entries of rows without tied
+                                      levels are unchanged; the loss value is the merge-free forward kernel's (<= 3e-7 from the merge walk's) */
 
 /* One batch of spectrum pairs.  Mirrors the arguments of Wasserstein1D.forward
  * (losses.py:129) after its [batch,time,N] -> [B,N] reshape (losses.py:157-170). */
