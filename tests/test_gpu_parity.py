@@ -1050,7 +1050,7 @@ def test_config5_full_size_training_step_matches_reference():
     # maximum is a lottery of ties -- a tie between two levels may route a run's gradient to another member, a different valid
     # subgradient, DESIGN section 2 -- whose outcome depends on the last bits of the spectra: 3.9e-4 with the slot STFT kernels of
     # rounds 2-3 (134 clean clips), 1.35e-3 with the one-wave-per-frame forward kernel of round 4 (139 clean clips; the backward kernel
-    # does not change it: tools/r4/run13.sh))
+    # does not change it: round 4 GPU call 13, docs/HISTORY.md §13))
     assert np.median(err[clean]) <= 5e-6 and np.percentile(err[clean], 99) <= 1e-4 and err[clean].max() <= 3e-3
     assert cos >= 0.99                                        # all clips: flipped rows move single clips, not the batch
 

@@ -1,9 +1,11 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of one kernel of library variants: tools/r4/traffic_pass.sh <out> <variant>:<flags>:<p>:<call>:<B>:<N> ...
 # (separate --pmc passes, MI355X_MICROARCH.md "HBM"; FETCH_SIZE x 2 for 16-B-per-lane / wide coalesced streams on gfx950)
+set -eu
+cd "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 export TMPDIR=/tmp
-OUT=gpurun_out/$1; shift
-rm -rf $OUT; mkdir -p $OUT; : > $OUT.txt
+OUT="gpurun_out/${1:?output tag}"; shift
+rm -rf -- "$OUT"; mkdir -p "$OUT"; : > "$OUT.txt"
 for spec in "$@"; do
   IFS=: read v flags p call B N <<< "$spec"
   for c in FETCH_SIZE WRITE_SIZE; do
