@@ -426,6 +426,34 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
     return loss_module(spec_x, spec_y, x_pos=pos[0], y_pos=pos[1])
 
 
+def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop",
+                      sample_rate: float = 16000.0, positions=None) -> torch.Tensor:
+    """The loss block of the reference's `trainer.shared_step` (trainer.py:183-245) for a `MixOfLosses` (or a single loss module):
+    unit-scaled bin frequencies built AFRESH (`x_pos = torch.tensor(transform.get_frequencies()).to(device); x_pos = x_pos / x_pos.max();
+    y_pos = x_pos.clone()`, :192-197), both signals through the transform (`TorchSTFT`, :199-200), `MSSLoss` fed the audio and every
+    other loss the spectra, each `loss_fn(a, b, x_pos=, y_pos=) * weight` (:206-221), the total = sum of `value.mean()` (:231-236).
+    `positions`: a device tensor of bin frequencies to start from instead of the host tensor (a captured step cannot copy from pageable
+    host memory); the division and the clone still run per step.  The caller backpropagates into `x_hat`."""
+    if positions is None:
+        positions = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device)   # torch.tensor(get_frequencies()).to(device)
+    x_pos = positions / positions.max()
+    y_pos = x_pos.clone()
+    spec_x = stft_magnitude(x, n_fft, hop, window)
+    spec_x_hat = stft_magnitude(x_hat, n_fft, hop, window)
+    if hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):   # isinstance(self.loss_fn, losses.MixOfLosses)
+        distance = {}
+        for fn, weight in zip(loss_fn.losses, loss_fn.weights):
+            name = fn.__class__.__name__
+            a, b = (x, x_hat) if name == "MSSLoss" else (spec_x, spec_x_hat)
+            distance[name] = fn(a, b, x_pos=x_pos, y_pos=y_pos) * weight
+        loss = 0
+        for value in distance.values():
+            loss = loss + value.mean()
+        return loss
+    a, b = (x, x_hat) if loss_fn.__class__.__name__ == "MSSLoss" else (spec_x, spec_x_hat)
+    return loss_fn(a, b, x_pos=x_pos, y_pos=y_pos).mean()
+
+
 _METRIC_MODULES = {}
 
 

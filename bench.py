@@ -334,8 +334,8 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
                    "x %d bins; compare: value's ms_per_step (p = 1), extras.b%dn%d_cutoff_forward, _cutoff_module_forward_backward, "
                    "b%dn%d_per_row_positions_forward" % (B, N, B, N, rows_pr, N))
     out["reference_ops_on_this_gpu"] = ref
+    del prx, pry, srx, sry, per_row, per_row_sorted
     torch.cuda.empty_cache()
-    del prx, pry, srx, sry
 
     # (1) the headline shape in the paper's mode (p = 2, square_dist, dont_normalize, limit_quantile_range)
     cut = sot_entries(f"b{B}n{N}", B, N, sets, pos_x, pos_y, l3=False if len(sets) * 2 * B * N * 4 > 2**28 else True)
@@ -437,7 +437,8 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
             l3_resident=True, mean_kept_support=rs["kept"])
         out["config4_b8192n512_csr_forward"] = entry(
             timed(lambda i: wasserstein_1d_csr(xw, xp_, xo, yw, yp_, yo, rs["max_n"], rs["max_m"], **kw), n), "sot_forward_kernel<CSR>",
-            csr_bytes, l3_resident=True, mean_kept_support=rs["kept"])
+            csr_bytes, l3_resident=True, mean_kept_support=rs["kept"], retired=True,
+            note="NOT a product path: the CSR form left the public surface in round 4 (DESIGN.md §8); timed only so the decision stays checkable")
     del xm, ym, xw, xp_, yw, yp_
 
     # (4) BASELINE config 5: 256 harmonic clips -> STFT x2 (n_fft 2048, hop 256, flattop; 16 frames) -> SOT paper mode
@@ -507,6 +508,107 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         except Exception as exc:  # noqa: BLE001 -- a capture that fails must not take the bench line with it
             out[key + "_graph_replay"] = {"error": repr(exc)[:200]}
     out.update(rccl_world1_probe())
+    return out
+
+
+def paper_loss_workloads(dev, nat, timed, n):
+    """The loss block a user of the reference actually runs per step (trainer.py:183-245 with the paper's YAML,
+    paper-experiments/SOT-2048/*/train_config.yaml:73-102): fresh x_pos / y_pos, two TorchSTFT transforms (n_fft 2048, hop 256, flattop),
+    MixOfLosses([MSSLoss(6 scales, L1, mag_weight 1), Wasserstein1D(paper kwargs)], [0.05, 1]), sum of the means, backward() into x_hat --
+    at the paper's batch (64 clips of 4096 samples) and at config 5's (256), eager and replayed from one HIP graph; next to it MSSLoss
+    alone, the SOT slice alone, and the reference's own op sequence (torch.stft / ATen ops) on the same GPU and inputs."""
+    from sot_amd import spectra
+    from sot_amd import _torch_path as tpath
+    from sot_amd.losses import MixOfLosses, MSSLoss, Wasserstein1D
+    out = {}
+    sizes = (2048, 1024, 512, 256, 128, 64)
+    mss = MSSLoss(fft_sizes=sizes, loss_type="L1", mag_weight=1, logmag_weight=0).to(dev)
+    sot = Wasserstein1D(**MODES["cutoff"], require_sort=True).to(dev)
+    mix = MixOfLosses([mss, sot], [0.05, 1]).to(dev)
+    freqs_dev = torch.fft.rfftfreq(2048, d=1.0 / 16000.0).to(dev)
+    seed = torch.ones((), device=dev)
+
+    def replayed(step_fn):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step_fn(0)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step_fn(0)
+        return timed(lambda i: graph.replay(), n)
+
+    def torch_mss(t_audio, v_audio):   # losses.py:365-425 on torch ops (torch.stft = rocFFT)
+        loss = 0.0
+        for size in sizes:
+            hop = int(size * 0.25)
+            t = spectra.stft_magnitude_torch(t_audio, size, hop, None)
+            v = spectra.stft_magnitude_torch(v_audio, size, hop, None)
+            loss = loss + torch.mean(torch.abs(t - v))
+        return loss
+
+    def torch_step(x, e, pos):     # the same block on the reference's ops: torch.stft + losses.py:129-313 as ATen calls
+        x_pos = pos / pos.max()
+        y_pos = x_pos.clone()
+        sx = spectra.stft_magnitude_torch(x, 2048, 256, "flattop")
+        sy = spectra.stft_magnitude_torch(e, 2048, 256, "flattop")
+        w = tpath.module_forward(sx, sy, x_pos, y_pos, p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True,
+                                 require_sort=True, hinge_on=False)
+        return (torch_mss(x, e) * 0.05).mean() + (w * 1).mean()
+
+    for clips in (64, 256):
+        gen = torch.Generator(device=dev).manual_seed(1000 + clips)
+        x = spectra.harmonic_batch(clips, generator=gen, device=dev)
+        hats = [spectra.harmonic_batch(clips, generator=gen, device=dev).requires_grad_(True) for _ in range(2)]
+        io_bytes = 3 * clips * 4096 * 4   # both clips' audio in, the estimate's gradient out: what the block must move
+
+        def full_step(i, fresh_host_positions=True):
+            e = hats[i % 2]
+            e.grad = None
+            spectra.trainer_loss_step(mix, x, e, 2048, 256, "flattop", 16000.0, positions=None if fresh_host_positions else freqs_dev).backward(seed)
+
+        def mss_step(i):
+            e = hats[i % 2]
+            e.grad = None
+            mss(x, e).backward(seed)
+
+        def sot_step(i):
+            e = hats[i % 2]
+            e.grad = None
+            spectra.training_step_slice(sot, x, e).backward(seed)
+
+        def ref_step(i):
+            e = hats[i % 2]
+            e.grad = None
+            torch_step(x, e, freqs_dev).backward(seed)
+
+        def ref_mss_step(i):
+            e = hats[i % 2]
+            e.grad = None
+            torch_mss(x, e).backward(seed)
+
+        def entry(ms, what, **kw):
+            return {"ms": ms, "what": what, "algorithmic_bytes": io_bytes, "frac": io_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "clips": clips, **kw}
+
+        tag = f"{clips}clips"
+        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 verbatim (x_pos from the host every step), eager, launched from Python")
+        out[f"paper_loss_step_{tag}_device_positions"] = entry(timed(lambda i: full_step(i, False), n), "the same with the bin frequencies already on the device (division + clone per step)")
+        out[f"mssloss_forward_backward_{tag}"] = entry(timed(mss_step, n), "MSSLoss(6 scales, L1, mag_weight 1) forward + backward into the estimate, eager")
+        out[f"sot_slice_forward_backward_{tag}"] = entry(timed(sot_step, n), "STFT pair + Wasserstein1D (paper mode) forward + backward, eager (= config 5's slice)")
+        for key, fn in ((f"paper_loss_step_{tag}", lambda i: full_step(i, False)), (f"mssloss_forward_backward_{tag}", mss_step),
+                        (f"sot_slice_forward_backward_{tag}", sot_step)):
+            try:
+                out[key + "_graph_replay"] = entry(replayed(fn), "the same kernels replayed from ONE HIP graph (GPU time of the block)")
+            except Exception as exc:  # noqa: BLE001
+                out[key + "_graph_replay"] = {"error": repr(exc)[:200]}
+        try:
+            out[f"paper_loss_step_{tag}_reference_ops"] = entry(timed(ref_step, max(3, n // 5)), "the reference's op sequence on this GPU: torch.stft (rocFFT) x 14 + ATen ops of losses.py, eager")
+            out[f"mssloss_forward_backward_{tag}_reference_ops"] = entry(timed(ref_mss_step, max(3, n // 5)), "MSSLoss on torch ops (torch.stft x 12 + abs / mean), eager")
+        except Exception as exc:  # noqa: BLE001
+            out[f"paper_loss_step_{tag}_reference_ops"] = {"error": repr(exc)[:200]}
+        del x, hats
     return out
 
 
@@ -879,6 +981,7 @@ def main():
     elif not args.no_extras:
         del sets[4:], marshalled[4:]   # four rotating sets (512 MiB) still exceed the Infinity Cache
         extras.update(other_workloads(dev, nat, sets, pos_x, pos_y, timed, n_extra))
+        extras.update(paper_loss_workloads(dev, nat, timed, n_extra))
     bytes_per_row = 4 * (N + N) + 4  # fwd, shared positions
     achieved = bytes_per_row * B / (kern_ms * 1e-3) / 1e9
 
