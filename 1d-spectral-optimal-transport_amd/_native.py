@@ -31,7 +31,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 8                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 9                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -90,6 +90,10 @@ EXPORTS = {
                                           _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
     "sot_synth_tap_table_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int64]),
     "sot_synth_tap_tables": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp]),
+    "sot_mss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int]),
+    "sot_mss_loss_and_grad": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, _vp, ctypes.c_int,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                             ctypes.c_size_t, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                                  _vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
@@ -752,6 +756,40 @@ def spec_distance_backward(target, value, mag_weight, logmag_weight, upstream, g
                                              float(eps), int(bool(l2)), upstream.contiguous().data_ptr(), float(grad_scale), _ptr(gt), _ptr(gv),
                                              stream_ptr(target.device)))
     return gt, gv
+
+
+MSS_FUSED_SIZES = (64, 128, 256, 512, 1024, 2048)   # n_fft the two-launch form takes (hop = n_fft / 4); include/sot_hip.h: sot_mss_loss_and_grad
+
+
+def mss_loss_and_grad(target: torch.Tensor, value: torch.Tensor, fft_sizes, windows, mag_weight: float, logmag_weight: float, eps: float = 1e-5,
+                      l2: bool = False, per_clip: bool = False, want_grad: bool = True):
+    """MSSLoss (losses.py:365-425) of [batch, samples] float32 audio and d loss / d value in two launches (sot_mss_loss_and_grad):
+    -> (loss: 0-d, or [batch] with per_clip; grad: [batch, samples] or None).  windows: one n_fft-tap device tensor per scale."""
+    require_hip(target, value)
+    lib = load()
+    if target.ndim != 2 or target.shape != value.shape:
+        raise RuntimeError("mss_loss_and_grad expects two [batch, samples] tensors of one shape")
+    if target.stride(1) != 1:
+        target = target.contiguous()
+    if value.stride(1) != 1:
+        value = value.contiguous()
+    batch, samples = value.shape
+    n = len(fft_sizes)
+    sizes = (ctypes.c_int * n)(*[int(s) for s in fft_sizes])
+    wins = [_aligned8(w) for w in windows]
+    wptr = (ctypes.c_void_p * n)(*[w.data_ptr() for w in wins])
+    nbytes = int(lib.sot_mss_workspace_bytes(batch, samples, sizes, n))
+    if nbytes == 0 and batch > 0:
+        raise SotError(f"sot_mss_loss_and_grad does not take fft_sizes={tuple(fft_sizes)} (powers of two in [64, 2048], at most 8)")
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=value.device)
+    loss = torch.empty(batch if per_clip else (), dtype=torch.float32, device=value.device)
+    grad = torch.empty((batch, samples), dtype=torch.float32, device=value.device) if want_grad else None
+    with _on_device(value.device):
+        check(lib.sot_mss_loss_and_grad(target.data_ptr(), target.stride(0), value.data_ptr(), value.stride(0), batch, samples,
+                                        ctypes.cast(sizes, ctypes.c_void_p), ctypes.cast(wptr, ctypes.c_void_p), n, float(mag_weight), float(logmag_weight),
+                                        float(eps), int(bool(l2)), int(bool(per_clip)), loss.data_ptr(), _ptr(grad), ws.data_ptr(), ws.numel(),
+                                        stream_ptr(value.device)))
+    return loss, grad
 
 
 def oscillator_bank_forward(freq: torch.Tensor, amp: torch.Tensor, sample_rate: float, return_workspace: bool = False):

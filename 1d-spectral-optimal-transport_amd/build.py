@@ -13,7 +13,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "sot_hip.hip")
 STFT_SRC = os.path.join(PKG_DIR, "csrc", "sot_stft.hip")   # the STFT-magnitude producer: its own translation unit
 OSC_SRC = os.path.join(PKG_DIR, "csrc", "sot_osc.hip")     # the oscillator bank
-DEPS = [SRC, STFT_SRC, OSC_SRC, os.path.join(PKG_DIR, "csrc", "sot_stft_tables.inc"), os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
+MSS_SRC = os.path.join(PKG_DIR, "csrc", "sot_mss.hip")     # MSSLoss with its gradient in two launches (round 5)
+DEPS = [SRC, STFT_SRC, OSC_SRC, MSS_SRC, os.path.join(PKG_DIR, "csrc", "sot_stft_tables.inc"), os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")]
 LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 
@@ -61,9 +62,9 @@ def is_stale() -> bool:
 
 def _compile_part(part, extra_flags, verbose: bool, obj_dir: str = None) -> str:
     obj_dir = obj_dir or OBJ_DIR
-    if part in ("stft", "osc"):
+    if part in ("stft", "osc", "mss"):
         obj = os.path.join(obj_dir, f"sot_{part}.o")
-        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, STFT_SRC if part == "stft" else OSC_SRC]
+        cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, {"stft": STFT_SRC, "osc": OSC_SRC, "mss": MSS_SRC}[part]]
     else:
         obj = os.path.join(obj_dir, f"sot_part{part}.o")
         cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-DSOT_PART={part}", "-c", "-o", obj, SRC]
@@ -99,7 +100,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
         os.makedirs(obj_dir, exist_ok=True)
         workers = max(1, min(len(PARTS), (os.cpu_count() or 2)))
         with ThreadPoolExecutor(max_workers=workers) as pool:
-            objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose, obj_dir), (*PARTS, "stft", "osc")))
+            objs = list(pool.map(lambda part: _compile_part(part, tuple(extra_flags), verbose, obj_dir), (*PARTS, "stft", "osc", "mss")))
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
         if verbose:
             print(" ".join(cmd))

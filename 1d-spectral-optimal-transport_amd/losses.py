@@ -577,6 +577,35 @@ class _MultiScaleSpectral(torch.autograd.Function):
         return grad_t, grad_v, None, None, None, None, None
 
 
+MSS_FUSED = True   # module switch (tests compare both forms): MSSLoss on the GPU as TWO launches (sot_mss_loss_and_grad) instead of 36
+
+
+class _MultiScaleSpectralFused(torch.autograd.Function):
+    """MSSLoss as one call (include/sot_hip.h: sot_mss_loss_and_grad, csrc/sot_mss.hip): the loss of all scales AND its gradient w.r.t.
+    the estimate's audio come out of the forward (no spectrogram is ever stored); the backward multiplies by the upstream gradient.
+    Only the estimate is differentiated (trainer.py:206-221: the target is data); a target that asks for a gradient takes
+    _MultiScaleSpectral."""
+
+    @staticmethod
+    def forward(ctx, target_audio, audio, fft_sizes, mag_weight, logmag_weight, l2, per_item=False):
+        from . import spectra
+        windows = [spectra._cached_window(None, size, audio.device) for size in fft_sizes]   # window=None -> hann (features.py:203-204)
+        want = ctx.needs_input_grad[1]
+        loss, grad = nat.mss_loss_and_grad(target_audio, audio, fft_sizes, windows, mag_weight, logmag_weight, 1e-5, l2, per_item, want)
+        ctx.per_item = per_item
+        if want:
+            ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.needs_input_grad[1]:
+            return (None,) * 7
+        (grad,) = ctx.saved_tensors
+        g = g.float()
+        return None, grad * (g.reshape(-1, 1) if ctx.per_item else g), None, None, None, None, None
+
+
 class MSSLoss(torch.nn.Module):
     """Multi-scale spectrogram loss, the reference's `losses.MSSLoss` (losses.py:365-425): for each FFT
     size the magnitude STFT (hann window, 75 % overlap, end-padded, normalized: features.compute_mag) of target and estimate,
@@ -608,6 +637,10 @@ class MSSLoss(torch.nn.Module):
             warn_once(("mss", dims is not None, self.fft_sizes),
                       "MSSLoss: this call runs the torch composition instead of the HIP kernels (`dims` other than the two spectrogram axes, FFT sizes outside "
                       "64..4096, shapes that differ, or both weights zero)")
+        if native_ok and MSS_FUSED and len(self.fft_sizes) <= 8 and all(int(s) in nat.MSS_FUSED_SIZES for s in self.fft_sizes) and \
+                not (torch.is_grad_enabled() and target_audio.requires_grad):
+            return _MultiScaleSpectralFused.apply(target_audio.float(), audio.float(), tuple(int(s) for s in self.fft_sizes), float(self.mag_weight),
+                                                  float(self.logmag_weight), kind == "L2", per_item)
         if native_ok:
             return _MultiScaleSpectral.apply(target_audio.float(), audio.float(), self.fft_sizes, float(self.mag_weight),
                                              float(self.logmag_weight), kind == "L2", per_item)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 8   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 9   /* bumped on every change of a signature below; the binding checks it */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -355,6 +355,25 @@ int sot_spec_distance_rows_backward(const float *target, const float *value, int
                                     float mag_weight, float logmag_weight, float eps, int l2,
                                     const float *upstream /* [rows] */, float grad_scale,
                                     float *grad_target, float *grad_value, void *stream);
+
+/* ---- Round 5: the WHOLE multi-scale spectrogram loss and its gradient in two launches (the reference's `MSSLoss.forward`,
+ * losses.py:406-425, + autograd; per scale: compute_mag features.py:191-237 -- hann or any caller-given window, hop = n_fft / 4,
+ * end padding utils.py:252-275, normalized -- and mean_difference losses.py:7-36 / safe_log utils.py:145-151):
+ *   loss = sum_s [mag_weight * mean D(T_s - V_s) + logmag_weight * mean D(slog T_s - slog V_s)]      (per_clip == 0: one float;
+ *   per_clip != 0: the means run over each clip's own spectrogram, `dims` = its two axes: loss[batch]),
+ *   grad_value[b, t] = d loss (or d loss[b]) / d value[b, t]   (NULL: forward only; the caller applies its upstream gradient).
+ * target / value: [batch, samples] float32 with the given row strides (in floats); fft_sizes[n_scales]: powers of two in [64, 2048],
+ * n_scales <= 8; windows[s]: n_fft taps of scale s, device pointers on 8-byte boundaries (host array of device pointers).
+ * One workgroup per (scale, clip, 4096-sample chunk): 2048 / n_fft frames per wavefront through a register-resident FFT, magnitudes,
+ * distance, gradient w.r.t. the spectrum, inverse transform and overlap-add without a spectrogram in memory; a second kernel adds the
+ * scales per sample in a fixed order.  Deterministic, enqueue-only, graph-capturable.
+ * workspace: sot_mss_workspace_bytes(batch, samples, fft_sizes, n_scales) bytes, 8-byte aligned (0 is returned for sizes it does not take). */
+size_t sot_mss_workspace_bytes(int64_t batch, int64_t samples, const int *fft_sizes, int n_scales);
+int sot_mss_loss_and_grad(const float *target, int64_t target_row_stride, const float *value, int64_t value_row_stride,
+                          int64_t batch, int64_t samples, const int *fft_sizes, const float *const *windows, int n_scales,
+                          float mag_weight, float logmag_weight, float eps, int l2, int per_clip,
+                          float *loss /* [1] or [batch] */, float *grad_value /* [batch, samples] contiguous, or NULL */,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

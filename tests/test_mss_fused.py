@@ -1,0 +1,171 @@
+"""The two-launch MSSLoss (csrc/sot_mss.hip: sot_mss_loss_and_grad; reference losses.py:365-425 + autograd): every transform size on its own
+and together, clip lengths that end inside a frame / span several 4096-sample chunks, per-clip means, L2 and log-magnitude terms, strided
+rows -- against the reference's own composition (the module on CPU tensors = torch.stft + mean_difference, pinned to the reference by
+test_mssloss_torch_composition_matches_reference) in float64 as the yardstick, and against the round-2 kernel chain (MSS_FUSED = False)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (2048, 1024, 512, 256, 128, 64)
+
+
+def _clips(batch, samples, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(samples) / 16000.0
+    f0 = 60 + 900 * torch.rand(batch, 1, generator=g)
+    x = sum((0.5 / k) * torch.sin(2 * np.pi * k * f0 * t + k) for k in range(1, 6)) + 0.02 * torch.randn(batch, samples, generator=g)
+    f1 = f0 * (1 + 0.05 * torch.randn(batch, 1, generator=g))
+    y = sum((0.45 / k) * torch.sin(2 * np.pi * k * f1 * t + 0.3 * k) for k in range(1, 6)) + 0.02 * torch.randn(batch, samples, generator=g)
+    return x.float(), y.float()
+
+
+def _mss_torch(mod, x, y, dims, dtype):
+    """losses.py:365-425 on torch ops in `dtype` (the reference's op sequence: hann window as float32 values, torch.stft(center=False,
+    normalized=True) of the end-padded signal, abs, mean_difference / safe_log)"""
+    from sot_amd import spectra
+    loss = 0.0
+    l2 = mod.loss_type.upper() == "L2"
+    for size in mod.fft_sizes:
+        hop = int(size * 0.25)
+        win = torch.hann_window(size).to(dtype)
+
+        def mag(a):
+            a = spectra.end_padded(a.to(dtype), size, hop)
+            return torch.stft(a, n_fft=size, hop_length=hop, win_length=size, window=win, center=False, normalized=True, return_complex=True).abs()
+
+        t, v = mag(x), mag(y)
+        eps = torch.tensor(1e-5, dtype=dtype)
+        for weight, a, b in ((mod.mag_weight, t, v), (mod.logmag_weight, torch.log(torch.where(t <= eps, eps, t)), torch.log(torch.where(v <= eps, eps, v)))):
+            if weight > 0:
+                d = a - b
+                red = list(range(d.ndim)) if dims is None else list(dims)
+                loss = loss + weight * (torch.mean(d ** 2, dim=red) if l2 else torch.mean(torch.abs(d), dim=red))
+    return loss
+
+
+def _reference(mod, x, y, dims=None, weights=None, dtype=torch.float64):
+    """float64: the yardstick; float32: what the reference itself computes"""
+    yy = y.to(dtype).clone().requires_grad_(True)
+    out = _mss_torch(mod, x, yy, dims, dtype)
+    (out if weights is None else (out * weights.to(dtype)).sum()).backward()
+    return out.detach(), yy.grad
+
+
+def _check(mod, x, y, dims=None, weights=None, loss_tol=1e-5):
+    from gpu_util import device
+    want64, g64 = _reference(mod, x, y, dims, weights)
+    want32, g32 = _reference(mod, x, y, dims, weights, torch.float32)
+    yd = y.to(device()).requires_grad_(True)
+    got = mod(x.to(device()), yd, **({"dims": dims} if dims is not None else {}))
+    (got if weights is None else (got * weights.to(device())).sum()).backward()
+    assert got.dtype == torch.float32 and got.shape == want64.shape
+    if float(want64.abs().max()) == 0.0:     # e.g. one sample per clip: it meets the hann window's zero tap
+        assert float(got.abs().max()) == 0.0 and float(yd.grad.abs().max()) == 0.0
+        return got.detach(), yd.grad.detach()
+    err = float((got.detach().cpu().double() - want64).abs().max() / want64.abs().max())
+    assert err <= loss_tol, err
+    g = yd.grad.cpu().double()
+    ref_err = float(torch.linalg.norm(g32.double() - g64) / torch.linalg.norm(g64))
+    hip_err = float(torch.linalg.norm(g - g64) / torch.linalg.norm(g64))
+    # the HIP gradient is as close to float64 as the reference's own float32 gradient is (sign() kinks, 1 / v of the log term)
+    assert hip_err <= 1.5 * ref_err + 2e-6, (hip_err, ref_err)
+    return got.detach(), yd.grad.detach()
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_each_transform_size_alone(size):
+    from gpu_util import native
+    from sot_amd.losses import MSSLoss
+    native()
+    x, y = _clips(3, 4096, size)
+    _check(MSSLoss(fft_sizes=(size,), mag_weight=1.0), x, y)
+
+
+@pytest.mark.parametrize("samples,batch", [(4096, 5), (4000, 2), (100, 3), (1, 2), (4097, 2), (9000, 2), (16384, 1), (777, 4)])
+def test_clip_lengths_and_chunks(samples, batch):
+    """ends inside a frame, shorter than one frame, exactly / just over one 4096-sample chunk, several chunks"""
+    from gpu_util import native
+    from sot_amd.losses import MSSLoss
+    native()
+    x, y = _clips(batch, samples, samples)
+    _check(MSSLoss(mag_weight=1.0), x, y)
+
+
+@pytest.mark.parametrize("kw", [dict(mag_weight=1.0, logmag_weight=0.5), dict(mag_weight=0.7, logmag_weight=0.3, loss_type="L2"),
+                                dict(mag_weight=0.0, logmag_weight=1.0), dict(mag_weight=2.0, loss_type="L2")])
+def test_distance_kinds(kw):
+    from gpu_util import native
+    from sot_amd.losses import MSSLoss
+    native()
+    x, y = _clips(4, 4096, 11)
+    _check(MSSLoss(**kw), x, y, loss_tol=2e-5 if kw.get("logmag_weight") else 1e-5)
+
+
+def test_per_clip_means_with_weights():
+    from gpu_util import native
+    from sot_amd.losses import MSSLoss
+    native()
+    x, y = _clips(5, 5000, 21)
+    w = torch.linspace(0.5, 1.5, 5)
+    got, _ = _check(MSSLoss(mag_weight=1.0, logmag_weight=0.25), x, y, dims=(1, 2), weights=w, loss_tol=2e-5)
+    assert got.shape == (5,)
+
+
+def test_two_launches_equal_the_kernel_chain_and_are_deterministic():
+    """same loss as the round-2 chain (STFT pair + distance kernels per scale) to float32 rounding; two calls bit-identical"""
+    from gpu_util import device, native
+    import sot_amd.losses as L
+    native()
+    x, y = _clips(6, 4096, 5)
+    mod = L.MSSLoss(mag_weight=1.0)
+    res = []
+    for fused in (True, False, True):
+        L.MSS_FUSED = fused
+        try:
+            yd = y.to(device()).requires_grad_(True)
+            v = mod(x.to(device()), yd)
+            v.backward()
+            res.append((v.detach().clone(), yd.grad.clone()))
+        finally:
+            L.MSS_FUSED = True
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+    assert abs(float(res[0][0]) - float(res[1][0])) <= 2e-6 * abs(float(res[1][0]))
+    a, b = res[0][1].double(), res[1][1].double()
+    assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) <= 5e-3    # two float32 FFTs: the sign() kinks of |t - v| differ at a few bins
+
+
+def test_strided_rows_no_grad_and_upstream_gradient():
+    from gpu_util import device, native
+    from sot_amd.losses import MSSLoss
+    nat = native()
+    x, y = _clips(4, 4096, 8)
+    big_x, big_y = torch.zeros(4, 5000), torch.zeros(4, 5000)
+    big_x[:, :4096], big_y[:, :4096] = x, y
+    xs, ys = big_x.to(device())[:, :4096], big_y.to(device())[:, :4096]
+    assert not xs.is_contiguous()
+    mod = MSSLoss(mag_weight=1.0)
+    yc = y.to(device()).requires_grad_(True)
+    base = mod(x.to(device()), yc)
+    (base * 0.05).backward()                       # MixOfLosses' weight: the upstream gradient reaches the stored gradient as a factor
+    ysr = ys.detach().requires_grad_(True)
+    v = mod(xs, ysr)
+    (v * 0.05).backward()
+    assert torch.equal(v, base) and torch.equal(ysr.grad, yc.grad)
+    with torch.no_grad():
+        assert torch.equal(mod(xs, ys), base)      # forward only: the gradient-free kernel
+    # the C ABI says so when a size is outside its domain
+    with pytest.raises(nat.SotError):
+        nat.mss_loss_and_grad(xs, ys, (4096,), [torch.ones(4096, device=device())], 1.0, 0.0)
+
+
+def test_target_gradient_takes_the_differentiating_chain():
+    from gpu_util import device, native
+    from sot_amd.losses import MSSLoss
+    native()
+    x, y = _clips(2, 4096, 9)
+    xd = x.to(device()).requires_grad_(True)
+    yd = y.to(device()).requires_grad_(True)
+    MSSLoss(mag_weight=1.0)(xd, yd).backward()
+    assert xd.grad is not None and float(xd.grad.abs().max()) > 0 and float(yd.grad.abs().max()) > 0

@@ -272,12 +272,29 @@ def test_mssloss_hip_matches_reference(tag):
     else:
         assert np.linalg.norm(got - gwant) <= 6e-2 * np.linalg.norm(gwant)
         assert float((got * gwant).sum()) >= 0.998 * float(np.linalg.norm(got) * np.linalg.norm(gwant))
-    # the same module through torch ops on the GPU (dims given -> composition path) agrees as well
+    # the same module through torch ops on the GPU (dims given -> composition path: HIP STFT kernels + torch distance ops) agrees as well.
+    # Round 5: the default GPU route is the two-launch form (csrc/sot_mss.hip, its own FFT): the value agrees to float32 rounding; the
+    # element-wise 1e-5 pin "distance kernels == torch ops" holds for the kernel CHAIN, which shares its STFT with the composition
+    # (the two-launch form against float64: tests/test_mss_fused.py)
+    import sot_amd.losses as L
     ay2 = ay.detach().clone().requires_grad_(True)
     val2 = mod(ax, ay2, dims=[0, 1, 2])
     val2.backward()
     assert abs(float(val2) - float(val)) <= 2e-6 * abs(float(val))
-    assert float((ay2.grad - ay.grad).abs().max()) <= 1e-5 * float(ay.grad.abs().max())   # distance kernels == torch ops
+    L.MSS_FUSED = False
+    try:
+        ay4 = ay.detach().clone().requires_grad_(True)
+        val4 = mod(ax, ay4)
+        val4.backward()
+    finally:
+        L.MSS_FUSED = True
+    assert abs(float(val4) - float(val2)) <= 2e-6 * abs(float(val2))
+    assert float((ay2.grad - ay4.grad).abs().max()) <= 1e-5 * float(ay4.grad.abs().max())   # distance kernels == torch ops
+    g4 = ay4.grad.cpu().numpy()
+    if MSS_CASES[tag]["logmag_weight"] == 0:      # chain and two-launch form: each within the reference's tolerance of the other too
+        assert np.abs(got - g4).max() <= 5e-3 * np.abs(g4).max()
+    else:
+        assert np.linalg.norm(got - g4) <= 6e-2 * np.linalg.norm(g4)
     # deterministic
     ay3 = ay.detach().clone().requires_grad_(True)
     v3 = mod(ax, ay3); v3.backward()

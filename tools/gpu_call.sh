@@ -49,7 +49,8 @@ PY
   tests)                # <tag> [pytest args]: the GPU suite (or a selection)
     O="gpurun_out/${1:-r5}"; shift || true
     mkdir -p "$O"
-    timeout 1700 python -m pytest tests -q -m gpu "$@" > "$O/pytest.log" 2>&1; echo "pytest rc=$?"
+    if [ $# -eq 0 ]; then set -- tests; fi     # default: the whole suite; else the given files / -k selections
+    timeout 1700 python -m pytest -q -m gpu "$@" > "$O/pytest.log" 2>&1; echo "pytest rc=$?"
     tail -n 15 "$O/pytest.log" | cut -c1-300 ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 3 ;;
