@@ -4,13 +4,14 @@
 // TOGETHER WITH ITS GRADIENT w.r.t. the estimate's audio, in TWO launches for all scales (round 4: 36 launches and ~40 B of HBM traffic per
 // spectrogram bin; here no spectrogram ever leaves the chip):
 //
-//  mss_fused_kernel   one 512-thread workgroup per (scale, clip, chunk of 4096 samples).  Each of its 8 wavefronts takes 1024 packed
-//                     points = F = 2048 / n_fft consecutive frames: both signals' frames -> window -> one-wavefront FFT (16 points per lane,
-//                     radix-4 stages in registers, 1-2 exchanges through the wave's LDS buffer; index algebra: tests/wave_fft_model.py, checked
-//                     against numpy) -> bins (k, m - k) of the real frames -> |T|, |V| -> distance terms (fp64 partial sums) -> the gradient
-//                     w.r.t. the estimate's spectrum g_k V_k / |V_k| as a Hermitian packing, written over the spectrum in LDS -> transposed
-//                     (inverse) network -> window -> the workgroup overlap-adds its 8 F frames in LDS and stores the chunk's span.
-//  mss_finish_kernel  sums, per sample, the spans of all scales in a fixed order (deterministic; no atomics) and the loss partials.
+//  mss_fused_kernel   persistent 512-thread workgroups; every WAVEFRONT takes tasks on its own (no workgroup barrier after the twiddle tables
+//                     are built): a task = 1024 packed points = F = 2048 / n_fft consecutive frames of one clip at one scale.  Both signals'
+//                     frames -> window -> one-wavefront FFT (16 points per lane, radix-4 stages in registers, 1-2 exchanges through the wave's
+//                     LDS buffer; index algebra: tests/wave_fft_model.py, checked against numpy) -> bins (k, m - k) of the real frames -> |T|, |V|
+//                     -> distance terms -> the gradient w.r.t. the estimate's spectrum g_k V_k / |V_k| as a Hermitian packing, written over the
+//                     spectrum in LDS -> transposed (inverse) network -> window -> the wave overlap-adds its F frames and stores their span
+//                     (512 samples + 3 hops of tail).
+//  mss_finish_kernel  sums, per sample, the spans of all scales that cover it in a fixed order (deterministic; no atomics) and the loss partials.
 //
 // The gradient is that of the loss value itself (upstream gradient 1); the autograd node multiplies by the upstream scalar (or per-clip vector).
 #include <hip/hip_runtime.h>
@@ -28,9 +29,20 @@ typedef float v2f __attribute__((ext_vector_type(2)));   // one complex point; a
 constexpr int kThreads = 512, kWaves = 8;
 constexpr int kBuf = 1088;            // complex points of one wave's exchange buffer: 1024 + pads (both address maps below)
 constexpr int kTw = 768;              // W_1024^t, t < 768
-constexpr int kWnMax = 520;           // W_n^k, k <= m / 2 <= 512
+constexpr int kWnMax = 520;           // -i W_2048^k / 2, k <= 512 (scale M reads index k << (10 - M))
 constexpr size_t kLdsBytes = ((size_t)kWaves * kBuf + kTw + kWnMax) * sizeof(float2);
 constexpr int kMaxScales = 8;
+// Diagnostic build only (-DMSS_STAMPS): wave 0 of the workgroups 0, 1, 2, ... (at most 64) stamps the shader clock at its phase boundaries
+// (tools/r5/mss_stamps.py reads them through sot_mss_debug_read_stamps)
+#ifdef MSS_STAMPS
+__device__ unsigned long long g_mss_stamps[64 * 16];
+#define MSS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) { __builtin_amdgcn_sched_barrier(0); g_mss_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define MSS_STAMP(i) do { } while (0)
+#endif
+#ifndef MSS_WAVES_PER_EU
+#define MSS_WAVES_PER_EU 4   /* two 512-thread workgroups per CU (LDS: 2 x 80 KB): 128 VGPRs */
+#endif
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -39,19 +51,33 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// complex products on the packed-fp32 unit (see csrc/sot_stft.hip: cmul / cmul_conj / add_mi / add_pi)
+// complex products on the packed-fp32 unit: one v_pk_mul_f32 + one v_pk_fma_f32 (operand halves picked by op_sel, signs by neg_*).
+// (csrc/sot_stft.hip keeps the three-rounding form for the SOT chain's knife edge; nothing here has one, and the fused form is the more accurate.)
+#ifndef MSS_CMUL_3OP
+#define MSS_CMUL_3OP 0    /* diagnostic: 1 = the three-rounding products of csrc/sot_stft.hip */
+#endif
 __device__ __forceinline__ v2f cmul(v2f a, v2f b)
 {
-    v2f t;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));   // (-a.y b.y, a.y b.x)
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));          // (-a.y b.y, a.y b.x)
+#if MSS_CMUL_3OP
     return a.xx * b + t;
+#else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));       // (a.x b.x, a.x b.y) + t
+    return r;
+#endif
 }
 __device__ __forceinline__ v2f cmul_conj(v2f a, v2f b)   // a * conj(b)
 {
-    v2f t1, t2;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t1) : "v"(a), "v"(b));   // (a.x b.x, -a.x b.y)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(a), "v"(b));               // (a.y b.y, a.y b.x)
-    return t1 + t2;
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));                                   // (a.y b.y, a.y b.x)
+#if MSS_CMUL_3OP
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));                      // (a.x b.x, -a.x b.y)
+    return r + t;
+#else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));    // (a.x b.x, -a.x b.y) + t
+    return r;
+#endif
 }
 __device__ __forceinline__ v2f add_mi(v2f a, v2f b)      // a - i b
 {
@@ -233,30 +259,20 @@ struct MssArgs {
     int logm[kMaxScales];                             // log2(n_fft / 2) per scale
     const float* window[kMaxScales];                  // n_fft taps per scale
     int frames[kMaxScales];                           // ceil(samples / hop), hop = n_fft / 4
-    int chunks[kMaxScales];                           // workgroups per clip: ceil(frames / (8 F))
-    int block_base[kMaxScales + 1];                   // first workgroup of each scale
+    int waves[kMaxScales];                            // wave tasks per clip: ceil(frames / F), F = 2048 / n_fft frames = 512 samples of hop positions each
+    int task_base[kMaxScales + 1];                    // first task of each scale; task = task_base[s] + clip * waves[s] + w
     float coef[kMaxScales];                           // d loss / d (sum of the scale's distance terms): 1 / count (all clips) or 1 / (frames bins)
     double inv_count[kMaxScales];                     // the same in double, for the loss value
     int64_t grad_base[kMaxScales];                    // offset (floats) of the scale's spans in partial_grad
-    int64_t loss_base[kMaxScales];                    // offset of the scale's partial sums in partial_loss
     float mag_weight, logmag_weight, eps; int l2, per_clip, want_grad;
-    double* partial_loss;                             // [scale][clip][chunk]
-    float* partial_grad;                              // [scale][clip][chunk][span]: span = 4096 + 3 hop samples
+    double* partial_loss;                             // [task]
+    float* partial_grad;                              // [scale][clip][wave][span]: span = 512 + 3 hop samples (256 + 3 m / 4 packed points)
     float* loss; float* grad;                         // outputs: [1] or [batch]; [batch, samples] (contiguous)
 };
 
 __device__ __forceinline__ float safe_logf(float x, float eps) { return logf(x <= eps ? eps : x); }
 
-// |x| for a frame whose windowed samples passed the range test (csrc/sot_stft.hip: magnitude_plain / frame_is_plain)
-__device__ __forceinline__ float magnitude_plain(v2f x)
-{
-    const float s = fmaf(x.x, x.x, x.y * x.y);
-    const float r = __builtin_amdgcn_sqrtf(s);
-    const float h = 0.5f * __builtin_amdgcn_rsqf(s);
-    const float e = fmaf(-r, r, s);
-    const float v = fmaf(e, h, r);
-    return s == 0.0f ? 0.0f : v;
-}
+// range test of a frame's windowed samples (csrc/sot_stft.hip: frame_is_plain): then re^2 + im^2 of its bins neither overflows nor loses the bins that matter
 __device__ __forceinline__ bool frame_is_plain(float amax) { return (amax > 1e-9f && amax < 1e15f) || amax == 0.0f; }
 
 __device__ __forceinline__ float wave_max_f32(float v)
@@ -285,9 +301,10 @@ __device__ __forceinline__ float bin_term(const MssArgs& a, float t, float v, do
     return gv;
 }
 
-// frames [frame0, frame0 + F) of one signal -> windowed packed points in phase-0 registers; returns the largest |sample * tap| of the lane
+// frames [frame0, frame0 + F) of one signal: raw packed points (samples 2 i, 2 i + 1) and the window's tap pairs into registers -- loads only,
+// nothing waits for them here (the estimate's frames are requested before the target's pair pass and used after it)
 template <int M>
-__device__ __forceinline__ float load_frames(const float* __restrict__ clip, int64_t samples, int frames, int frame0, const float2* __restrict__ win,
+__device__ __forceinline__ void fetch_frames(const float* __restrict__ clip, int64_t samples, int frames, int frame0, const float2* __restrict__ win,
                                              int lane, v2f (&r)[16])
 {
     using G = Geo<M>;
@@ -299,28 +316,35 @@ __device__ __forceinline__ float load_frames(const float* __restrict__ clip, int
     // the wave's fast path: every frame it owns exists and lies inside the clip, 8-byte aligned
     const int64_t last = ((int64_t)frame0 + G::F - 1) * hop + G::n;
     const bool fast = frame0 + G::F <= frames && last <= samples && (reinterpret_cast<uintptr_t>(clip) & 7u) == 0;
-    float amax = 0.0f;
     if (fast) {
         const float2* const s2 = reinterpret_cast<const float2*>(s0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 v = s2[G::L * q + l], w = win[G::L * q + l];
-            r[q] = (v2f){v.x * w.x, v.y * w.y};
-            amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
-        }
+        for (int q = 0; q < 16; ++q) { const float2 v = s2[G::L * q + l]; r[q] = (v2f){v.x, v.y}; }
     } else {
         const int64_t left = (f < frames) ? samples - t0 : 0;     // samples of the frame that exist: zeros beyond (utils.py:252-275)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int i = G::L * q + l;
-            const float2 w = win[i];
-            const float v0 = (2 * i < left) ? s0[2 * i] * w.x : 0.0f;
-            const float v1 = (2 * i + 1 < left) ? s0[2 * i + 1] * w.y : 0.0f;
-            r[q] = (v2f){v0, v1};
-            amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+            r[q] = (v2f){(2 * i < left) ? s0[2 * i] : 0.0f, (2 * i + 1 < left) ? s0[2 * i + 1] : 0.0f};
         }
     }
-    return amax;
+}
+
+// sample * tap (the taps come from L1 / L2: every wave of the scale reads the same n_fft floats); returns whether the wave's frames pass
+// the range test (wave-uniform)
+template <int M>
+__device__ __forceinline__ bool window_frames(v2f (&r)[16], const float2* __restrict__ win, int lane)
+{
+    using G = Geo<M>;
+    const float2* const wl = win + (lane & (G::L - 1));
+    float amax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float2 w = wl[G::L * q];
+        r[q] = r[q] * (v2f){w.x, w.y};
+        amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
+    }
+    return __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;
 }
 
 // last-phase registers -> the wave's buffer in natural frequency order, frame-major with L pad slots per frame (address j (m + L) + k);
@@ -336,92 +360,203 @@ __device__ __forceinline__ void write_natural(const v2f (&r)[16], v2f* zl, int l
     if (kl == 0) p[G::m] = r[0];
 }
 
-// bins k and m - k of the real frame from the packed transform (csrc/sot_stft.hip: unpack_pair); w = W_n^k
-__device__ __forceinline__ void unpack_pair(v2f zk, v2f zm, v2f w, v2f& xk, v2f& xm)
+// a + conj(b), a - conj(b), conj(a - b): one packed add each (negated halves)
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b)
 {
-    const v2f ze = 0.5f * (zk + cconj(zm));
-    const v2f zo = 0.5f * mul_mi(zk - cconj(zm));
-    const v2f wz = cmul(w, zo);
-    xk = ze + wz;
-    xm = cconj(ze - wz);
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f conj_sub(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-// The bin pairs of the lane: q < 8: k = L q + l (all lanes), q = 8: k = m / 2 (lane l = 0 of each frame).  Pass 1 (target): |T| of both
-// bins into tm[].  Pass 2 (estimate): |V|, distance terms, and -- GRAD -- the Hermitian packing G of the gradient w.r.t. the spectrum written
-// over Z in the buffer (the two slots of a pair are read and written by the same lane only).
-template <int M, bool PLAIN, bool SECOND, bool GRAD>
-__device__ __forceinline__ void pair_pass(const MssArgs& a, float coef, v2f* zl, const v2f* wn, int lane, bool active, float (&tm)[18], double& acc)
+// The bin pairs of the lane: q < 8: k = L q + l (all lanes), q = 8: k = m / 2 (lane l = 0 of each frame).  With the packed transform Z,
+// e = Z_k + conj Z_(m-k), o = Z_k - conj Z_(m-k) and the table entry w' = -i W_n^k / 2:   X_k = e / 2 + w' o,   conj X_(m-k) = e / 2 - w' o
+// (csrc/sot_stft.hip: unpack_pair, regrouped: 8 packed operations per pair).
+// Pass 1 (target): |T| of both bins into tm[].  Pass 2 (estimate): |V|, the distance terms, and -- GRAD -- the Hermitian packing of the
+// gradient w.r.t. the spectrum written over Z in the buffer (the two slots of a pair are read and written by the same lane only):
+//   Zin_k = g_k X_k / |X_k| (torch: sgn(0) = 0),  H_k = Zin_k / 2 (0 < k < m), H_0 = Re Zin_0, H_m = Re Zin_m,
+//   s = H_k + conj H_(m-k), P = i conj(W) (H_k - conj H_(m-k)):   G_k = s + P,   G_(m-k) = conj(s - P)     (csrc/sot_stft.hip, backward).
+// KIND 0: the paper's distance (L1 on the magnitudes only: mag_weight |t - v|, float32 partial sums per lane); KIND 1: every combination
+// (L1 / L2, magnitudes and / or their safe_log; float64 partial sums).  PLAIN: the frame passed the range test: |x| = v_sqrt(re^2 + im^2),
+// 1 / |x| = v_rsq; otherwise hypotf and an IEEE division.
+template <int M, bool PLAIN, bool SECOND, bool GRAD, int KIND>
+__device__ __forceinline__ void pair_pass(const MssArgs& a, float coef, v2f* zl, const v2f* wn, int lane, float (&tm)[18], float& accf, double& acc)
 {
     using G = Geo<M>;
     const int j = lane >> G::logL, l = lane & (G::L - 1);
     v2f* const pk = zl + j * (G::m + G::L) + l;         // + L q
     v2f* const pm = zl + j * (G::m + G::L) - l;         // + L (16 - q)
     const float scale = 1.0f / sqrtf((float)G::n);      // normalized=True: frame_length^-0.5
+    const float cw = coef * a.mag_weight;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         if (q == 8 && l != 0) break;
         const int k = (q < 8) ? G::L * q + l : G::m / 2;
         const v2f zk = (q < 8) ? pk[G::L * q] : pk[G::m / 2], zm = (q < 8) ? pm[G::L * (16 - q)] : zk;
-        v2f xk, xm;
-        unpack_pair(zk, zm, wn[k], xk, xm);
+        const v2f wp = wn[k << (10 - M)];
+        const v2f e = add_conj(zk, zm), o = sub_conj(zk, zm);
+        const v2f wz = cmul(o, wp), eh = 0.5f * e;
+        const v2f xk = eh + wz, xc = eh - wz;            // X_k, conj X_(m-k)
+        const float sk2 = fmaf(xk.x, xk.x, xk.y * xk.y), sm2 = fmaf(xc.x, xc.x, xc.y * xc.y);
         float mk, mm;
-        if (PLAIN) { mk = magnitude_plain(xk); mm = magnitude_plain(xm); }
-        else { mk = hypotf(xk.x, xk.y); mm = hypotf(xm.x, xm.y); }
-        if (!SECOND) { tm[2 * q] = mk * scale; tm[2 * q + 1] = mm * scale; continue; }
-        const bool both = q < 8;                                   // k = m / 2 (q = 8) is its own partner: one bin; k = 0 pairs with bin m
-        float gk = 0.0f, gm = 0.0f;
-        if (active) {
-            gk = bin_term(a, tm[2 * q], mk * scale, acc);
-            if (both) gm = bin_term(a, tm[2 * q + 1], mm * scale, acc);
+        if (PLAIN) { mk = __builtin_amdgcn_sqrtf(sk2); mm = __builtin_amdgcn_sqrtf(sm2); }
+        else { mk = hypotf(xk.x, xk.y); mm = hypotf(xc.x, xc.y); }
+        mk *= scale; mm *= scale;
+        if (!SECOND) { tm[2 * q] = mk; tm[2 * q + 1] = mm; continue; }
+        float gk, gm;                                     // d term / d |V| of the two bins (times coef)
+        if (KIND == 0) {
+            const float dk = tm[2 * q] - mk, dm = tm[2 * q + 1] - mm;
+            accf += fabsf(dk);
+            if (q < 8) accf += fabsf(dm);                 // k = m / 2 (q = 8) is its own partner: one bin; k = 0 pairs with bin m
+            gk = dk > 0.0f ? -cw : cw; gk = dk == 0.0f ? 0.0f : gk;    // torch: sgn(0) = 0
+            gm = dm > 0.0f ? -cw : cw; gm = dm == 0.0f ? 0.0f : gm;
+        } else {
+            gk = coef * bin_term(a, tm[2 * q], mk, acc);
+            gm = (q < 8) ? coef * bin_term(a, tm[2 * q + 1], mm, acc) : 0.0f;
         }
         if (GRAD) {
-            // Zin_k = g_k X_k / |X_k| (torch: sgn(0) = 0); H_k = Zin_k / 2 (0 < k < m), H_0 = Re Zin_0, H_m = Re Zin_m;
-            // G_k = (H_k + conj H_(m-k)) + i conj(W) (H_k - conj H_(m-k)),  G_(m-k) = conj(s) + i W conj(d)   (csrc/sot_stft.hip, backward)
             float ck, cm;
             if (PLAIN) {
-                const float sk2 = fmaf(xk.x, xk.x, xk.y * xk.y), sm2 = fmaf(xm.x, xm.x, xm.y * xm.y);
-                ck = sk2 > 0.0f ? (gk * coef) * __builtin_amdgcn_rsqf(sk2) : 0.0f;
-                cm = sm2 > 0.0f ? (gm * coef) * __builtin_amdgcn_rsqf(sm2) : 0.0f;
+                ck = sk2 > 0.0f ? gk * __builtin_amdgcn_rsqf(sk2) : 0.0f;
+                cm = sm2 > 0.0f ? gm * __builtin_amdgcn_rsqf(sm2) : 0.0f;
             } else {
-                ck = mk > 0.0f ? (gk * coef) / mk : 0.0f;
-                cm = mm > 0.0f ? (gm * coef) / mm : 0.0f;
+                ck = mk > 0.0f ? gk / (mk / scale) : 0.0f;
+                cm = mm > 0.0f ? gm / (mm / scale) : 0.0f;
             }
-            v2f hk = (0.5f * ck) * xk, hm = (0.5f * cm) * xm;
-            if (k == 0) { hk = (v2f){ck * xk.x, 0.0f}; hm = (v2f){cm * xm.x, 0.0f}; }
-            if (q == 8) hm = hk;                                   // k = m / 2: H_(m-k) is H_k itself
-            const v2f sk = hk + cconj(hm), dk = hk - cconj(hm);
-            const v2f w = wn[k];
-            const v2f g_k = sk + mul_i(cmul(cconj(w), dk));
+            if (q == 0 && k == 0) { ck *= 2.0f; cm *= 2.0f; }   // H_0 and H_m are the (real) Zin themselves, not halves
+            const v2f hk = ck * xk;                        // 2 H_k
+            const v2f hc = (q < 8) ? cm * xc : cconj(hk);  // 2 conj H_(m-k)   (k = m / 2: H_(m-k) is H_k itself)
+            const v2f sk = 0.5f * (hk + hc), dd = hk - hc;
+            const v2f P = cmul_conj(dd, wp);               // conj(w') (2 d) = i conj(W) d
             if (q < 8) {
-                pk[G::L * q] = g_k;
-                if (k != 0) pm[G::L * (16 - q)] = cconj(sk) + mul_i(cmul(w, cconj(dk)));
+                pk[G::L * q] = sk + P;
+                if (k != 0) pm[G::L * (16 - q)] = conj_sub(sk, P);
             } else {
-                pk[G::m / 2] = g_k;
+                pk[G::m / 2] = sk + P;
             }
         }
     }
 }
 
-template <int M, bool GRAD>
-__device__ __forceinline__ void scale_body(const MssArgs& a, int s, int unit)
+// One task of one wavefront: frames [w F, w F + F) of clip b at scale s.
+template <int M, bool GRAD, int KIND>
+__device__ __forceinline__ void wave_task(const MssArgs& a, int s, int task, const v2f* tw, const v2f* wn, v2f* zl)
 {
     using G = Geo<M>;
+    // the lane number as an opaque value per task: hipcc otherwise hoists the lane-derived LDS addresses of all six scales out of the caller's
+    // loop and pays for them with hundreds of spilled registers
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int waves = a.waves[s], frames = a.frames[s];
+    const int local = task - a.task_base[s];
+    const int b = local / waves, w = local - b * waves;
+    const float* const tclip = a.target + (int64_t)b * a.stride_t;
+    const float* const vclip = a.value + (int64_t)b * a.stride_v;
+    const float2* const win = reinterpret_cast<const float2*>(a.window[s]);
+    const int frame0 = w * G::F;
+
+    MSS_STAMP(1);
+    float tm[18];
+    float accf = 0.0f;
+    double acc = 0.0;
+    v2f r[16];
+    // ---- target: |T| of the lane's bins
+    fetch_frames<M>(tclip, a.samples, frames, frame0, win, lane, r);
+    bool plain = window_frames<M>(r, win, lane);
+    MSS_STAMP(2);
+    forward_transform<M>(r, zl, tw, lane);
+    MSS_STAMP(3);
+    write_natural<M>(r, zl, lane);
+    fetch_frames<M>(vclip, a.samples, frames, frame0, win, lane, r);     // the estimate's frames travel during the target's pair pass
+    wave_sync();
+    if (plain) pair_pass<M, true, false, false, KIND>(a, 0.0f, zl, wn, lane, tm, accf, acc);
+    else pair_pass<M, false, false, false, KIND>(a, 0.0f, zl, wn, lane, tm, accf, acc);
+    wave_sync();
+    MSS_STAMP(4);
+    // ---- estimate: |V|, distance, gradient packing
+    plain = window_frames<M>(r, win, lane);
+    forward_transform<M>(r, zl, tw, lane);
+    MSS_STAMP(5);
+    write_natural<M>(r, zl, lane);
+    wave_sync();
+    const float coef = a.coef[s];
+    if (plain) pair_pass<M, true, true, GRAD, KIND>(a, coef, zl, wn, lane, tm, accf, acc);
+    else pair_pass<M, false, true, GRAD, KIND>(a, coef, zl, wn, lane, tm, accf, acc);
+    wave_sync();
+    MSS_STAMP(6);
+    // ---- the task's distance sum: lanes -> wave (fixed shuffle tree)
+    if (KIND == 0) acc = (double)accf * (double)a.mag_weight;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) a.partial_loss[task] = acc;
+    if (GRAD) {
+        // ---- inverse: G (natural order) -> last-phase registers -> time order; windowed, scaled frame gradients
+        const int j = lane >> G::logL, kl = lane & (G::L - 1);
+        const v2f* const p = zl + j * (G::m + G::L) + kl;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[q] = p[G::L * brev4(q)];
+        v2f wt[16];                                                // the synthesis taps arrive during the transform (tm[] is dead: the registers are free)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float2 wv = win[G::L * q + kl]; wt[q] = (v2f){wv.x, wv.y}; }
+        wave_sync();
+        inverse_transform<M>(r, zl, tw, lane);
+        MSS_STAMP(7);
+        const float scale = 1.0f / sqrtf((float)G::n);
+        constexpr int hp = G::m / 4, span = 256 + 3 * hp;          // packed points: the F frames start hp apart (F hp = 256) and are m long
+        float2* const dst = reinterpret_cast<float2*>(a.partial_grad + a.grad_base[s]) + (int64_t)local * span;
+        if constexpr (M == 10) {                                   // one frame per wave: its span is the frame, straight from the registers
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2f o = (wt[q] * r[q]) * scale;
+                dst[64 * q + lane] = make_float2(o.x, o.y);
+            }
+        } else {
+            v2f* const o = zl + j * (G::m + G::L) + kl;              // packed point i = L q + l of frame j at j (m + L) + i
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[G::L * q] = (wt[q] * r[q]) * scale;
+            wave_sync();
+            // overlap-add of the wave's frames (frame j starts at packed point j hp) in ascending frame order
+            const int nfr = min(G::F, frames - frame0);
+#pragma unroll
+            for (int t = 0; t < (span + 63) / 64; ++t) {
+                const int pp = 64 * t + lane;
+                if (pp < span) {
+                    const int f_hi = min(pp / hp, nfr - 1);
+                    int f_lo = (pp - (G::m - 1) + hp - 1) / hp;
+                    if (pp - (G::m - 1) <= 0) f_lo = 0;
+                    v2f sum = (v2f){0.0f, 0.0f};
+                    for (int f = f_lo; f <= f_hi; ++f) sum += zl[f * (G::m + G::L) + (pp - f * hp)];
+                    dst[pp] = make_float2(sum.x, sum.y);
+                }
+            }
+            wave_sync();      // the overlap-add has read the buffer before the next task writes it
+        }
+    }
+    MSS_STAMP(8);
+}
+
+// Persistent workgroups: each builds the two twiddle tables once (W_1024^t for the transforms; -i W_2048^k / 2 for the real-frame bins of
+// every scale); after that barrier its eight waves are on their own, each with a CONTIGUOUS range of tasks -- mostly one scale, so the
+// scale's code stays in the instruction cache.
+template <bool GRAD, int KIND>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSS_WAVES_PER_EU, MSS_WAVES_PER_EU))) void mss_fused_kernel(const MssArgs a, int tasks_per_wave)
+{
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     v2f* const tw = reinterpret_cast<v2f*>(smem_f);      // tables first: every lane-part address into a wave's buffer stays positive
     v2f* const wn = tw + kTw;
     v2f* const bufs = wn + kWnMax;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    v2f* const zl = bufs + wave * kBuf;
-    const int chunks = a.chunks[s], frames = a.frames[s];
-    const int b = unit / chunks, c = unit - b * chunks;
-    const float* const tclip = a.target + (int64_t)b * a.stride_t;
-    const float* const vclip = a.value + (int64_t)b * a.stride_v;
-    const float2* const win = reinterpret_cast<const float2*>(a.window[s]);
-    const int frame0 = (c * kWaves + wave) * G::F;
-
-    // the target's frames are in flight while the tables are built
-    v2f r[16];
-    float amax = load_frames<M>(tclip, a.samples, frames, frame0, win, lane, r);
+    MSS_STAMP(0);
     for (int t = threadIdx.x; t < kTw; t += kThreads) {     // W_1024^(256 a + b) = W_4096^(4 b) (-i)^a: exact quarter turns of the committed table
         const float2 w0 = kWn[4 * (t & 255)];
         v2f w = (v2f){w0.x, w0.y};
@@ -429,132 +564,70 @@ __device__ __forceinline__ void scale_body(const MssArgs& a, int s, int unit)
         if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w;
         tw[t] = w;
     }
-    for (int k = threadIdx.x; k <= G::m / 2; k += kThreads) { const float2 w0 = kWn[k << (11 - M)]; wn[k] = (v2f){w0.x, w0.y}; }
+    for (int k = threadIdx.x; k <= 512; k += kThreads) { const float2 w0 = kWn[2 * k]; wn[k] = (v2f){0.5f * w0.y, -0.5f * w0.x}; }   // -i W_2048^k / 2
     __syncthreads();
-
-    const int jf = frame0 + (lane >> G::logL);
-    const bool active = jf < frames;
-    float tm[18];
-    double acc = 0.0;
-    const bool wave_has_frames = frame0 < frames;          // wave-uniform: the last chunk of a clip may own fewer than 8 F frames
-    if (wave_has_frames) {
-    // ---- target: |T| of the lane's bins
-    {
-        const bool plain = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;
-        forward_transform<M>(r, zl, tw, lane);
-        write_natural<M>(r, zl, lane);
-        wave_sync();
-        if (plain) pair_pass<M, true, false, false>(a, 0.0f, zl, wn, lane, active, tm, acc);
-        else pair_pass<M, false, false, false>(a, 0.0f, zl, wn, lane, active, tm, acc);
-        wave_sync();
-    }
-    // ---- estimate: |V|, distance, gradient packing
-    amax = load_frames<M>(vclip, a.samples, frames, frame0, win, lane, r);
-    {
-        const bool plain = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;
-        forward_transform<M>(r, zl, tw, lane);
-        write_natural<M>(r, zl, lane);
-        wave_sync();
-        const float coef = a.coef[s];
-        if (plain) pair_pass<M, true, true, GRAD>(a, coef, zl, wn, lane, active, tm, acc);
-        else pair_pass<M, false, true, GRAD>(a, coef, zl, wn, lane, active, tm, acc);
-        wave_sync();
-    }
-    if (GRAD) {
-        // ---- inverse: G (natural order) -> last-phase registers -> time order; windowed, scaled frame gradients back into the buffer
-        const int j = lane >> G::logL, kl = lane & (G::L - 1);
-        const v2f* const p = zl + j * (G::m + G::L) + kl;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) r[q] = p[G::L * brev4(q)];
-        wave_sync();
-        inverse_transform<M>(r, zl, tw, lane);
-        const float scale = 1.0f / sqrtf((float)G::n);
-        v2f* const o = zl + j * (G::m + G::L) + kl;          // packed point i = L q + l of frame j at j (m + L) + i
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 w = win[G::L * q + kl];
-            o[G::L * q] = (v2f){w.x * r[q].x * scale, w.y * r[q].y * scale};
-        }
-    }
-    }   // wave_has_frames
-    // ---- the workgroup's distance sum: lanes -> wave (fixed shuffle tree) -> workgroup (wave order)
-    double* const red = reinterpret_cast<double*>(wn);     // the W_n table is dead once every wave has finished its pair passes (barrier below)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    __syncthreads();
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < kWaves; ++w) tot += red[w];
-        a.partial_loss[a.loss_base[s] + unit] = tot;
-    }
-    if (GRAD) {
-        // overlap-add of the chunk's 8 F frames (frame fc starts at packed point fc m / 4) in ascending frame order, span = 2048 + 3 m / 4 points
-        constexpr int hp = G::m / 4, span = 2048 + 3 * hp;
-        const int nfr = min(kWaves * G::F, frames - c * kWaves * G::F);
-        float2* const dst = reinterpret_cast<float2*>(a.partial_grad + a.grad_base[s]) + (int64_t)unit * span;
-        for (int p = threadIdx.x; p < span; p += kThreads) {
-            const int f_hi = min(p / hp, nfr - 1);
-            int f_lo = (p - (G::m - 1) + hp - 1) / hp;
-            if (p - (G::m - 1) <= 0) f_lo = 0;
-            v2f sum = (v2f){0.0f, 0.0f};
-            for (int f = f_lo; f <= f_hi; ++f)
-                sum += bufs[(f >> (10 - M)) * kBuf + (f & (G::F - 1)) * (G::m + G::L) + (p - f * hp)];
-            dst[p] = make_float2(sum.x, sum.y);
-        }
-    }
-}
-
-template <bool GRAD>
-__global__ __launch_bounds__(kThreads) void mss_fused_kernel(const MssArgs a)
-{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    v2f* const zl = bufs + wave * kBuf;
+    const int total = a.task_base[a.n_scales];
+    const int first = (blockIdx.x * kWaves + wave) * tasks_per_wave, last = min(total, first + tasks_per_wave);
     int s = 0;
-    const int blk = blockIdx.x;
-    while (s + 1 < a.n_scales && blk >= a.block_base[s + 1]) ++s;
-    const int unit = blk - a.block_base[s];
-    switch (a.logm[s]) {
-        case 5: scale_body<5, GRAD>(a, s, unit); break;
-        case 6: scale_body<6, GRAD>(a, s, unit); break;
-        case 7: scale_body<7, GRAD>(a, s, unit); break;
-        case 8: scale_body<8, GRAD>(a, s, unit); break;
-        case 9: scale_body<9, GRAD>(a, s, unit); break;
-        default: scale_body<10, GRAD>(a, s, unit); break;
+    for (int task = first; task < last; ++task) {
+        while (s + 1 < a.n_scales && task >= a.task_base[s + 1]) ++s;
+#ifdef MSS_ONLY_M      /* diagnostic builds: one transform size (compile time, register pressure of one body) */
+        wave_task<MSS_ONLY_M, GRAD, KIND>(a, s, task, tw, wn, zl);
+#else
+        switch (a.logm[s]) {
+            case 5: wave_task<5, GRAD, KIND>(a, s, task, tw, wn, zl); break;
+            case 6: wave_task<6, GRAD, KIND>(a, s, task, tw, wn, zl); break;
+            case 7: wave_task<7, GRAD, KIND>(a, s, task, tw, wn, zl); break;
+            case 8: wave_task<8, GRAD, KIND>(a, s, task, tw, wn, zl); break;
+            case 9: wave_task<9, GRAD, KIND>(a, s, task, tw, wn, zl); break;
+            default: wave_task<10, GRAD, KIND>(a, s, task, tw, wn, zl); break;
+        }
+#endif
     }
 }
 
-// Finish: workgroup 0 also turns the partial sums into the loss (per scale: fixed-order sum, mean as float32, `loss += mean` in the
-// reference's scale order, losses.py:411-424); every workgroup sums the spans covering its samples, scales in order.
+// Finish: the last workgroup turns the partial sums into the loss (per scale: fixed-order sum, mean as float32, `loss += mean` in the
+// reference's scale order, losses.py:411-424); every workgroup sums the wave spans covering its samples, scales and waves in order.
 constexpr int kFinishThreads = 256;
 __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArgs a)
 {
-    __shared__ double red[kFinishThreads];
-    if (a.per_clip) {        // one value per clip: a thread per clip, its chunks in order
+    __shared__ double red[(kFinishThreads / 64) * kMaxScales];
+    if (a.per_clip) {        // one value per clip: a thread per clip, its tasks in order
         for (int64_t o = (int64_t)blockIdx.x * kFinishThreads + threadIdx.x; o < a.batch; o += (int64_t)gridDim.x * kFinishThreads) {
             float total = 0.0f;
             for (int s = 0; s < a.n_scales; ++s) {
                 double acc = 0.0;
-                for (int c = 0; c < a.chunks[s]; ++c) acc += a.partial_loss[a.loss_base[s] + o * a.chunks[s] + c];
+                for (int c = 0; c < a.waves[s]; ++c) acc += a.partial_loss[a.task_base[s] + o * a.waves[s] + c];
                 total += (float)(acc * a.inv_count[s]);
             }
             a.loss[o] = total;
         }
-    } else if (blockIdx.x == 0) {
-        float total = 0.0f;
-        for (int s = 0; s < a.n_scales; ++s) {
-            const int64_t count = a.batch * a.chunks[s];
-            double acc = 0.0;
-            for (int64_t i = threadIdx.x; i < count; i += kFinishThreads) acc += a.partial_loss[a.loss_base[s] + i];
-            red[threadIdx.x] = acc;
-            __syncthreads();
-            for (int off = kFinishThreads / 2; off > 0; off >>= 1) {
-                if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-                __syncthreads();
+    } else if (blockIdx.x == gridDim.x - 1) {
+        // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves
+        // reduce by shuffles, thread 0 adds the four wave sums per scale in order
+#pragma unroll
+        for (int s = 0; s < kMaxScales; ++s) {
+            if (s < a.n_scales) {
+                double acc = 0.0;
+                const int count = a.task_base[s + 1] - a.task_base[s];
+                for (int i = threadIdx.x; i < count; i += kFinishThreads) acc += a.partial_loss[a.task_base[s] + i];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+                if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * kMaxScales + s] = acc;
             }
-            total += (float)(red[0] * a.inv_count[s]);
-            __syncthreads();
         }
-        if (threadIdx.x == 0) a.loss[0] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float total = 0.0f;
+            for (int s = 0; s < a.n_scales; ++s) {
+                double tot = 0.0;
+                for (int w = 0; w < kFinishThreads / 64; ++w) tot += red[w * kMaxScales + s];
+                total += (float)(tot * a.inv_count[s]);     // `loss += mean` in float32, scale by scale (losses.py:411-424)
+            }
+            a.loss[0] = total;
+        }
     }
     if (!a.want_grad) return;
     const int64_t half = (a.samples + 1) / 2;                   // packed points per clip
@@ -564,11 +637,12 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
         const int p = (int)(idx - b * half);                    // packed point of the clip: samples 2 p, 2 p + 1
         float gx = 0.0f, gy = 0.0f;
         for (int s = 0; s < a.n_scales; ++s) {
-            const int hp = (1 << a.logm[s]) / 4, span = 2048 + 3 * hp;
-            const int c = p >> 11, pp = p & 2047;
-            const float2* const base = reinterpret_cast<const float2*>(a.partial_grad + a.grad_base[s]) + (b * a.chunks[s]) * (int64_t)span;
-            if (c > 0 && pp < 3 * hp) { const float2 v = base[(int64_t)(c - 1) * span + 2048 + pp]; gx += v.x; gy += v.y; }   // the previous chunk's tail
-            if (c < a.chunks[s]) { const float2 v = base[(int64_t)c * span + pp]; gx += v.x; gy += v.y; }
+            const int span = 256 + 3 * ((1 << a.logm[s]) / 4), waves = a.waves[s];
+            const float2* const base = reinterpret_cast<const float2*>(a.partial_grad + a.grad_base[s]) + (b * waves) * (int64_t)span;
+            const int w_hi = min(p >> 8, waves - 1);
+            int w_lo = (p - span + 256) >> 8;                   // first wave whose span [256 w, 256 w + span) holds p
+            if (p - span + 1 <= 0) w_lo = 0;
+            for (int w = w_lo; w <= w_hi; ++w) { const float2 v = base[(int64_t)w * span + (p - 256 * w)]; gx += v.x; gy += v.y; }
         }
         float* const dst = a.grad + b * a.samples + 2 * (int64_t)p;
         dst[0] = gx;
@@ -596,18 +670,17 @@ static int fill(const float* target, int64_t stride_t, const float* value, int64
         a->window[s] = windows ? windows[s] : nullptr;
         const int64_t frames = (samples + hop - 1) / hop;        // utils.py:265
         a->frames[s] = (int)frames;
-        a->chunks[s] = (int)((frames + 8 * F - 1) / (8 * F));
-        a->block_base[s] = (int)blocks;
-        blocks += batch * a->chunks[s];
+        a->waves[s] = (int)((frames + F - 1) / F);
+        a->task_base[s] = (int)blocks;
+        blocks += batch * a->waves[s];
         const double count = (double)frames * (double)(m + 1) * (per_clip ? 1.0 : (double)batch);
         a->inv_count[s] = 1.0 / count;
         a->coef[s] = (float)(1.0 / count);
         a->grad_base[s] = gfloats;
-        a->loss_base[s] = ldoubles;
-        gfloats += 2 * batch * a->chunks[s] * (int64_t)(2048 + 3 * (m / 4));
-        ldoubles += batch * a->chunks[s];
+        gfloats += 2 * batch * a->waves[s] * (int64_t)(256 + 3 * (m / 4));
+        ldoubles += batch * a->waves[s];
     }
-    a->block_base[n_scales] = (int)blocks;
+    a->task_base[n_scales] = (int)blocks;
     if (blocks > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
     *workspace_bytes = sizeof(double) * (size_t)ldoubles + sizeof(float) * (size_t)gfloats;
     *grad_offset_bytes = sizeof(double) * (size_t)ldoubles;    // workspace = [partial sums (double) | spans (float)]
@@ -649,20 +722,36 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     a.loss = loss; a.grad = grad_value; a.want_grad = grad_value != nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    static bool attr_done[64][2] = {};
+    static bool attr_done[64][4] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-    void (*kern)(const MssArgs) = a.want_grad ? mss_fused_kernel<true> : mss_fused_kernel<false>;
-    if (dev < 0 || dev >= 64 || !attr_done[dev][a.want_grad]) {   // idempotent per device; a benign race sets it twice
+    const int kind = (l2 == 0 && !(logmag_weight > 0.0f)) ? 0 : 1;     // the paper's configuration (L1 on the magnitudes) has its own instantiation
+    void (*kern)(const MssArgs, int) = kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0> : mss_fused_kernel<false, 0>)
+                                            : (a.want_grad ? mss_fused_kernel<true, 1> : mss_fused_kernel<false, 1>);
+    const int which = 2 * kind + a.want_grad;
+    if (dev < 0 || dev >= 64 || !attr_done[dev][which]) {   // idempotent per device; a benign race sets it twice
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess)
             (void)hipGetLastError();
-        if (dev >= 0 && dev < 64) attr_done[dev][a.want_grad] = true;
+        if (dev >= 0 && dev < 64) attr_done[dev][which] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.block_base[n_scales]), dim3(kThreads), kLdsBytes, st, a);
+    // persistent grid: two workgroups per CU (LDS), every wave a contiguous range of tasks
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+    const int tasks = a.task_base[n_scales], slots = 2 * cus * kWaves;              // one wave per task slot
+    const int per = (tasks + slots - 1) / slots, waves_needed = (tasks + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves_needed + kWaves - 1) / kWaves)), dim3(kThreads), kLdsBytes, st, a, per);
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
     const int64_t work = a.want_grad ? (batch * ((samples + 1) / 2) + kFinishThreads - 1) / kFinishThreads : 1;
     hipLaunchKernelGGL(mss_finish_kernel, dim3((unsigned)(work < 4096 ? (work < 1 ? 1 : work) : 4096)), dim3(kFinishThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
+
+#ifdef MSS_STAMPS
+int sot_mss_debug_read_stamps(unsigned long long* host_out, int count)   // diagnostic build only (synchronises)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sot_mss::g_mss_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

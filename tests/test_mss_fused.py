@@ -69,8 +69,14 @@ def _check(mod, x, y, dims=None, weights=None, loss_tol=1e-5):
     g = yd.grad.cpu().double()
     ref_err = float(torch.linalg.norm(g32.double() - g64) / torch.linalg.norm(g64))
     hip_err = float(torch.linalg.norm(g - g64) / torch.linalg.norm(g64))
-    # the HIP gradient is as close to float64 as the reference's own float32 gradient is (sign() kinks, 1 / v of the log term)
-    assert hip_err <= 1.5 * ref_err + 2e-6, (hip_err, ref_err)
+    # the HIP gradient is as close to float64 as the reference's own float32 gradient is.  Per scale and in most cases the two errors are
+    # equal (3e-6; tools/r5/mss_accuracy.py); a bin whose |V| sits at the rounding floor hands its gradient g V / |V| a direction that is noise
+    # in ANY float32 FFT -- there both errors jump (reference 2.4e-5, HIP 4e-5 ... 9e-5 depending on the rounding of the products: observed at
+    # one bin of n_fft 128 in the 5 x 4096 case), hence the factor 4 rather than 1.5
+    assert hip_err <= 4.0 * ref_err + 5e-6, (hip_err, ref_err)
+    med_hip = float((g - g64).abs().median() / g64.abs().max())
+    med_ref = float((g32.double() - g64).abs().median() / g64.abs().max())
+    assert med_hip <= 1.5 * med_ref + 1e-8, (med_hip, med_ref)
     return got.detach(), yd.grad.detach()
 
 
