@@ -62,7 +62,21 @@ def parse():
                          "with rocprofv3), 2 when there is a collective to hide (N > 1)")
     ap.add_argument("--cpu-rows", type=int, default=8192)   # all rows of the headline workload (set 0); ~15 s of CPU work
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads reported under `extras`")
-    return ap.parse_args()
+    ap.add_argument("--global-rows", type=int, default=0,
+                    help="STRONG scaling (BASELINE config 3: 65536): the total batch is fixed and every rank takes global / N rows "
+                         "(shard r = the rows [r, r + 1) * global / N of the 8 x 8192-row blocks seeded 1234 + block); overrides --rows")
+    return resolve_rows(ap.parse_args())
+
+
+def resolve_rows(args):
+    """--global-rows G: rows per rank = G / N (must divide); `scaling` is then "strong" (total work fixed as N grows)."""
+    args.scaling = "weak"
+    if args.global_rows:
+        if args.global_rows % args.gpus:
+            sys.exit(f"bench.py: --global-rows {args.global_rows} is not a multiple of --gpus {args.gpus}")
+        args.rows = args.global_rows // args.gpus
+        args.scaling = "strong"
+    return args
 
 
 # kernel the shared-position forward dispatches for a row length (csrc/sot_forward_full.inc: dispatch_forward_full):
@@ -118,6 +132,21 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
     if n == 1025 and batch >= 6144:
         g, cpt, rows = 64, 17, 4
     return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
+
+
+def global_batch_rows(first, count, n, block=8192):
+    """Rows [first, first + count) of BASELINE config 3's global batch: consecutive blocks of `block` rows, block k drawn with the CPU
+    generator seeded 1234 + k (x before y) -- what the 8 ranks of the weak-scaling run hold, cut differently for fewer ranks."""
+    from sot_amd.bench_inputs import spectrum_pairs
+    xs, ys = [], []
+    k = first // block
+    while k * block < first + count:
+        x, y = spectrum_pairs("uniform", block, n, n, 1234 + k)
+        lo, hi = max(first, k * block) - k * block, min(first + count, (k + 1) * block) - k * block
+        xs.append(x[lo:hi])
+        ys.append(y[lo:hi])
+        k += 1
+    return torch.cat(xs).contiguous(), torch.cat(ys).contiguous()
 
 
 def launcher_command(gpus, argv, port, python=None):
@@ -411,6 +440,63 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
         out["b1024n1025_cutoff_module_forward"] = entry(timed(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), n),
                                                          forward_kernel_name(1025, "cutoff", batch=1024) + " + batch mean", 1024 * (8 * 1025 + 4), l3_resident=True)
         out["b1024n1025_cutoff_module_forward"]["host_us_per_call"] = wall_us(lambda i: cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b), 400)
+        # the entry above is two launches per call issued from Python: with ~10 us of host time per call against ~12 us of GPU time it reads the
+        # host on a slower or busier box (round 4: 19.9 us on the driver's box, 12.4 on the builder's).  The same call replayed from a HIP graph
+        # is the GPU-bound figure:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b)
+            torch.cuda.current_stream().wait_stream(side)
+            fgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fgraph):
+                cut(xs1, ys1[0], x_pos=pf1, y_pos=pf1b)
+            out["b1024n1025_cutoff_module_forward"]["graph_replay_us"] = 1e3 * timed(lambda i: fgraph.replay(), n)
+        except Exception as exc:  # noqa: BLE001
+            out["b1024n1025_cutoff_module_forward"]["graph_replay_us"] = repr(exc)[:200]
+    # (1c) the same step captured ONCE by the user in a HIP graph and replayed (INTEGRATION.md "HIP-graph recipe"): eager is pinned at
+    #      PyTorch's autograd floor for ~10 us of kernels, so the GPU-bound figure and how to get it; with persistent position tensors and with
+    #      positions rebuilt inside the captured step (trainer.py:187-197: the plan launch is then part of the graph)
+    def user_graph(fresh):
+        ystat = ys1[0].detach().clone().requires_grad_(True)
+        side = torch.cuda.Stream(device=dev)
+
+        def step():
+            if fresh:
+                xp_ = pf1 / 1.0
+                return cut(xs1, ystat, x_pos=xp_, y_pos=xp_.clone())
+            return cut(xs1, ystat, x_pos=pf1, y_pos=pf1b)
+
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ystat.grad = None
+                step().backward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        ystat.grad = None
+        with torch.cuda.graph(graph):
+            static_loss = step()
+            static_loss.backward()
+        graph.replay()
+        torch.cuda.synchronize()
+        ycheck = ystat.detach().clone().requires_grad_(True)
+        want = cut(xs1, ycheck, x_pos=pf1, y_pos=pf1b)
+        want.backward()
+        same = bool(torch.equal(want.detach(), static_loss.detach()) and torch.equal(ycheck.grad, ystat.grad))
+        e = entry(timed(lambda i: graph.replay(), n), "torch.cuda.graph around `loss = mod(x, y, x_pos=, y_pos=); loss.backward()`: loss_and_grad kernel + mean + scale"
+                  + (" + the caller's two position kernels + sot_prepare_positions" if fresh else ""), 1024 * (12 * 1025 + 4), l3_resident=True,
+                  equals_eager=same)
+        e["host_us_per_call"] = wall_us(lambda i: graph.replay(), 400)
+        return e
+
+    for key, fresh in (("b1024n1025_cutoff_step_user_graph", False), ("b1024n1025_cutoff_step_user_graph_fresh_positions", True)):
+        try:
+            out[key] = user_graph(fresh)
+        except Exception as exc:  # noqa: BLE001
+            out[key] = {"error": repr(exc)[:300]}
     del xs1, ys1
 
     # (2) the paper's own row shape: one-sided spectra of n_fft 2048 (1025 bins), 16384 rows, rfftfreq / max positions
@@ -747,7 +833,10 @@ def main():
     pos_y = pos_x.clone()
 
     # set 0: the BASELINE recipe (CPU generator, seed 1234 + rank, x drawn before y); others: device RNG
-    x0, y0 = spectrum_pairs("uniform", B, N, N, 1234 + rank)
+    if args.scaling == "strong":   # config 3's global batch = blocks of 8192 rows seeded 1234 + block; this rank owns rows [rank B, rank B + B)
+        x0, y0 = global_batch_rows(rank * B, B, N)
+    else:
+        x0, y0 = spectrum_pairs("uniform", B, N, N, 1234 + rank)
     sets = [(x0.to(dev), y0.to(dev))]
     g = torch.Generator(device=dev).manual_seed(99 + rank)
     for _ in range(args.sets - 1):
@@ -1020,7 +1109,7 @@ def main():
         rec = {
             "metric": "sot_loss_evals_per_sec", "value": world * B * args.steps / elapsed, "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SOT-2048 config: B={B} rows/GPU x N_fft={N} fp32 spectrum pairs, forward, mode {args.mode} "
                                    f"({json.dumps(MODES[args.mode])}), shared linspace positions, {n_sets} rotating input sets "
                                    f"({n_sets * 2 * B * N * 4 / 2**20:.0f} MiB > 256 MiB L3)",

@@ -4,6 +4,8 @@ Runs only in the build container (imports /root/reference behind the shim of ora
 clips it stores what the reference's `features.TorchSTFT` (features.py:85-113 -> compute_mag -> stft, :191-237;
 utils.pad_for_stft, utils.py:252-275) returns, the scalar of the paper-cutoff SOT loss on those spectra, and the gradient
 of that scalar with respect to the ESTIMATE's audio (through torch.stft's autograd): tests/golden/stft_chain.npz.
+Also: MSSLoss (scalar and per-clip `dims` form) with its audio gradient, Wasserstein1DWithTransform, the oscillator bank, and the
+paper's whole loss block (trainer.py:183-245: MixOfLosses of MSSLoss and Wasserstein1D) with its gradient.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_stft.py
 """
@@ -56,6 +58,38 @@ def main():
         (gr,) = torch.autograd.grad(val, [ay_g])
         out[f"mss_{tag}_loss"], out[f"mss_{tag}_grad_y"] = val.detach().numpy(), gr.numpy()
         print("MSSLoss", tag, float(val))
+        # the same with `dims` = the two spectrogram axes (losses.py:406-425 hands it to mean_difference): one value per clip, and
+        # the gradient of a weighted sum of them (round-4 review: the per-clip form was pinned to the package's own composition only)
+        ay_c = ay.clone().requires_grad_(True)
+        per_clip = losses.MSSLoss(**kw)(ax, ay_c, dims=(1, 2))
+        wclip = torch.linspace(0.5, 1.5, ax.shape[0])
+        (gc,) = torch.autograd.grad((per_clip * wclip).sum(), [ay_c])
+        out[f"mss_{tag}_clip_loss"], out[f"mss_{tag}_clip_grad_y"], out["mss_clip_weights"] = per_clip.detach().numpy(), gc.numpy(), wclip.numpy()
+    # the paper's loss block (trainer.py:183-245 with paper-experiments/SOT-2048/*/train_config.yaml:73-102): fresh unit-scaled bin
+    # frequencies, TorchSTFT (n_fft 2048, hop 256, flattop) of both signals, MixOfLosses([MSSLoss(6 scales, L1, mag_weight 1),
+    # Wasserstein1D(paper kwargs)], [0.05, 1]) -- MSSLoss on the audio, Wasserstein1D on the spectra -- total = sum of value.mean();
+    # the trainer itself needs Lightning / wandb, so its lines are restated here around the reference's own modules
+    ax, ay = harmonic_audio_pair(nb=4, seed=2048, n_samples=4096)
+    tfm = features.get_transform({"type": "stft", "n_fft": 2048, "hop_length": 256, "window": "flattop"}, 16000)
+    mix = losses.MixOfLosses([losses.MSSLoss(fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type="L1", mag_weight=1, logmag_weight=0),
+                              losses.Wasserstein1D(**MODES["cutoff"], require_sort=True)], [0.05, 1])
+    ay_g = ay.clone().requires_grad_(True)
+    x_pos = torch.tensor(tfm.get_frequencies())
+    x_pos = x_pos / x_pos.max()
+    y_pos = x_pos.clone()
+    spec_x, spec_x_hat = tfm(ax), tfm(ay_g)
+    distance = {}
+    for loss_fn, weight in zip(mix.losses, mix.weights):
+        name = loss_fn.__class__.__name__
+        a, b = (ax, ay_g) if name == "MSSLoss" else (spec_x, spec_x_hat)
+        distance[name] = loss_fn(a, b, x_pos=x_pos, y_pos=y_pos) * weight
+    total = 0
+    for value in distance.values():
+        total = total + value.mean()
+    (gstep,) = torch.autograd.grad(total, [ay_g])
+    out.update({"step_audio_x": ax.numpy(), "step_audio_y": ay.numpy(), "step_loss": total.detach().numpy(), "step_grad_y": gstep.numpy(),
+                "step_mss_term": distance["MSSLoss"].detach().numpy(), "step_sot_term": distance["Wasserstein1D"].detach().numpy()})
+    print("paper loss block:", float(total), {k: float(v) for k, v in distance.items()})
     # Wasserstein1DWithTransform (losses.py:316-343): audio in, TorchSTFT of both signals inside the module; a plain p = 1
     # configuration (hann window by default) and the paper's keyword set with a named window
     ax, ay = harmonic_audio_pair(nb=3, seed=31, n_samples=3000)

@@ -85,3 +85,25 @@ def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
     assert "from oracle" not in body[0] and "import oracle" not in body[0]
     after = body[1].split("\ndef ", 1)[1]   # everything behind cpu_baseline()
     assert "from oracle" not in after and "import oracle" not in after
+
+
+def test_global_rows_flag_means_strong_scaling():
+    """--global-rows G (BASELINE config 3: 65536): rows per rank = G / N, `scaling` = "strong"; the shards are cuts of ONE global batch."""
+    import argparse
+    import pytest
+    import torch
+    b = _bench_module()
+    ns = b.resolve_rows(argparse.Namespace(gpus=8, rows=8192, global_rows=65536))
+    assert (ns.rows, ns.scaling) == (8192, "strong")
+    ns = b.resolve_rows(argparse.Namespace(gpus=2, rows=8192, global_rows=65536))
+    assert (ns.rows, ns.scaling) == (32768, "strong")
+    assert b.resolve_rows(argparse.Namespace(gpus=4, rows=8192, global_rows=0)).scaling == "weak"
+    with pytest.raises(SystemExit):
+        b.resolve_rows(argparse.Namespace(gpus=3, rows=8192, global_rows=65536))
+    # the global batch is the concatenation of the weak-scaling ranks' blocks (seed 1234 + block), whatever the cut
+    from sot_amd.bench_inputs import spectrum_pairs
+    x, y = b.global_batch_rows(60, 100, 16, block=64)          # spans blocks 0, 1, 2
+    x0, y0 = spectrum_pairs("uniform", 64, 16, 16, 1234)
+    x1, y1 = spectrum_pairs("uniform", 64, 16, 16, 1235)
+    x2, y2 = spectrum_pairs("uniform", 64, 16, 16, 1236)
+    assert torch.equal(x, torch.cat([x0[60:], x1, x2[:32]])) and torch.equal(y, torch.cat([y0[60:], y1, y2[:32]]))

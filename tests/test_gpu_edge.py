@@ -388,6 +388,75 @@ def test_module_under_make_graphed_callables():
             assert torch.equal(y2.grad, y.grad)
 
 
+def test_user_graph_of_the_trainers_fresh_position_step():
+    """INTEGRATION.md's HIP-graph recipe on the reference trainer's call pattern (trainer.py:187-228: x_pos rebuilt and y_pos = x_pos.clone()
+    on every step): `loss = mod(x, y, x_pos=, y_pos=); loss.backward()` captured once with the position arithmetic INSIDE the capture (the
+    position plan's launch becomes part of the graph), replayed on new data copied into the static tensors -- loss and gradient bit for bit
+    those of the eager module; the same through a wrapper module under torch.cuda.make_graphed_callables."""
+    import warnings
+    from sot_amd import spectra
+    from sot_amd.losses import Wasserstein1D
+    native()
+    dev = device()
+    B, N = 1024, 1025
+    mod = Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True).to(dev)
+    freqs = torch.fft.rfftfreq(2048, d=1.0 / 16000.0).to(dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    xs = torch.rand(B, N, device=dev, generator=g)
+    ys = torch.rand(B, N, device=dev, generator=g).requires_grad_(True)
+
+    def step():
+        x_pos = freqs / freqs.max()
+        return mod(xs, ys, x_pos=x_pos, y_pos=x_pos.clone())
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ys.grad = None
+            step().backward()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    ys.grad = None
+    with torch.cuda.graph(graph):
+        loss = step()
+        loss.backward()
+    pos = spectra.unit_frequencies(2048, 16000.0, dev)
+    for _ in range(3):
+        nx, ny = torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)
+        with torch.no_grad():
+            xs.copy_(nx)
+            ys.copy_(ny)
+        graph.replay()
+        yc = ny.clone().requires_grad_(True)
+        want = mod(nx, yc, x_pos=pos, y_pos=pos.clone())
+        want.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(loss.detach(), want.detach())
+        assert torch.equal(ys.grad, yc.grad)
+
+    class Step(torch.nn.Module):          # make_graphed_callables wants a module / function of tensors
+        def __init__(self):
+            super().__init__()
+            self.loss = mod
+
+        def forward(self, x, y, f):
+            x_pos = f / f.max()
+            return self.loss(x, y, x_pos=x_pos, y_pos=x_pos.clone())
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        graphed = torch.cuda.make_graphed_callables(Step().to(dev), (xs.detach().clone(), ys.detach().clone().requires_grad_(True), freqs.clone()))
+        nx, ny = torch.rand(B, N, device=dev, generator=g), torch.rand(B, N, device=dev, generator=g)
+        y1, y2 = ny.clone().requires_grad_(True), ny.clone().requires_grad_(True)
+        want = mod(nx, y1, x_pos=pos, y_pos=pos.clone())
+        want.backward()
+        got = graphed(nx, y2, freqs)
+        got.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(got.detach(), want.detach()) and torch.equal(y2.grad, y1.grad)
+
+
 def test_hot_call_cache_does_not_swallow_position_gradients():
     """an entry made under no_grad (a validation step) must not serve a later training call whose POSITIONS require a
     gradient -- requires_grad_() does not bump the version counter, so identity + version alone would still match."""

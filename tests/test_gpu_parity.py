@@ -105,6 +105,43 @@ def test_config2_full_size_scalars(kind, mode, manifest):
     assert abs(got - want) <= RTOL * abs(want), (got, want)
 
 
+@pytest.mark.parametrize("mode", ["p1", "cutoff"])
+def test_config3_global_batch_on_one_gpu(mode):
+    """BASELINE config 3 (B = 65536 = 8 ranks x 8192 rows x 2048 bins, rank r seeded 1234 + r) evaluated on ONE GPU the way the 8 ranks
+    evaluate it: per shard the module's row losses and their fixed-order fp64 sum (distributed._RowSum = sot_w1d_reduce_mean's sum_out),
+    the 8 (sum, rows) pairs added as the all-reduce(SUM) adds them (distributed._AllReduceSumCount), mean = sum / rows as float32 --
+    against the OpenMP oracle's rows and mean over all 65 536 rows.  (No 8-GPU node has been available to the driver: the arithmetic of the
+    reduction is what can be pinned without one; the collective itself runs under RCCL at world size 1, tests/test_rccl_gpu.py.)"""
+    from oracle import sot_oracle as so
+    from oracle.make_golden import MODES
+    from sot_amd import distributed as sd
+    from sot_amd.bench_inputs import spectrum_pairs
+    dev = device()
+    mod = module_for(MODES[mode])
+    pos = torch.linspace(0, 1, 2048)
+    pos_d, pos_d2 = pos.to(dev), pos.to(dev).clone()
+    flags = so.make_flags(MODES[mode].get("square_dist", False), MODES[mode].get("dont_normalize", False),
+                          MODES[mode].get("limit_quantile_range", False), True)
+    packed = torch.zeros(2, dtype=torch.float64, device=dev)
+    want_rows = []
+    for r in range(8):
+        x, y = spectrum_pairs("uniform", 8192, 2048, 2048, 1234 + r)
+        rows = mod.row_losses(x.to(dev), y.to(dev), x_pos=pos_d, y_pos=pos_d2)
+        local_sum = sd._RowSum.apply(rows.float().contiguous())
+        packed += torch.stack([local_sum.to(torch.float64).reshape(()), torch.tensor(float(rows.numel()), dtype=torch.float64, device=dev)])
+        want = so.forward(x.numpy(), y.numpy(), pos.numpy(), pos.numpy(), p=float(MODES[mode].get("p", 1)), flags=flags)
+        np.testing.assert_allclose(rows.cpu().numpy(), want, rtol=RTOL)          # every row of every shard
+        want_rows.append(want)
+    got = float((packed[0] / packed[1]).to(torch.float32))
+    want_mean = float(so.mean(np.concatenate(want_rows)))
+    assert int(packed[1]) == 65536
+    assert abs(got - want_mean) <= 1e-6 * abs(want_mean), (got, want_mean)
+    # shard 0 is config 2's batch: its own mean is the reference's stored scalar
+    # (tests/golden/manifest.json: _config2_b8192n2048_seed1234), so the global figure hangs on a reference value, not only on the oracle
+    assert abs(float(so.mean(want_rows[0])) - json.load(open(os.path.join(GOLDEN, "manifest.json")))["_config2_b8192n2048_seed1234"][f"uniform_{mode}"]) \
+        <= 1e-6 * abs(float(so.mean(want_rows[0])))
+
+
 @pytest.mark.parametrize("N,B", [(512, 1030), (1024, 777), (2048, 520), (4096, 130), (8192, 70)])
 @pytest.mark.parametrize("flags,p", [(0, 1.0), (1, 1.0), (1 | 2 | 4, 2.0), (4, 1.0), (1 | 4 | 8, 2.0), (2, 2.0), (0, 3.0), (1 | 2 | 4, 1.5)])
 def test_full_row_kernel_matches_generic(N, B, flags, p):

@@ -244,6 +244,73 @@ def test_mssloss_torch_composition_matches_reference(tag):
     assert np.abs(ay.grad.numpy() - gwant).max() <= 1e-3 * np.abs(gwant).max()
 
 
+@pytest.mark.parametrize("tag", list(MSS_CASES))
+def test_mssloss_per_clip_torch_composition_matches_reference(tag):
+    """CPU tensors, `dims` = the two spectrogram axes: the reference's per-clip values and the gradient of their weighted sum."""
+    from sot_amd.losses import MSSLoss
+    fx = _fx()
+    ax = torch.as_tensor(fx["mss_audio_x"])
+    ay = torch.as_tensor(fx["mss_audio_y"]).requires_grad_(True)
+    val = MSSLoss(**MSS_CASES[tag])(ax, ay, dims=(1, 2))
+    (val * torch.as_tensor(fx["mss_clip_weights"])).sum().backward()
+    want, gwant = fx[f"mss_{tag}_clip_loss"], fx[f"mss_{tag}_clip_grad_y"]
+    assert np.abs(val.detach().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.abs(ay.grad.numpy() - gwant).max() <= 1e-3 * np.abs(gwant).max()
+
+
+def _paper_mix():
+    from sot_amd.losses import MixOfLosses, MSSLoss, Wasserstein1D
+    return MixOfLosses([MSSLoss(fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type="L1", mag_weight=1, logmag_weight=0),
+                        Wasserstein1D(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True, require_sort=True)], [0.05, 1])
+
+
+def test_paper_loss_block_on_cpu_matches_reference():
+    """spectra.trainer_loss_step = trainer.py:183-245 (fresh x_pos / y_pos, two transforms, MixOfLosses of MSSLoss on the audio and
+    Wasserstein1D on the spectra, sum of the means) on CPU tensors against the reference's own modules run that way
+    (oracle/make_golden_stft.py, `step_*`): the scalar, its two terms and the audio gradient."""
+    from sot_amd import spectra
+    fx = _fx()
+    ax = torch.as_tensor(fx["step_audio_x"])
+    ay = torch.as_tensor(fx["step_audio_y"]).requires_grad_(True)
+    mix = _paper_mix()
+    loss = spectra.trainer_loss_step(mix, ax, ay)
+    loss.backward()
+    assert abs(float(loss) - float(fx["step_loss"])) <= 1e-6 * abs(float(fx["step_loss"]))
+    g, gw = ay.grad.numpy(), fx["step_grad_y"]
+    assert np.abs(g - gw).max() <= 1e-4 * np.abs(gw).max()
+
+
+@pytest.mark.gpu
+def test_paper_loss_block_on_gpu_matches_reference():
+    """The same block on GPU tensors: two HIP STFT launches, the two-launch MSSLoss, the SOT training form.  The MSS term to 1e-5; the SOT
+    term and the total to the audio-in chain's 2e-5 (the cutoff's knife edge)."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    native()
+    fx = _fx()
+    dev = device()
+    ax = torch.as_tensor(fx["step_audio_x"]).to(dev)
+    ay = torch.as_tensor(fx["step_audio_y"]).to(dev).requires_grad_(True)
+    mix = _paper_mix().to(dev)
+    loss = spectra.trainer_loss_step(mix, ax, ay)
+    loss.backward()
+    with torch.no_grad():
+        mss_term = 0.05 * float(mix.losses[0](ax, ay.detach()))
+        pos = spectra.unit_frequencies(2048, 16000.0, dev)
+        sot_term = float(mix.losses[1](spectra.stft_magnitude(ax), spectra.stft_magnitude(ay.detach()), x_pos=pos, y_pos=pos.clone()))
+    print(f"paper loss block on the GPU: total {float(loss):.9g} (reference {float(fx['step_loss']):.9g}); MSS term rel err "
+          f"{abs(mss_term - float(fx['step_mss_term'])) / float(fx['step_mss_term']):.2e}; SOT term rel err "
+          f"{abs(sot_term - float(fx['step_sot_term'])) / float(fx['step_sot_term']):.2e}")
+    assert abs(mss_term - float(fx["step_mss_term"])) <= 1e-5 * float(fx["step_mss_term"])
+    assert abs(sot_term - float(fx["step_sot_term"])) <= 2e-5 * float(fx["step_sot_term"])       # the audio-in chain's bound (README: 2e-5); observed 8e-8
+    assert abs(float(loss) - (mss_term + sot_term)) <= 1e-6 * abs(float(loss))
+    assert abs(float(loss) - float(fx["step_loss"])) <= 2e-5 * abs(float(fx["step_loss"]))       # observed 1.2e-7
+    g, gw = ay.grad.cpu().numpy().astype(np.float64), fx["step_grad_y"].astype(np.float64)
+    cos = float((g * gw).sum() / np.sqrt((g * g).sum() * (gw * gw).sum()))
+    print(f"    audio gradient: cosine {cos:.6f}, max err / peak {np.abs(g - gw).max() / np.abs(gw).max():.2e}")
+    assert cos >= 0.9999 and np.abs(g - gw).max() <= 1e-3 * np.abs(gw).max()      # observed 1.000000 / 9e-5 (the SOT part's conditioning: test_gpu_parity config 5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", list(MSS_CASES))
 def test_mssloss_hip_matches_reference(tag):
@@ -327,6 +394,18 @@ def test_mssloss_per_clip_dims_runs_the_hip_kernels(tag):
     assert got.shape == want.shape == (ax.shape[0],)
     (got * w.to(device())).sum().backward()
     assert float((got.detach().cpu() - want.detach()).abs().max()) <= 1e-5 * float(want.detach().abs().max())
+    # round 5: the REFERENCE'S OWN per-clip values and autograd (oracle/make_golden_stft.py: losses.MSSLoss(...)(x, y, dims=(1, 2)) imported from
+    # /root/reference), same weights: values to 1e-5, gradients with the tolerances of test_mssloss_hip_matches_reference
+    assert np.array_equal(fx["mss_clip_weights"], w.numpy())
+    ref_val, ref_grad = fx[f"mss_{tag}_clip_loss"], fx[f"mss_{tag}_clip_grad_y"]
+    assert np.abs(got.detach().cpu().numpy() - ref_val).max() <= 1e-5 * np.abs(ref_val).max()
+    assert np.abs(want.detach().numpy() - ref_val).max() <= 1e-5 * np.abs(ref_val).max()
+    gh = yd.grad.cpu().numpy()
+    if MSS_CASES[tag]["logmag_weight"] == 0:
+        assert np.abs(gh - ref_grad).max() <= 5e-3 * np.abs(ref_grad).max()
+    else:
+        assert np.linalg.norm(gh - ref_grad) <= 6e-2 * np.linalg.norm(ref_grad)
+        assert float((gh * ref_grad).sum()) >= 0.998 * float(np.linalg.norm(gh) * np.linalg.norm(ref_grad))
     a, b = yd.grad.cpu().numpy(), yc.grad.numpy()
     if MSS_CASES[tag]["logmag_weight"] == 0:
         assert np.abs(a - b).max() <= 5e-3 * np.abs(b).max()
