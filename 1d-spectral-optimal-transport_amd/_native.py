@@ -31,7 +31,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 9                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 10                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -43,7 +43,8 @@ class SotProblem(ctypes.Structure):
                 ("x_row_stride", ctypes.c_int64), ("y_row_stride", ctypes.c_int64),
                 ("xpos_row_stride", ctypes.c_int64), ("ypos_row_stride", ctypes.c_int64),
                 ("p", ctypes.c_float), ("flags", ctypes.c_uint32),
-                ("xperm", _vp), ("yperm", _vp), ("perm_is_identity", _vp)]
+                ("xperm", _vp), ("yperm", _vp), ("perm_is_identity", _vp),
+                ("row_perm_out", _vp), ("row_perm_in", _vp)]
 
 
 EXPORTS = {
@@ -259,10 +260,20 @@ def rows_view(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def make_problem(x, y, xpos, ypos, p, flags, plan=None) -> SotProblem:
+def row_permutations(x, y, xpos, ypos, flags):
+    """A [B, n + m] uint16 buffer for the per-row sort permutations (sot_problem.row_perm_out / row_perm_in), or None when the call does not
+    sort per row (shared positions, no REQUIRE_SORT, rows beyond uint16)."""
+    if not (flags & FLAG_REQUIRE_SORT) or xpos.ndim != 2 or ypos.ndim != 2 or max(x.shape[1], y.shape[1]) > 65535:
+        return None
+    return torch.empty((x.shape[0], x.shape[1] + y.shape[1]), dtype=torch.uint16, device=x.device)
+
+
+def make_problem(x, y, xpos, ypos, p, flags, plan=None, perm_out=None, perm_in=None) -> SotProblem:
     B, n = x.shape
     m = y.shape[1]
     pr = SotProblem()
+    pr.row_perm_out = perm_out.data_ptr() if perm_out is not None else None
+    pr.row_perm_in = perm_in.data_ptr() if perm_in is not None else None
     if plan is not None:
         plan.use_on_current_stream(x.device)
     pr.x, pr.y = x.data_ptr(), y.data_ptr()
@@ -385,13 +396,14 @@ def workspace(pr: SotProblem, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
 
-def forward_rows(x, y, xpos, ypos, p, flags, plan=None, out=None) -> torch.Tensor:
-    """row_loss[B] = W_p^p per row (sot_w1d_forward)."""
+def forward_rows(x, y, xpos, ypos, p, flags, plan=None, out=None, perm_out=None, perm_in=None) -> torch.Tensor:
+    """row_loss[B] = W_p^p per row (sot_w1d_forward).  perm_out / perm_in: row_permutations() buffers (per-row positions: the sort's
+    permutations are left there / taken from there)."""
     lib = load()
     dev = x.device
     B = x.shape[0]
     row_loss = out if out is not None else torch.empty(B, dtype=torch.float32, device=dev)
-    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan, perm_out, perm_in)
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
@@ -507,15 +519,15 @@ def reduce_mean(row_loss, denom=None, hinge=None, want_sum=False, sum_out=None):
     return (mean, total) if want_sum else mean
 
 
-def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=True, plan=None, grad_scale=1.0):
-    """grad_row: [B] tensor, or a 0-d / 1-element tensor that is broadcast to every row (stride 0)."""
+def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=True, plan=None, grad_scale=1.0, perm_in=None):
+    """grad_row: [B] tensor, or a 0-d / 1-element tensor that is broadcast to every row (stride 0).  perm_in: the forward's row_permutations()."""
     lib = load()
     dev = x.device
     B, n = x.shape
     m = y.shape[1]
     gx = torch.empty(B, n, dtype=torch.float32, device=dev) if need_gx else None
     gy = torch.empty(B, m, dtype=torch.float32, device=dev) if need_gy else None
-    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan, perm_in=perm_in)
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
     g = grad_row.contiguous()
@@ -529,7 +541,7 @@ def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=Tr
     return gx, gy
 
 
-def position_grads(x, y, xpos, ypos, p, flags, grad_row, need_x=True, need_y=True, plan=None, grad_scale=1.0):
+def position_grads(x, y, xpos, ypos, p, flags, grad_row, need_x=True, need_y=True, plan=None, grad_scale=1.0, perm_in=None):
     """Gradients w.r.t. the support positions (sot_w1d_position_grad): per-row [B, n] / [B, m] for per-row positions; for a shared
     position row the batch sum [n] / [m] (sot_column_sum), which is what autograd's expand backward returns (losses.py:167-170)."""
     lib = load()
@@ -538,7 +550,7 @@ def position_grads(x, y, xpos, ypos, p, flags, grad_row, need_x=True, need_y=Tru
     m = y.shape[1]
     gxp = torch.empty(B, n, dtype=torch.float32, device=dev) if need_x else None
     gyp = torch.empty(B, m, dtype=torch.float32, device=dev) if need_y else None
-    pr = make_problem(x, y, xpos, ypos, p, flags, plan)
+    pr = make_problem(x, y, xpos, ypos, p, flags, plan, perm_in=perm_in)
     need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
     ws = workspace(pr, dev) if need_ws else None
     g = grad_row.contiguous()

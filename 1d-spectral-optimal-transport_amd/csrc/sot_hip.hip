@@ -121,6 +121,7 @@ struct FwdArgs {
     const float* xpos; const float* ypos;   // sorted positions when !ROWPOS
     const int* xperm; const int* yperm;     // shared-position sort permutations (may be null)
     const int* ident;                       // [2] device flags: permutation is the identity (may be null)
+    uint16_t* perm_out; const uint16_t* perm_in;   // per-row positions: [B, n + m] sort permutations written / reused (may be null)
     int64_t B; int n, m;
     int64_t xs, ys, xps, yps;               // row strides (elements)
     float p; uint32_t flags;
@@ -274,11 +275,41 @@ __device__ __forceinline__ void store_row(float* dst, int len, int t, const floa
 // original column.  Ends with a barrier (U/V may be overwritten by the weights afterwards).
 // MERGE: the stable merge sort of sot_device.hpp (round 4; its two 16-register output arrays cost the register-capped CSR kernel
 // occupancy -- 26.5 -> 34.7 us on config 4's rows, which never need the sort -- so that instantiation keeps the bitonic network)
+// perm_in (round 5): this row's two sort permutations from an earlier call on the same positions ([n + m] uint16): the sorted supports are
+// GATHERED through them, nothing is sorted (the backward and position-gradient kernels of a training step).  perm_out: where this call
+// leaves them.
+// (An instantiation WITHOUT the sort code, launched when perm_in is given, was measured: the position-gradient kernel drops from 233 to 200
+// registers -- still two waves per SIMD -- and both kernels get slower, 143.9 -> 151.5 us and 166.1 -> 173.2 us at 4096 x 2048: not kept.)
 template <int G, int CPT, bool MERGE = true>
 __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* xp, const float* yp, int nmax, int mmax,
-                                               int (&ix)[CPT], int (&iy)[CPT])
+                                               int (&ix)[CPT], int (&iy)[CPT], const uint16_t* perm_in = nullptr, uint16_t* perm_out = nullptr)
 {
     const int n = c.n, m = c.m, t = c.t;
+    if (perm_in != nullptr && c.do_sort) {            // workgroup-uniform
+        float gx[CPT], gy[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t * CPT + k;
+            ix[k] = (e < n) ? (int)perm_in[e] : e;
+            iy[k] = (e < m) ? (int)perm_in[n + e] : e;
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t * CPT + k;
+            gx[k] = (e < n) ? xp[ix[k]] : 0.0f;
+            gy[k] = (e < m) ? yp[iy[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t * CPT + k;
+            if (e < n) c.PX[e] = gx[k];
+            if (e < m) c.PY[e] = gy[k];
+        }
+        row_sync<G / kWave>();
+        if (t == 0) { c.PX[n] = c.PX[n - 1]; c.PY[m] = c.PY[m - 1]; }
+        for (int e = t; e < c.pad; e += G) { c.PX[e - c.pad] = c.PX[0]; c.U[e - c.pad] = 0.0f; }
+        return;
+    }
     int* const IX = reinterpret_cast<int*>(c.U);  // index payloads alias U/V until the weights arrive
     int* const IY = reinterpret_cast<int*>(c.V);
     // barriers are workgroup-wide, so the sort network is sized by the maximum lengths (identical for every
@@ -333,6 +364,14 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
         const int e = t * CPT + k;
         ix[k] = (need_sort && e < n) ? IX[e] : e;
         iy[k] = (need_sort && e < m) ? IY[e] : e;
+    }
+    if (perm_out != nullptr && c.do_sort) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t * CPT + k;
+            if (e < n) perm_out[e] = (uint16_t)ix[k];
+            if (e < m) perm_out[n + e] = (uint16_t)iy[k];
+        }
     }
     row_sync<G / kWave>();
     if (t == 0) { c.PX[n] = c.PX[n - 1]; c.PY[m] = c.PY[m - 1]; }
@@ -609,7 +648,11 @@ __global__ __launch_bounds__((G < 256 ? 256 : G), ((CSR && G == 64) ? SOT_CSR_MI
         }
         const int n = c.n, m = c.m, K = c.K;
         int ix[CPT], iy[CPT];
-        if (ROWPOS) rowpos_prepare<G, CPT, !CSR>(c, xp, yp, a.n, a.m, ix, iy);
+        if (ROWPOS) {
+            const int64_t pw = (int64_t)a.n + a.m;
+            rowpos_prepare<G, CPT, !CSR>(c, xp, yp, a.n, a.m, ix, iy, (!CSR && a.perm_in) ? a.perm_in + rowc * pw : nullptr,
+                                         (!CSR && a.perm_out && valid) ? a.perm_out + rowc * pw : nullptr);
+        }
         // ---- P1: registers -> LDS (original column order), then fetch the next row into the registers --
         store_row<G, CPT, VEC>(U, n, t, rx);
         store_row<G, CPT, VEC>(V, m, t, ry);
@@ -791,7 +834,11 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_backward_kernel(const
         const bool valid = row < a.B;
         const int64_t rowc = valid ? row : a.B - 1;
         int ix[CPT], iy[CPT];
-        if (ROWPOS) rowpos_prepare<G, CPT>(c, a.xpos + rowc * a.xps, a.ypos + rowc * a.yps, a.n, a.m, ix, iy);
+        if (ROWPOS) {
+            const int64_t pw = (int64_t)a.n + a.m;
+            rowpos_prepare<G, CPT>(c, a.xpos + rowc * a.xps, a.ypos + rowc * a.yps, a.n, a.m, ix, iy,
+                                                   a.perm_in ? a.perm_in + rowc * pw : nullptr, (a.perm_out && valid) ? a.perm_out + rowc * pw : nullptr);
+        }
         store_row<G, CPT, VEC>(U, n, t, rx);
         store_row<G, CPT, VEC>(V, m, t, ry);
         if (row0 + row_step < a.B) {
@@ -1452,7 +1499,11 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void sot_position_grad_kernel(
         const bool valid = row < a.B;
         const int64_t rowc = valid ? row : a.B - 1;
         int ix[CPT], iy[CPT];
-        if (ROWPOS) rowpos_prepare<G, CPT>(c, a.xpos + rowc * a.xps, a.ypos + rowc * a.yps, a.n, a.m, ix, iy);
+        if (ROWPOS) {
+            const int64_t pw = (int64_t)a.n + a.m;
+            rowpos_prepare<G, CPT>(c, a.xpos + rowc * a.xps, a.ypos + rowc * a.yps, a.n, a.m, ix, iy,
+                                                   a.perm_in ? a.perm_in + rowc * pw : nullptr, (a.perm_out && valid) ? a.perm_out + rowc * pw : nullptr);
+        }
         store_row<G, CPT, false>(U, n, t, rx);
         store_row<G, CPT, false>(V, m, t, ry);
         if (row0 + row_step < a.B) {
@@ -1784,6 +1835,7 @@ int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t 
     a.B = pr->B; a.n = n; a.m = m;
     a.xs = pr->x_row_stride; a.ys = pr->y_row_stride; a.xps = pr->xpos_row_stride; a.yps = pr->ypos_row_stride;
     a.p = pr->p; a.flags = pr->flags;
+    if (l.rowpos && (pr->flags & SOT_FLAG_REQUIRE_SORT)) { a.perm_out = pr->row_perm_out; a.perm_in = pr->row_perm_in; }
 
     if (need_prep && pr->perm_is_identity != nullptr) {  // caller-provided plan: positions are already sorted
         a.xperm = pr->xperm; a.yperm = pr->yperm; a.ident = pr->perm_is_identity;

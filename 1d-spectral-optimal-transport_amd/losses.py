@@ -94,14 +94,14 @@ def _flags(square_dist, dont_normalize, limit_quantile_range, require_sort, pren
             | (FLAG_PRENORMALIZED if prenormalized else 0))
 
 
-def _position_grads(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, need_y):
+def _position_grads(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, need_y, perm_in=None):
     """d sum_r grad_rows[r] * loss_r / d positions (losses.py:287-313: the positions enter through torch.sort and
     take_along_dim, both differentiable).  No reference call site asks for it; autograd supplies it, and so does
     this package: ONE deterministic HIP kernel (sot_w1d_position_grad: the merge walk accumulates
         d loss / d xs[i] = sum over the merged levels k whose x-rank is i of  delta_k * p |uq_k - vq_k|^(p-1) sign(uq_k - vq_k)
     and minus that for ys, no atomics) plus the fixed-order batch sum for a position row shared by all rows (sot_column_sum)."""
     try:
-        return nat.position_grads(x, y, xpos, ypos, p, flags, grad_rows, need_x, need_y, plan)
+        return nat.position_grads(x, y, xpos, ypos, p, flags, grad_rows, need_x, need_y, plan, perm_in=perm_in)
     except nat.SotError as err:   # rows whose gradient layout + per-thread tails exceed one CU's LDS (n + m beyond ~12 000)
         if err.status != nat.SOT_ERR_UNSUPPORTED_SIZE:
             raise
@@ -139,25 +139,29 @@ def _position_grads_torch(x, y, xpos, ypos, p, flags, plan, grad_rows, need_x, n
 
 
 class _RowLoss(torch.autograd.Function):
-    """rows[B] = W_p^p per spectrum pair; backward = closed-form HIP kernel."""
+    """rows[B] = W_p^p per spectrum pair; backward = closed-form HIP kernel.  Per-row positions (the `torch.sort(u_values, 1)`
+    of losses.py:286-288 on every row) are sorted ONCE per step: the forward leaves each row's permutations in a uint16 buffer and the
+    backward / position-gradient kernels gather through them (sot_problem.row_perm_out / row_perm_in)."""
 
     @staticmethod
     def forward(ctx, x, y, xpos, ypos, p, flags, plan):
-        rows = nat.forward_rows(x, y, xpos, ypos, p, flags, plan)
-        ctx.save_for_backward(x, y, xpos, ypos)
+        perm = nat.row_permutations(x, y, xpos, ypos, flags) if (plan is None and any(ctx.needs_input_grad[:4])) else None
+        rows = nat.forward_rows(x, y, xpos, ypos, p, flags, plan, perm_out=perm)
+        ctx.save_for_backward(x, y, xpos, ypos, *([perm] if perm is not None else []))
         ctx.p, ctx.flags, ctx.plan = p, flags, plan
         return rows
 
     @staticmethod
     def backward(ctx, grad_rows):
-        x, y, xpos, ypos = ctx.saved_tensors
+        x, y, xpos, ypos, *perm = ctx.saved_tensors
+        perm = perm[0] if perm else None
         gx = gy = gxp = gyp = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             gx, gy = nat.backward_rows(x, y, xpos, ypos, ctx.p, ctx.flags, grad_rows.float(),
-                                       need_gx=ctx.needs_input_grad[0], need_gy=ctx.needs_input_grad[1], plan=ctx.plan)
+                                       need_gx=ctx.needs_input_grad[0], need_gy=ctx.needs_input_grad[1], plan=ctx.plan, perm_in=perm)
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             gxp, gyp = _position_grads(x, y, xpos, ypos, ctx.p, ctx.flags, ctx.plan, grad_rows.float(), ctx.needs_input_grad[2],
-                                       ctx.needs_input_grad[3])
+                                       ctx.needs_input_grad[3], perm_in=perm)
         return gx, gy, gxp, gyp, None, None, None
 
 

@@ -351,8 +351,24 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     with torch.no_grad():
         out[f"b{rows_pr}n{N}_segmented_sort"] = entry(timed(lambda i: nat.segmented_sort(prx[i % 2]), n), "sot_segmented_sort_kernel (16 keys per thread, skewed LDS image with sentinels)",
                                                       rows_pr * 16 * N, l3_resident=True, rows=rows_pr, note="4 B in, 4 + 8 B out per key")
-        out[f"b{rows_pr}n{N}_per_row_position_gradients"] = entry(timed(lambda i: nat.position_grads(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg), n),
-                                                                  "sot_position_grad_kernel<256, 8, true> (sort + CDFs + walk + tails)", rows_pr * (24 * N + 4), l3_resident=True, rows=rows_pr)
+        out[f"b{rows_pr}n{N}_per_row_position_gradients_resorting"] = entry(timed(lambda i: nat.position_grads(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg), n),
+                                                                            "sot_position_grad_kernel<256, 8, true> called on its own (sort + CDFs + walk + tails)", rows_pr * (24 * N + 4), l3_resident=True, rows=rows_pr)
+        # round 5: a training step sorts each row's supports ONCE -- the forward leaves the permutations ([B, n + m] uint16), the backward and
+        # position-gradient kernels gather through them (what the module's autograd node does)
+        perms = [nat.row_permutations(two[j][0][:rows_pr], two[j][1][:rows_pr], prx[j], pry[j], cutflags) for j in range(2)]
+        out[f"b{rows_pr}n{N}_per_row_positions_forward_storing_permutations"] = entry(
+            timed(lambda i: nat.forward_rows(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, None, perm_out=perms[i % 2]), n),
+            "sot_forward_kernel<ROWPOS> + 2 (n + m) B / row of permutations", rows_pr * (18 * N + 4), l3_resident=True, rows=rows_pr)
+        out[f"b{rows_pr}n{N}_per_row_backward"] = entry(
+            timed(lambda i: nat.backward_rows(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg, need_gx=False, perm_in=perms[i % 2]), n),
+            "sot_backward_kernel<ROWPOS> gathering through the forward's permutations (no sort), d/dy", rows_pr * (22 * N + 4), l3_resident=True, rows=rows_pr)
+        out[f"b{rows_pr}n{N}_per_row_backward_resorting"] = entry(
+            timed(lambda i: nat.backward_rows(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg, need_gx=False), n),
+            "sot_backward_kernel<ROWPOS> called on its own (sorts again)", rows_pr * (20 * N + 4), l3_resident=True, rows=rows_pr)
+        out[f"b{rows_pr}n{N}_per_row_position_gradients"] = entry(
+            timed(lambda i: nat.position_grads(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg, perm_in=perms[i % 2]), n),
+            "sot_position_grad_kernel<256, 8, true> gathering through the forward's permutations (no sort)", rows_pr * (26 * N + 4), l3_resident=True, rows=rows_pr)
+        del perms
     ref = {}
     with torch.no_grad():
         ref["p1_forward_ms"] = timed(torch_ops("p1", B, pos_x, pos_y), 6)

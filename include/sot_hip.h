@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 9   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 10   /* bumped on every change of a signature below; the binding checks it */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -88,6 +88,13 @@ typedef struct sot_problem {
     const int32_t *xperm;            /* [n] sort permutation of the original xpos             */
     const int32_t *yperm;            /* [m]                                                    */
     const int32_t *perm_is_identity; /* [2] device flags: 1 = positions were already sorted    */
+    /* Round 5, per-row positions with SOT_FLAG_REQUIRE_SORT (the `torch.sort(u_values, 1)` of losses.py:286-288 on every row): the sort runs
+     * ONCE per training step.  row_perm_out (or NULL): a call that sorts stores each row's two sort permutations here, [B, n + m] uint16 (the n
+     * original columns of x's sorted supports, then the m of y's; n, m <= 16384).  row_perm_in (or NULL): permutations an earlier call produced
+     * for the SAME position tensors -- sot_w1d_backward / sot_w1d_position_grad (and the forward itself) then gather the sorted supports
+     * through them instead of sorting again.  Ignored for shared positions. */
+    uint16_t *row_perm_out;
+    const uint16_t *row_perm_in;
 } sot_problem;
 
 int sot_abi_version(void);

@@ -537,6 +537,51 @@ def test_unsorted_positions_shared_and_per_row(shape, mode):
             assert (np.abs(got.cpu().numpy() - ref) <= tol).all()
 
 
+@pytest.mark.parametrize("shape", [(5, 50, 70), (7, 300, 411), (9, 1025, 1025), (6, 2048, 2048), (3, 4096, 3000), (70, 129, 129)])
+@pytest.mark.parametrize("mode", ["p1", "cutoff"])
+def test_per_row_supports_are_sorted_once_per_step(shape, mode):
+    """Round 5: per-row supports (`torch.sort(u_values, 1)` on every row, losses.py:286-288) are sorted by the forward only, which leaves each
+    row's two permutations in a uint16 buffer (sot_problem.row_perm_out); the backward and the position-gradient kernels gather through them
+    (row_perm_in).  The permutations are the STABLE argsort of the positions (distinct keys: torch's own order); gradients with the hand-over
+    are bit-identical to the kernels sorting on their own, to the module's autograd (which uses the hand-over), and a forward that is handed
+    permutations returns the same rows; rows that arrive sorted give the identity."""
+    from oracle.inputs import gen_inputs
+    from oracle.make_golden import MODES
+    nat = native()
+    dev = device()
+    B, n, m = shape
+    x, y = gen_inputs("peaky", B, n, m, 77 + n)
+    g = torch.Generator().manual_seed(n + m)
+    xp, yp = torch.rand(B, n, generator=g), torch.rand(B, m, generator=g)
+    xp[1] = torch.sort(xp[1]).values                     # one row arrives sorted
+    p, flags = ctor_to_flags(MODES[mode])
+    xd, yd, xpd, ypd = x.to(dev), y.to(dev), xp.to(dev), yp.to(dev)
+    perm = nat.row_permutations(xd, yd, xpd, ypd, flags)
+    assert perm is not None and perm.shape == (B, n + m) and perm.dtype == torch.uint16
+    rows = nat.forward_rows(xd, yd, xpd, ypd, p, flags, None, perm_out=perm)
+    assert torch.equal(rows, nat.forward_rows(xd, yd, xpd, ypd, p, flags, None))
+    assert torch.equal(rows, nat.forward_rows(xd, yd, xpd, ypd, p, flags, None, perm_in=perm))
+    pc = perm.cpu().numpy().astype(np.int64)
+    assert np.array_equal(pc[:, :n], np.argsort(xp.numpy(), axis=1, kind="stable"))
+    assert np.array_equal(pc[:, n:], np.argsort(yp.numpy(), axis=1, kind="stable"))
+    assert np.array_equal(pc[1, :n], np.arange(n))
+    up = torch.rand(B, generator=g).to(dev)
+    gx0, gy0 = nat.backward_rows(xd, yd, xpd, ypd, p, flags, up)
+    gx1, gy1 = nat.backward_rows(xd, yd, xpd, ypd, p, flags, up, perm_in=perm)
+    assert torch.equal(gx0, gx1) and torch.equal(gy0, gy1)
+    px0, py0 = nat.position_grads(xd, yd, xpd, ypd, p, flags, up)
+    px1, py1 = nat.position_grads(xd, yd, xpd, ypd, p, flags, up, perm_in=perm)
+    assert torch.equal(px0, px1) and torch.equal(py0, py1)
+    # the module's autograd node
+    mod = module_for(MODES[mode])
+    ts = [t.clone().requires_grad_(True) for t in (xd, yd, xpd, ypd)]
+    out = run_rows(mod, ts[0], ts[1], dict(x_pos=ts[2], y_pos=ts[3]))
+    (out * up).sum().backward()
+    assert torch.equal(out.detach(), rows)
+    for got, want in zip((t.grad for t in ts), (gx0, gy0, px0, py0)):
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("shape", [(3, 4000, 4000), (2, 8192, 8192), (2, 9000, 700), (300, 33, 2049)])
 def test_large_and_ragged_sizes_against_oracle(shape):
     from oracle import sot_oracle as so
