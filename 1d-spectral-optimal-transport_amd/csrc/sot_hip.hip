@@ -362,8 +362,10 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int e = t * CPT + k;
-        ix[k] = (need_sort && e < n) ? IX[e] : e;
-        iy[k] = (need_sort && e < m) ? IY[e] : e;
+        // (clamped: a NaN position orders above the +inf pads, so a pad's index INT_MAX can surface among the first n outputs -- ADVICE r4;
+        // NaN positions have no defined order here or in the reference's loss, but they must not become wild gather / store indices)
+        ix[k] = (need_sort && e < n) ? min(IX[e], n - 1) : e;
+        iy[k] = (need_sort && e < m) ? min(IY[e], m - 1) : e;
     }
     if (perm_out != nullptr && c.do_sort) {
 #pragma unroll
@@ -1797,7 +1799,7 @@ __global__ __launch_bounds__(1024) void sot_segmented_sort_kernel(const float* _
         merge_sort16_kv2<1>(job, none, t, T, [] { __syncthreads(); });   // the launcher sizes the block so that npad <= 16 T
         for (int i = t; i < n; i += T) {
             if (out_keys) out_keys[row * (int64_t)n + i] = key[i];
-            if (out_idx) out_idx[row * (int64_t)n + i] = (int64_t)idx[i];
+            if (out_idx) out_idx[row * (int64_t)n + i] = (int64_t)min(idx[i], n - 1);   // NaN keys: a pad's index never leaves the kernel
         }
         __syncthreads();
     }

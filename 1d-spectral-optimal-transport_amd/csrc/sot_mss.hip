@@ -263,10 +263,13 @@ struct MssArgs {
     int task_base[kMaxScales + 1];                    // first task of each scale; task = task_base[s] + clip * waves[s] + w
     float coef[kMaxScales];                           // d loss / d (sum of the scale's distance terms): 1 / count (all clips) or 1 / (frames bins)
     double inv_count[kMaxScales];                     // the same in double, for the loss value
-    int64_t grad_base[kMaxScales];                    // offset (floats) of the scale's spans in partial_grad
+    int slot_base[kMaxScales + 1];                    // partial_grad: first 256-point slot of the scale inside a (clip, range) block; [n_scales] = slots per block
+    int ranges;                                       // 256-point ranges per clip: ceil(ceil(samples / 2) / 256)
+    int slot_info[32];                                // scale | piece << 8: which scale and which 256-point piece of its waves' spans a slot holds (dwords: scalar loads)
     float mag_weight, logmag_weight, eps; int l2, per_clip, want_grad;
     double* partial_loss;                             // [task]
-    float* partial_grad;                              // [scale][clip][wave][span]: span = 512 + 3 hop samples (256 + 3 m / 4 packed points)
+    float* partial_grad;                              // [clip][range r][slot][256 points]: the wave w of a scale writes piece j of its span (256 + 3 m / 4
+                                                      // packed points) into slot slot_base[s] + j of range r = w + j: all a range needs is contiguous
     float* loss; float* grad;                         // outputs: [1] or [batch]; [batch, samples] (contiguous)
 };
 
@@ -330,21 +333,25 @@ __device__ __forceinline__ void fetch_frames(const float* __restrict__ clip, int
     }
 }
 
-// sample * tap (the taps come from L1 / L2: every wave of the scale reads the same n_fft floats); returns whether the wave's frames pass
-// the range test (wave-uniform)
+// sample * tap for BOTH signals' frames with one fetch of the taps (every wave of the scale reads the same n_fft floats: L1 / L2 hits);
+// plain_t / plain_v: whether each signal's frames pass the range test (wave-uniform)
 template <int M>
-__device__ __forceinline__ bool window_frames(v2f (&r)[16], const float2* __restrict__ win, int lane)
+__device__ __forceinline__ void window_frames(v2f (&rt)[16], v2f (&rv)[16], const float2* __restrict__ win, int lane, bool& plain_t, bool& plain_v)
 {
     using G = Geo<M>;
     const float2* const wl = win + (lane & (G::L - 1));
-    float amax = 0.0f;
+    float at = 0.0f, av = 0.0f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float2 w = wl[G::L * q];
-        r[q] = r[q] * (v2f){w.x, w.y};
-        amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
+        const v2f wv = (v2f){w.x, w.y};
+        rt[q] = rt[q] * wv;
+        rv[q] = rv[q] * wv;
+        at = fmaxf(at, fmaxf(fabsf(rt[q].x), fabsf(rt[q].y)));
+        av = fmaxf(av, fmaxf(fabsf(rv[q].x), fabsf(rv[q].y)));
     }
-    return __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;
+    plain_t = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(at))) != 0;
+    plain_v = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(av))) != 0;
 }
 
 // last-phase registers -> the wave's buffer in natural frequency order, frame-major with L pad slots per frame (address j (m + L) + k);
@@ -399,6 +406,7 @@ __device__ __forceinline__ void pair_pass(const MssArgs& a, float coef, v2f* zl,
     v2f* const pm = zl + j * (G::m + G::L) - l;         // + L (16 - q)
     const float scale = 1.0f / sqrtf((float)G::n);      // normalized=True: frame_length^-0.5
     const float cw = coef * a.mag_weight;
+    v2f gk_out[(SECOND && GRAD) ? 9 : 1], gm_out[(SECOND && GRAD) ? 9 : 1];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         if (q == 8 && l != 0) break;
@@ -439,11 +447,21 @@ __device__ __forceinline__ void pair_pass(const MssArgs& a, float coef, v2f* zl,
             const v2f hc = (q < 8) ? cm * xc : cconj(hk);  // 2 conj H_(m-k)   (k = m / 2: H_(m-k) is H_k itself)
             const v2f sk = 0.5f * (hk + hc), dd = hk - hc;
             const v2f P = cmul_conj(dd, wp);               // conj(w') (2 d) = i conj(W) d
+            gk_out[q] = sk + P;
+            gm_out[q] = conj_sub(sk, P);
+        }
+    }
+    if (SECOND && GRAD) {
+        // stored after every pair has been read: the loads of all nine pairs can be in flight together (a store between two pairs' loads
+        // would order them: the compiler cannot know that a pair's slots are private to its lane)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (q == 8 && l != 0) break;
             if (q < 8) {
-                pk[G::L * q] = sk + P;
-                if (k != 0) pm[G::L * (16 - q)] = conj_sub(sk, P);
+                pk[G::L * q] = gk_out[q];
+                if (q != 0 || l != 0) pm[G::L * (16 - q)] = gm_out[q];
             } else {
-                pk[G::m / 2] = sk + P;
+                pk[G::m / 2] = gk_out[q];
             }
         }
     }
@@ -470,28 +488,29 @@ __device__ __forceinline__ void wave_task(const MssArgs& a, int s, int task, con
     float tm[18];
     float accf = 0.0f;
     double acc = 0.0;
-    v2f r[16];
-    // ---- target: |T| of the lane's bins
+    v2f r[16], rv[16];
+    // ---- both signals' frames and the taps in one round of loads; the estimate's windowed frames wait in registers
     fetch_frames<M>(tclip, a.samples, frames, frame0, win, lane, r);
-    bool plain = window_frames<M>(r, win, lane);
+    fetch_frames<M>(vclip, a.samples, frames, frame0, win, lane, rv);
+    bool plain, plain_v;
+    window_frames<M>(r, rv, win, lane, plain, plain_v);
     MSS_STAMP(2);
+    // ---- target: |T| of the lane's bins
     forward_transform<M>(r, zl, tw, lane);
     MSS_STAMP(3);
     write_natural<M>(r, zl, lane);
-    fetch_frames<M>(vclip, a.samples, frames, frame0, win, lane, r);     // the estimate's frames travel during the target's pair pass
     wave_sync();
     if (plain) pair_pass<M, true, false, false, KIND>(a, 0.0f, zl, wn, lane, tm, accf, acc);
     else pair_pass<M, false, false, false, KIND>(a, 0.0f, zl, wn, lane, tm, accf, acc);
     wave_sync();
     MSS_STAMP(4);
     // ---- estimate: |V|, distance, gradient packing
-    plain = window_frames<M>(r, win, lane);
-    forward_transform<M>(r, zl, tw, lane);
+    forward_transform<M>(rv, zl, tw, lane);
     MSS_STAMP(5);
-    write_natural<M>(r, zl, lane);
+    write_natural<M>(rv, zl, lane);
     wave_sync();
     const float coef = a.coef[s];
-    if (plain) pair_pass<M, true, true, GRAD, KIND>(a, coef, zl, wn, lane, tm, accf, acc);
+    if (plain_v) pair_pass<M, true, true, GRAD, KIND>(a, coef, zl, wn, lane, tm, accf, acc);
     else pair_pass<M, false, true, GRAD, KIND>(a, coef, zl, wn, lane, tm, accf, acc);
     wave_sync();
     MSS_STAMP(6);
@@ -514,12 +533,15 @@ __device__ __forceinline__ void wave_task(const MssArgs& a, int s, int task, con
         MSS_STAMP(7);
         const float scale = 1.0f / sqrtf((float)G::n);
         constexpr int hp = G::m / 4, span = 256 + 3 * hp;          // packed points: the F frames start hp apart (F hp = 256) and are m long
-        float2* const dst = reinterpret_cast<float2*>(a.partial_grad + a.grad_base[s]) + (int64_t)local * span;
+        // piece j = points [256 j, 256 j + 256) of the span belongs to range w + j of the clip; ranges past the clip's end are dropped
+        const int slots = a.slot_base[a.n_scales], ranges = a.ranges;
+        float2* const blk = reinterpret_cast<float2*>(a.partial_grad) + (((int64_t)b * ranges + w) * slots + a.slot_base[s]) * 256;
+        const int64_t rstride = (int64_t)slots * 256 + 256;        // from (range r, piece j) to (range r + 1, piece j + 1)
         if constexpr (M == 10) {                                   // one frame per wave: its span is the frame, straight from the registers
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const v2f o = (wt[q] * r[q]) * scale;
-                dst[64 * q + lane] = make_float2(o.x, o.y);
+                if (w + (q >> 2) < ranges) blk[(q >> 2) * rstride + 64 * (q & 3) + lane] = make_float2(o.x, o.y);
             }
         } else {
             v2f* const o = zl + j * (G::m + G::L) + kl;              // packed point i = L q + l of frame j at j (m + L) + i
@@ -531,13 +553,13 @@ __device__ __forceinline__ void wave_task(const MssArgs& a, int s, int task, con
 #pragma unroll
             for (int t = 0; t < (span + 63) / 64; ++t) {
                 const int pp = 64 * t + lane;
-                if (pp < span) {
+                if (pp < span && w + (t >> 2) < ranges) {
                     const int f_hi = min(pp / hp, nfr - 1);
                     int f_lo = (pp - (G::m - 1) + hp - 1) / hp;
                     if (pp - (G::m - 1) <= 0) f_lo = 0;
                     v2f sum = (v2f){0.0f, 0.0f};
                     for (int f = f_lo; f <= f_hi; ++f) sum += zl[f * (G::m + G::L) + (pp - f * hp)];
-                    dst[pp] = make_float2(sum.x, sum.y);
+                    blk[(t >> 2) * rstride + (pp & 255)] = make_float2(sum.x, sum.y);
                 }
             }
             wave_sync();      // the overlap-add has read the buffer before the next task writes it
@@ -569,9 +591,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSS_WA
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v2f* const zl = bufs + wave * kBuf;
     const int total = a.task_base[a.n_scales];
-    const int first = (blockIdx.x * kWaves + wave) * tasks_per_wave, last = min(total, first + tasks_per_wave);
+    // Tasks are ordered by scale; wave g takes tasks g, g + (waves of the grid), ...: at any moment the waves resident on a CU work on the
+    // same one or two scales.  (The instruction cache is shared by the waves of a CU pair and one scale's path is ~30 KB of straight-line
+    // code: with a contiguous range per wave every CU ran all six scales at once and refetched code from L2 all the time.)
+    const int stride = (int)gridDim.x * kWaves;
     int s = 0;
-    for (int task = first; task < last; ++task) {
+    (void)tasks_per_wave;
+    for (int task = (int)blockIdx.x * kWaves + wave; task < total; task += stride) {
         while (s + 1 < a.n_scales && task >= a.task_base[s + 1]) ++s;
 #ifdef MSS_ONLY_M      /* diagnostic builds: one transform size (compile time, register pressure of one body) */
         wave_task<MSS_ONLY_M, GRAD, KIND>(a, s, task, tw, wn, zl);
@@ -605,48 +631,112 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
             a.loss[o] = total;
         }
     } else if (blockIdx.x == gridDim.x - 1) {
-        // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves
-        // reduce by shuffles, thread 0 adds the four wave sums per scale in order
+        // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves reduce by
+        // shuffles, thread 0 adds the four wave sums per scale in order.  The loads of ALL scales of a pass (4 per thread and scale) are issued
+        // before the first is used (a loop that waits per load: 48 serialised round trips for 256 clips).
+        double acc[kMaxScales];
+#pragma unroll
+        for (int s = 0; s < kMaxScales; ++s) acc[s] = 0.0;
+        int longest = 0;
+        for (int s = 0; s < a.n_scales; ++s) longest = max(longest, a.task_base[s + 1] - a.task_base[s]);
+        for (int i0 = 0; i0 < longest; i0 += 4 * kFinishThreads) {
+            double part[kMaxScales][4];
+#pragma unroll
+            for (int s = 0; s < kMaxScales; ++s) {
+                const bool on = s < a.n_scales;               // uniform
+                const int count = on ? a.task_base[s + 1] - a.task_base[s] : 1;
+                const double* const src = a.partial_loss + (on ? a.task_base[s] : 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * kFinishThreads + (int)threadIdx.x;
+                    part[s][u] = 0.0;
+                    if (on && i0 + u * kFinishThreads < count) part[s][u] = src[min(i, count - 1)];     // uniform branch
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kMaxScales; ++s) {
+                const int count = (s < a.n_scales) ? a.task_base[s + 1] - a.task_base[s] : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[s] += (i0 + u * kFinishThreads + (int)threadIdx.x < count) ? part[s][u] : 0.0;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < kMaxScales; ++s) {
             if (s < a.n_scales) {
-                double acc = 0.0;
-                const int count = a.task_base[s + 1] - a.task_base[s];
-                for (int i = threadIdx.x; i < count; i += kFinishThreads) acc += a.partial_loss[a.task_base[s] + i];
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-                if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * kMaxScales + s] = acc;
+                for (int off = 32; off >= 1; off >>= 1) acc[s] += __shfl_xor(acc[s], off);
+                if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * kMaxScales + s] = acc[s];
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            float total = 0.0f;
-            for (int s = 0; s < a.n_scales; ++s) {
-                double tot = 0.0;
-                for (int w = 0; w < kFinishThreads / 64; ++w) tot += red[w * kMaxScales + s];
-                total += (float)(tot * a.inv_count[s]);     // `loss += mean` in float32, scale by scale (losses.py:411-424)
+        if (threadIdx.x < 64) {                                  // lane s of the first wave finishes scale s; then `loss += mean` in float32, scale by scale
+            const int sl = (int)threadIdx.x;
+            double tot = 0.0;
+            if (sl < a.n_scales) {
+#pragma unroll
+                for (int w = 0; w < kFinishThreads / 64; ++w) tot += red[w * kMaxScales + sl];
+                tot *= a.inv_count[min(sl, kMaxScales - 1)];
             }
-            a.loss[0] = total;
+            const float mean_s = (float)tot;
+            float total = 0.0f;
+#pragma unroll
+            for (int sc = 0; sc < kMaxScales; ++sc) {
+                const float ms = __shfl(mean_s, sc);
+                if (sc < a.n_scales) total += ms;                // losses.py:411-424
+            }
+            if (sl == 0) a.loss[0] = total;
         }
     }
     if (!a.want_grad) return;
-    const int64_t half = (a.samples + 1) / 2;                   // packed points per clip
-    const int64_t total = a.batch * half;
-    for (int64_t idx = (int64_t)blockIdx.x * kFinishThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kFinishThreads) {
-        const int64_t b = idx / half;
-        const int p = (int)(idx - b * half);                    // packed point of the clip: samples 2 p, 2 p + 1
-        float gx = 0.0f, gy = 0.0f;
-        for (int s = 0; s < a.n_scales; ++s) {
-            const int span = 256 + 3 * ((1 << a.logm[s]) / 4), waves = a.waves[s];
-            const float2* const base = reinterpret_cast<const float2*>(a.partial_grad + a.grad_base[s]) + (b * waves) * (int64_t)span;
-            const int w_hi = min(p >> 8, waves - 1);
-            int w_lo = (p - span + 256) >> 8;                   // first wave whose span [256 w, 256 w + span) holds p
-            if (p - span + 1 <= 0) w_lo = 0;
-            for (int w = w_lo; w <= w_hi; ++w) { const float2 v = base[(int64_t)w * span + (p - 256 * w)]; gx += v.x; gy += v.y; }
+    // One workgroup per (clip, 256 packed points = one wave range): the spans that cover its points are the same for all its threads -- waves
+    // w_hi - 3 ... w_hi of every scale (span = 256 + 3 m / 4 <= 1024 points) -- so the address arithmetic is scalar; scales and waves in order.
+    const int half = (int)((a.samples + 1) / 2);                // packed points per clip
+    const int ranges = (half + 255) >> 8;
+    // COMPACT code on purpose: a rolled loop over the block's slots, sixteen loads in flight per pass (the six MSSLoss scales: 15 slots, one pass; a load of this
+    // freshly written scratch takes ~2 us, so passes are what the gather costs).  (The fully unrolled form of this gather
+    // -- 32 predicated loads, 19 KB of straight-line code -- took 10 us for 64 clips and 24 us for 256 however its loads were arranged:
+    // every workgroup executes the code once, and the first workgroup of each CU fetches all of it from L2.)
+    if (threadIdx.x >= 128) return;                             // two packed points per thread: 16-byte loads
+    MSS_STAMP(11);
+    const int slots = a.slot_base[a.n_scales];
+    for (int64_t blk = blockIdx.x; blk < a.batch * ranges; blk += gridDim.x) {
+        const int b = (int)(blk / ranges), w_hi = (int)(blk - (int64_t)b * ranges);
+        const int t2 = 2 * (int)threadIdx.x;
+        const int p = 256 * w_hi + t2;
+        const float4* const blk4 = reinterpret_cast<const float4*>(a.partial_grad) + (((int64_t)b * ranges + w_hi) * slots) * 128 + threadIdx.x;
+        float g0x = 0.0f, g0y = 0.0f, g1x = 0.0f, g1y = 0.0f;
+#pragma unroll 1
+        for (int s0 = 0; s0 < slots; s0 += 16) {                 // slots in order = scales in order, pieces ascending (= waves descending)
+            float4 got[16];
+            int q[16], span[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int slot = min(s0 + u, slots - 1);
+                const int info = a.slot_info[slot], sc = info & 255, piece = info >> 8, w = w_hi - piece;
+                const bool covers = s0 + u < slots && w >= 0 && w < a.waves[sc];       // uniform: a scalar branch, the load stays in flight past it
+                span[u] = covers ? 256 + 3 * ((1 << a.logm[sc]) / 4) : 0;
+                q[u] = 256 * piece + t2;
+                got[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (covers) got[u] = blk4[slot * 128];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {                      // the per-thread end of a span masks the VALUE (a load inside a divergent branch is waited for)
+                const bool k0 = q[u] < span[u], k1 = q[u] + 1 < span[u];
+                g0x += k0 ? got[u].x : 0.0f; g0y += k0 ? got[u].y : 0.0f;
+                g1x += k1 ? got[u].z : 0.0f; g1y += k1 ? got[u].w : 0.0f;
+            }
         }
-        float* const dst = a.grad + b * a.samples + 2 * (int64_t)p;
-        dst[0] = gx;
-        if (2 * (int64_t)p + 1 < a.samples) dst[1] = gy;
+        MSS_STAMP(12);
+        float* const dst = a.grad + (int64_t)b * a.samples + 2 * (int64_t)p;
+        const int64_t left = a.samples - 2 * (int64_t)p;        // samples of the clip from 2 p on
+        if (left >= 4 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(g0x, g0y, g1x, g1y);
+        else {
+            if (left >= 1) dst[0] = g0x;
+            if (left >= 2) dst[1] = g0y;
+            if (left >= 3) dst[2] = g1x;
+            if (left >= 4) dst[3] = g1y;
+        }
+        MSS_STAMP(13);
     }
 }
 
@@ -676,10 +766,14 @@ static int fill(const float* target, int64_t stride_t, const float* value, int64
         const double count = (double)frames * (double)(m + 1) * (per_clip ? 1.0 : (double)batch);
         a->inv_count[s] = 1.0 / count;
         a->coef[s] = (float)(1.0 / count);
-        a->grad_base[s] = gfloats;
-        gfloats += 2 * batch * a->waves[s] * (int64_t)(256 + 3 * (m / 4));
+        a->slot_base[s] = (int)gfloats;                          // (slots so far)
+        for (int j = 0; j < (256 + 3 * (m / 4) + 255) / 256; ++j) a->slot_info[gfloats + j] = s | (j << 8);
+        gfloats += (256 + 3 * (m / 4) + 255) / 256;             // 256-point pieces of a span: 4, 3, 2, 2, 2, 2 for n_fft 2048 ... 64
         ldoubles += batch * a->waves[s];
     }
+    a->slot_base[n_scales] = (int)gfloats;
+    a->ranges = (int)(((samples + 1) / 2 + 255) / 256);
+    gfloats = 2 * 256 * gfloats * a->ranges * batch;            // floats: [clip][range][slot][256 points][2]
     a->task_base[n_scales] = (int)blocks;
     if (blocks > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
     *workspace_bytes = sizeof(double) * (size_t)ldoubles + sizeof(float) * (size_t)gfloats;
@@ -739,10 +833,12 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
     const int tasks = a.task_base[n_scales], slots = 2 * cus * kWaves;              // one wave per task slot
     const int per = (tasks + slots - 1) / slots, waves_needed = (tasks + per - 1) / per;
+#ifndef MSS_SKIP_FUSED     /* diagnostic (timing only, results are garbage): the finish kernel on its own */
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves_needed + kWaves - 1) / kWaves)), dim3(kThreads), kLdsBytes, st, a, per);
+#endif
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
-    const int64_t work = a.want_grad ? (batch * ((samples + 1) / 2) + kFinishThreads - 1) / kFinishThreads : 1;
-    hipLaunchKernelGGL(mss_finish_kernel, dim3((unsigned)(work < 4096 ? (work < 1 ? 1 : work) : 4096)), dim3(kFinishThreads), 0, st, a);
+    const int64_t work = a.want_grad ? batch * ((((samples + 1) / 2) + 255) / 256) : 1;      // one workgroup per (clip, 256 packed points)
+    hipLaunchKernelGGL(mss_finish_kernel, dim3((unsigned)(work < 16384 ? (work < 1 ? 1 : work) : 16384)), dim3(kFinishThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 

@@ -236,7 +236,9 @@ int sot_column_sum(const float *rows, int64_t B, int32_t n, int64_t row_stride, 
  * Segmented (per-row) stable ascending sort with index payload: what torch.sort(keys, 1)
  * returns at losses.py:287-288 (indices are int64 like torch's; bit-identical to torch on
  * distinct keys; ties keep the lower index first).  row_stride in elements; outputs are
- * dense [B, n].  Either output may be NULL.
+ * dense [B, n].  Either output may be NULL.  NaN keys: no defined order (torch puts them last; here a positive NaN orders above the
+ * internal +inf pads, a negative one first), but every returned index is a valid column (< n) -- as are the gather / store indices of
+ * the per-row-position kernels, which use the same sort.
  */
 int sot_segmented_sort(const float *keys, int64_t B, int32_t n, int64_t row_stride,
                        float *sorted_keys, int64_t *indices, void *stream);

@@ -54,6 +54,9 @@ PY
     tail -n 15 "$O/pytest.log" | cut -c1-300 ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 3 ;;
+  kstats)               # <tag> <script.py> [args]: rocprofv3 kernel stats of one python program
+    O="gpurun_out/${1:?tag}"; shift
+    kstats "$O" "$@" ;;
   run)                  # <tag> <script.py> [args]: one python program, output kept
     O="gpurun_out/${1:?tag}"; shift
     mkdir -p "$O"

@@ -30,4 +30,5 @@ print("wg    " + " ".join(f"{n[:13]:>13s}" for n in names) + "         total")
 for wg in list(range(0, 6)) + [20, 40, 63]:
     st = [buf[wg * 16 + i] for i in range(9)]
     d = [st[i + 1] - st[i] for i in range(8)]
-    print(f"{wg:3d}   " + " ".join(f"{v:13d}" for v in d) + f"   {st[8] - st[0]:10d}")
+    fin = [buf[wg * 16 + i] for i in (11, 12, 13)]
+    print(f"{wg:3d}   " + " ".join(f"{v:13d}" for v in d) + f"   {st[8] - st[0]:10d}   finish kernel: start {fin[0] - st[0]:8d} after kernel 1 start, gather {fin[1] - fin[0]:6d}, store {fin[2] - fin[1]:6d}")
