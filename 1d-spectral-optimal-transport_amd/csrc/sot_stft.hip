@@ -24,6 +24,7 @@
 #include <math.h>
 
 #include "../../include/sot_hip.h"
+#include "sot_wave_fft.hpp"
 
 namespace sot_stft {
 
@@ -1149,6 +1150,207 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clip_ker
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: n_fft 2048 on the one-wavefront FFT of csrc/sot_wave_fft.hpp (written for the two-launch MSSLoss: 16 points per lane, radix-4 stages
+// in registers, padded additive exchange maps, fused complex products, a transposed network for the inverse -- a frame's forward transform is
+// ~415 instructions and ~4 000 clocks on one wave against the 28 000-clock chain of the round-4 wave kernels).
+//  * stft_mag_backward_spec_clipw_kernel: the backward from the stored spectrum with the overlap-add inside (clips of at most 16 frames),
+//    same structure as stft_mag_backward_spec_clip_kernel: wave f of a 1024-thread workgroup turns frame f's spectrum and upstream gradient
+//    into the Hermitian packing G (natural order in its LDS buffer), runs the inverse network and leaves the windowed frame gradient in its
+//    buffer; after one barrier the workgroup adds the frames that cover each sample in ascending frame order.
+//  * stft_mag_forward_wavew_kernel: forward (single or pair form, optional spectrum) with one wavefront per frame in 512-thread workgroups,
+//    for the batches BELOW the round-4 wave kernel's threshold (512 ... 3071 frames: the paper's 64 clips), where the slot kernel ran.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kClipwLdsBytes = ((size_t)16 * sot_wfft::kBuf + sot_wfft::kTw + sot_wfft::kWnMax) * sizeof(float2);
+constexpr int kFwdwThreads = 512, kFwdwWaves = 8;
+constexpr size_t kFwdwLdsBytes = ((size_t)kFwdwWaves * sot_wfft::kBuf + sot_wfft::kTw + sot_wfft::kWnMax) * sizeof(float2);
+
+// Hermitian packing G of Zin_k = g_k X_k / |X_k| for the lane's bin pairs (k, m - k), k = 64 q + lane (q < 8) and k = m / 2 (lane 0), written to the
+// wave's buffer in natural order (csrc/sot_mss.hip: pair_pass, here from the stored spectrum).  PLAIN: 1 / |X| = rsq(re^2 + im^2); the pass also
+// returns the largest and the smallest non-zero component magnitude, from which the caller decides whether PLAIN was legitimate.
+template <bool PLAIN>
+__device__ __forceinline__ void clipw_pack_gradient(const float2* __restrict__ sp, const float* __restrict__ g, float up, sot_wfft::v2f* zl,
+                                                    const sot_wfft::v2f* wn, int lane, float& peak, float& least)
+{
+    using namespace sot_wfft;
+    constexpr int m = 1024;
+    peak = 0.0f; least = INFINITY;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        if (q == 8 && lane != 0) break;
+        const int k = (q < 8) ? 64 * q + lane : m / 2;
+        const float2 pk = sp[k], pm = sp[m - k];
+        const sot_wfft::v2f xk = (sot_wfft::v2f){pk.x, pk.y}, xm = (sot_wfft::v2f){pm.x, pm.y};
+        const float gk = g[k] * up, gm = g[m - k] * up;
+        float ck, cm;
+        if (PLAIN) {
+            const float ak = fmaxf(fabsf(pk.x), fabsf(pk.y)), am = fmaxf(fabsf(pm.x), fabsf(pm.y));
+            peak = fmaxf(peak, fmaxf(ak, am));
+            least = fminf(least, fminf(ak > 0.0f ? ak : INFINITY, am > 0.0f ? am : INFINITY));
+            const float sk2 = fmaf(xk.x, xk.x, xk.y * xk.y), sm2 = fmaf(xm.x, xm.x, xm.y * xm.y);
+            ck = sk2 > 0.0f ? gk * __builtin_amdgcn_rsqf(sk2) : 0.0f;      // torch: sgn(0) = 0
+            cm = sm2 > 0.0f ? gm * __builtin_amdgcn_rsqf(sm2) : 0.0f;
+        } else {
+            const float mk = hypotf(xk.x, xk.y), mm = hypotf(xm.x, xm.y);
+            ck = mk > 0.0f ? gk / mk : 0.0f;
+            cm = mm > 0.0f ? gm / mm : 0.0f;
+        }
+        if (q == 0 && k == 0) { ck *= 2.0f; cm *= 2.0f; }                  // H_0 and H_m are the (real) Zin themselves, not halves
+        const sot_wfft::v2f hk = ck * xk;                                   // 2 H_k
+        const sot_wfft::v2f hc = (q < 8) ? cm * cconj(xm) : cconj(hk);     // 2 conj H_(m-k)
+        const sot_wfft::v2f sk = 0.5f * (hk + hc), dd = hk - hc;
+        const sot_wfft::v2f P = cmul_conj(dd, wn[k]);                      // i conj(W) (H_k - conj H_(m-k))
+        zl[k] = sk + P;
+        if (q < 8 && k != 0) zl[m - k] = conj_sub(sk, P);
+    }
+}
+
+__global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clipw_kernel(const StftArgs a)
+{
+    using namespace sot_wfft;
+    constexpr int n = 2048, nb = 1025, m = 1024;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    sot_wfft::v2f* const tw = reinterpret_cast<sot_wfft::v2f*>(smem_f);
+    sot_wfft::v2f* const wn = tw + kTw;
+    sot_wfft::v2f* const bufs = wn + kWnMax;                   // 16 frame buffers of kBuf points
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    sot_wfft::v2f* const zl = bufs + wave * kBuf;
+    build_tables<kWave2Threads>(kWn, tw, wn);
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)n);
+    const float up = a.grad_scale ? *a.grad_scale : 1.0f;
+    const int frames = (int)a.frames, hp = a.hop >> 1;        // hop in packed points (hop is even: host)
+    const int samples = (int)a.samples;
+    const float2* const win2 = reinterpret_cast<const float2*>(a.window);
+    for (int64_t b = blockIdx.x; b < a.batch; b += gridDim.x) {
+        if (wave < frames) {
+            int lane = threadIdx.x & 63;
+            asm volatile("" : "+v"(lane));   // lane-derived LDS addresses are recomputed per clip instead of living in registers across clips
+            const float2* const sp = a.spec_in + (b * a.frames + wave) * nb;
+            const float* const g = a.grad_mag + (b * a.frames + wave) * nb;
+            float peak, least;
+            clipw_pack_gradient<true>(sp, g, up, zl, wn, lane, peak, least);
+            // re^2 + im^2 of every non-zero bin must be a normal number that cannot overflow (NaNs fail the test): else the careful form
+            const float wpeak = wave_max_f32(peak), wleast = -wave_max_f32(-least);
+            if (__builtin_amdgcn_readfirstlane((int)(wpeak < 1e15f && wleast > 1e-18f)) == 0) {
+                wave_sync();
+                clipw_pack_gradient<false>(sp, g, up, zl, wn, lane, peak, least);
+            }
+            wave_sync();
+            sot_wfft::v2f r[16], wt[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r[q] = zl[lane + 64 * brev4(q)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const float2 wv = win2[64 * q + lane]; wt[q] = (sot_wfft::v2f){wv.x, wv.y}; }   // arrive during the transform
+            wave_sync();
+            inverse_transform<10>(r, zl, tw, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) zl[64 * q + lane] = (wt[q] * r[q]) * scale;      // the windowed frame gradient, packed point 64 q + lane
+        }
+        __syncthreads();
+        float* const dst = a.grad_audio + b * a.samples;
+        for (int p = threadIdx.x; 2 * p < samples; p += kWave2Threads) {   // packed point p of the clip = samples 2 p, 2 p + 1
+            const int f_hi = min(p / hp, frames - 1);
+            int f_lo = (p - (m - 1) + hp - 1) / hp;
+            if (p - (m - 1) <= 0) f_lo = 0;
+            sot_wfft::v2f sum = (sot_wfft::v2f){0.0f, 0.0f};
+            for (int f = f_lo; f <= f_hi; ++f) sum += bufs[f * kBuf + (p - f * hp)];
+            if (2 * p + 1 < samples) {
+                float2* d2 = reinterpret_cast<float2*>(dst + 2 * p);
+                if ((reinterpret_cast<uintptr_t>(d2) & 7u) == 0) {
+                    float2 o = make_float2(sum.x, sum.y);
+                    if (a.accumulate) { const float2 old = *d2; o.x += old.x; o.y += old.y; }
+                    *d2 = o;
+                } else {
+                    dst[2 * p] = a.accumulate ? dst[2 * p] + sum.x : sum.x;
+                    dst[2 * p + 1] = a.accumulate ? dst[2 * p + 1] + sum.y : sum.y;
+                }
+            } else {
+                dst[2 * p] = a.accumulate ? dst[2 * p] + sum.x : sum.x;
+            }
+        }
+        __syncthreads();   // the frame buffers are read before the next clip overwrites them
+    }
+}
+
+// the frame's bins from the packed transform in the wave's buffer (natural order, Z_0 again at slot m): |.| / sqrt(n) (and the complex spectrum
+// on request); PLAIN: magnitude_plain(), else the careful form
+template <bool PLAIN>
+__device__ __forceinline__ void wavew_unpack_store(const sot_wfft::v2f* zl, const sot_wfft::v2f* wn, int lane, float scale, float* dst, float2* sp)
+{
+    using namespace sot_wfft;
+    constexpr int m = 1024;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        if (q == 8 && lane != 0) break;
+        const int k = (q < 8) ? 64 * q + lane : m / 2;
+        const sot_wfft::v2f zk = zl[k], zm = zl[m - k];                  // (k = 0: slot m holds the copy of Z_0)
+        const sot_wfft::v2f e = add_conj(zk, zm), o = sub_conj(zk, zm);
+        const sot_wfft::v2f wz = sot_wfft::cmul(o, wn[k]), eh = 0.5f * e;
+        const sot_wfft::v2f xk = eh + wz, xc = eh - wz;                   // X_k, conj X_(m-k)
+        const v2f xk_ = (v2f){xk.x, xk.y}, xc_ = (v2f){xc.x, xc.y};
+        store_mag(dst, k, (PLAIN ? magnitude_plain(xk_) : magnitude(xk_)) * scale);
+        store_mag(dst, m - k, (PLAIN ? magnitude_plain(xc_) : magnitude(xc_)) * scale);
+        if (sp != nullptr) { sp[k] = make_float2(xk.x, xk.y); sp[m - k] = make_float2(xc.x, -xc.y); }
+    }
+}
+
+__global__ __launch_bounds__(kFwdwThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mag_forward_wavew_kernel(const StftArgs a)
+{
+    using namespace sot_wfft;
+    constexpr int n = 2048, nb = 1025;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    sot_wfft::v2f* const tw = reinterpret_cast<sot_wfft::v2f*>(smem_f);
+    sot_wfft::v2f* const wn = tw + kTw;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    sot_wfft::v2f* const zl = wn + kWnMax + wave * kBuf;
+    const float2* const win2 = reinterpret_cast<const float2*>(a.window);
+    const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;
+    const unsigned stride = gridDim.x * kFwdwWaves;
+    build_tables<kFwdwThreads>(kWn, tw, wn);
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)n);
+    for (unsigned fr = blockIdx.x * kFwdwWaves + wave; fr < total; fr += stride) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const unsigned b = fr / frames, f = fr - b * frames;
+        const float* src = (a.audio_b != nullptr && (int64_t)b >= a.split) ? a.audio_b + ((int64_t)b - a.split) * a.row_stride_b
+                                                                          : a.audio + (int64_t)b * a.row_stride;
+        const int64_t t0 = (int64_t)f * a.hop;
+        const float* const s0 = src + t0;
+        sot_wfft::v2f r[16];
+        const bool pairs = t0 + n <= a.samples && (reinterpret_cast<uintptr_t>(s0) & 7u) == 0;   // wave-uniform
+        if (pairs) {
+            const float2* const s2 = reinterpret_cast<const float2*>(s0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const float2 v = s2[64 * q + lane]; r[q] = (sot_wfft::v2f){v.x, v.y}; }
+        } else {
+            const int left = (int)min((int64_t)n, a.samples - t0);      // zeros past the clip's end (utils.py:252-275)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = 64 * q + lane;
+                r[q] = (sot_wfft::v2f){(2 * i < left) ? s0[2 * i] : 0.0f, (2 * i + 1 < left) ? s0[2 * i + 1] : 0.0f};
+            }
+        }
+        float amax = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 wv = win2[64 * q + lane];
+            r[q] = r[q] * (sot_wfft::v2f){wv.x, wv.y};
+            amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
+        }
+        const bool plain = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;   // one range test per FRAME
+        forward_transform<10>(r, zl, tw, lane);
+        write_natural<10>(r, zl, lane);
+        wave_sync();
+        float* const dst = a.mag + (int64_t)fr * nb;
+        float2* const sp = (a.spec != nullptr && (int64_t)b >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * nb : nullptr;
+        if (plain) wavew_unpack_store<true>(zl, wn, lane, scale, dst, sp);
+        else wavew_unpack_store<false>(zl, wn, lane, scale, dst, sp);
+        wave_sync();   // the unpack reads are issued before the next frame's exchange writes
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void stft_overlap_add_kernel(const StftArgs a)
 {
     // clips over blockIdx.y; 32-bit arithmetic inside a clip (samples < 2^31 is checked by the host)
@@ -1443,6 +1645,12 @@ static bool launch_forward_wave2(const StftArgs& a, int64_t frames_total, hipStr
 #ifndef SOT_STFT_BWD_CLIP_MIN_CLIPS
 #define SOT_STFT_BWD_CLIP_MIN_CLIPS 64
 #endif
+#ifndef SOT_STFT_BWD_CLIPW_KERNEL
+#define SOT_STFT_BWD_CLIPW_KERNEL 1
+#endif
+#ifndef SOT_STFT_FWD_WAVEW_MIN_FRAMES
+#define SOT_STFT_FWD_WAVEW_MIN_FRAMES 512     /* below: the slot kernels (a frame is a dependent chain on one wave: small batches want the frame spread over four) */
+#endif
 // the backward from the stored spectrum with the overlap-add inside: clips of at most 16 frames of 2048, one workgroup per clip.  Returns true
 // when it has launched the WHOLE backward (the caller then skips stft_overlap_add_kernel).
 static bool launch_backward_spec_clip(const StftArgs& a, hipStream_t st)
@@ -1460,6 +1668,19 @@ static bool launch_backward_spec_clip(const StftArgs& a, hipStream_t st)
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int64_t cap = cu_count();
+#if SOT_STFT_BWD_CLIPW_KERNEL     /* round 5: the same structure on the one-wavefront FFT of csrc/sot_wave_fft.hpp */
+    {
+        static bool attrw_done[64] = {};
+        if (dev < 0 || dev >= 64 || !attrw_done[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_backward_spec_clipw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kClipwLdsBytes) != hipSuccess)
+                (void)hipGetLastError();
+            if (dev >= 0 && dev < 64) attrw_done[dev] = true;
+        }
+        hipLaunchKernelGGL(stft_mag_backward_spec_clipw_kernel, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(kWave2Threads), kClipwLdsBytes, st, a);
+        return true;
+    }
+#endif
     hipLaunchKernelGGL(stft_mag_backward_spec_clip_kernel, dim3((unsigned)(a.batch < cap ? a.batch : cap)), dim3(kWave2Threads), kWave2LdsBytes, st, a);
     return true;
 }
@@ -1485,8 +1706,28 @@ static bool launch_backward_spec_wave2(const StftArgs& a, int64_t groups_total, 
     return true;
 }
 
+// n_fft 2048, SOT_STFT_FWD_WAVEW_MIN_FRAMES <= frames < SOT_STFT_WAVE2_MIN_FRAMES: one wavefront per frame on the round-5 FFT (the round-4
+// wave kernel keeps the larger batches: its results on BASELINE config 5 are what the cutoff mode's knife-edge statistics were taken with)
+static bool launch_forward_wavew(const StftArgs& a, int64_t frames_total, hipStream_t st)
+{
+    if (a.logm != 10 || frames_total < SOT_STFT_FWD_WAVEW_MIN_FRAMES || (SOT_STFT_WAVE2_KERNEL && frames_total >= SOT_STFT_WAVE2_MIN_FRAMES)) return false;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_forward_wavew_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kFwdwLdsBytes) != hipSuccess)
+            (void)hipGetLastError();
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int64_t want = (frames_total + kFwdwWaves - 1) / kFwdwWaves, cap = 2 * (int64_t)cu_count();   // two 512-thread workgroups per CU
+    hipLaunchKernelGGL(stft_mag_forward_wavew_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(kFwdwThreads), kFwdwLdsBytes, st, a);
+    return true;
+}
+
 static bool launch_forward_wave(const StftArgs& a, int64_t frames_total, hipStream_t st)
 {
+    if (launch_forward_wavew(a, frames_total, st)) return true;
     if (launch_forward_wave2(a, frames_total, st)) return true;
     if (!SOT_STFT_WAVE_KERNEL || a.logm != 10) return false;
     const size_t lds = (1024 + 520 + 4 * (size_t)kWaveBuf) * sizeof(float2);
