@@ -27,8 +27,10 @@ namespace sot_mss {
 
 using namespace sot_wfft;             // the one-wavefront FFT engine (csrc/sot_wave_fft.hpp)
 
-constexpr int kThreads = 512, kWaves = 8;
-constexpr size_t kLdsBytes = ((size_t)kWaves * kBuf + kTw + kWnMax) * sizeof(float2);
+// workgroups of 8 waves (two per CU: 2 x 80 KB of LDS) for batches that take more than one round of the chip's 16 x CUs wave slots; of 4 waves
+// (three per CU) for smaller ones -- the paper's 64 clips are 3072 tasks: 384 workgroups of 8 leave half the CUs with 16 waves and half with 8,
+// 768 of 4 give every CU 12 (41.6 -> 37.9 us; 256 clips: 98.7 -> 106.9 us, so the large form stays for those)
+constexpr size_t lds_bytes(int waves) { return ((size_t)waves * kBuf + kTw + kWnMax) * sizeof(float2); }
 constexpr int kMaxScales = 8;
 // Diagnostic build only (-DMSS_STAMPS): wave 0 of the workgroups 0, 1, 2, ... (at most 64) stamps the shader clock at its phase boundaries
 // (tools/r5/mss_stamps.py reads them through sot_mss_debug_read_stamps)
@@ -329,15 +331,15 @@ __device__ __forceinline__ void wave_task(const MssArgs& a, int s, int task, con
 // Persistent workgroups: each builds the two twiddle tables once (W_1024^t for the transforms; -i W_2048^k / 2 for the real-frame bins of
 // every scale); after that barrier its eight waves are on their own, each with a CONTIGUOUS range of tasks -- mostly one scale, so the
 // scale's code stays in the instruction cache.
-template <bool GRAD, int KIND>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSS_WAVES_PER_EU, MSS_WAVES_PER_EU))) void mss_fused_kernel(const MssArgs a, int tasks_per_wave)
+template <bool GRAD, int KIND, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(MSS_WAVES_PER_EU, MSS_WAVES_PER_EU))) void mss_fused_kernel(const MssArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     v2f* const tw = reinterpret_cast<v2f*>(smem_f);      // tables first: every lane-part address into a wave's buffer stays positive
     v2f* const wn = tw + kTw;
     v2f* const bufs = wn + kWnMax;
     MSS_STAMP(0);
-    build_tables<kThreads>(kWn, tw, wn);
+    build_tables<64 * kWaves>(kWn, tw, wn);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v2f* const zl = bufs + wave * kBuf;
@@ -347,7 +349,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MSS_WA
     // code: with a contiguous range per wave every CU ran all six scales at once and refetched code from L2 all the time.)
     const int stride = (int)gridDim.x * kWaves;
     int s = 0;
-    (void)tasks_per_wave;
     for (int task = (int)blockIdx.x * kWaves + wave; task < total; task += stride) {
         while (s + 1 < a.n_scales && task >= a.task_base[s + 1]) ++s;
 #ifdef MSS_ONLY_M      /* diagnostic builds: one transform size (compile time, register pressure of one body) */
@@ -567,25 +568,30 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     a.loss = loss; a.grad = grad_value; a.want_grad = grad_value != nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    static bool attr_done[64][4] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
     const int kind = (l2 == 0 && !(logmag_weight > 0.0f)) ? 0 : 1;     // the paper's configuration (L1 on the magnitudes) has its own instantiation
-    void (*kern)(const MssArgs, int) = kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0> : mss_fused_kernel<false, 0>)
-                                            : (a.want_grad ? mss_fused_kernel<true, 1> : mss_fused_kernel<false, 1>);
-    const int which = 2 * kind + a.want_grad;
+    const int tasks = a.task_base[n_scales], slots = 16 * cus;         // one wave per task slot: 16 waves per CU (LDS)
+    const bool small = tasks <= slots;                                 // a single round: 4-wave workgroups spread it evenly
+    void (*kern)(const MssArgs) =
+        small ? (kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0, 4> : mss_fused_kernel<false, 0, 4>)
+                           : (a.want_grad ? mss_fused_kernel<true, 1, 4> : mss_fused_kernel<false, 1, 4>))
+              : (kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0, 8> : mss_fused_kernel<false, 0, 8>)
+                           : (a.want_grad ? mss_fused_kernel<true, 1, 8> : mss_fused_kernel<false, 1, 8>));
+    const int wg_waves = small ? 4 : 8;
+    static bool attr_done[64][8] = {};
+    const int which = 4 * (small ? 1 : 0) + 2 * kind + a.want_grad;
     if (dev < 0 || dev >= 64 || !attr_done[dev][which]) {   // idempotent per device; a benign race sets it twice
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(wg_waves)) != hipSuccess)
             (void)hipGetLastError();
         if (dev >= 0 && dev < 64) attr_done[dev][which] = true;
     }
-    // persistent grid: two workgroups per CU (LDS), every wave a contiguous range of tasks
-    int cus = 256;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
-    const int tasks = a.task_base[n_scales], slots = 2 * cus * kWaves;              // one wave per task slot
-    const int per = (tasks + slots - 1) / slots, waves_needed = (tasks + per - 1) / per;
+    // persistent grid: at most 16 waves per CU; wave g takes tasks g, g + (waves of the grid), ...
+    const int waves_needed = tasks < slots ? tasks : slots;
 #ifndef MSS_SKIP_FUSED     /* diagnostic (timing only, results are garbage): the finish kernel on its own */
-    hipLaunchKernelGGL(kern, dim3((unsigned)((waves_needed + kWaves - 1) / kWaves)), dim3(kThreads), kLdsBytes, st, a, per);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves_needed + wg_waves - 1) / wg_waves)), dim3(64 * wg_waves), lds_bytes(wg_waves), st, a);
 #endif
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
     const int64_t work = a.want_grad ? batch * ((((samples + 1) / 2) + 255) / 256) : 1;      // one workgroup per (clip, 256 packed points)

@@ -36,6 +36,9 @@ struct Api {
     decltype(&sot_stft_mag_forward_pair_spec) stft_pair = nullptr;
     decltype(&sot_stft_mag_backward_spec) stft_backward = nullptr;
     decltype(&sot_stft_backward_workspace_bytes) stft_backward_ws = nullptr;
+    decltype(&sot_stft_mag_forward_spec) stft_forward = nullptr;
+    decltype(&sot_mss_workspace_bytes) mss_ws = nullptr;
+    decltype(&sot_mss_loss_and_grad) mss = nullptr;
 };
 Api g_api;
 
@@ -62,6 +65,9 @@ int64_t bind_library(const std::string& path)
     bind_symbol(handle, "sot_stft_mag_forward_pair_spec", g_api.stft_pair);
     bind_symbol(handle, "sot_stft_mag_backward_spec", g_api.stft_backward);
     bind_symbol(handle, "sot_stft_backward_workspace_bytes", g_api.stft_backward_ws);
+    bind_symbol(handle, "sot_stft_mag_forward_spec", g_api.stft_forward);
+    bind_symbol(handle, "sot_mss_workspace_bytes", g_api.mss_ws);
+    bind_symbol(handle, "sot_mss_loss_and_grad", g_api.mss);
     TORCH_CHECK(g_api.abi() == SOT_ABI_VERSION, "sot glue: libsot_hip.so has ABI version ", g_api.abi(), ", this glue was built for ",
                 SOT_ABI_VERSION);
     return g_api.abi();
@@ -314,6 +320,119 @@ at::Tensor audio_to_loss(const at::Tensor& target, const at::Tensor& estimate, c
     return AudioToLoss::apply(target, estimate, window, xs, ys, xperm, yperm, ident, n_fft, hop, p, flags, grad);
 }
 
+// ---- round 5: the two other modules of the trainer's loss block (trainer.py:199-221) on the same kind of host path: the transform
+// (`features.TorchSTFT.forward`: spectra.stft_magnitude) and `MSSLoss`.  Launched from Python through ctypes + a Python autograd.Function each
+// costs 40-60 us of host time per call; the paper's step makes five such calls.
+
+// [clips, samples] audio -> [clips, frames, n_fft / 2 + 1] magnitudes; keeps the complex spectrum for the backward when the audio is differentiated
+class StftMagnitude : public torch::autograd::Function<StftMagnitude> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& audio, const at::Tensor& window, int64_t n_fft, int64_t hop, bool grad)
+    {
+        TORCH_CHECK(audio.is_cuda() && audio.scalar_type() == at::kFloat && audio.dim() == 2 && audio.is_contiguous(),
+                    "sot glue: audio must be a contiguous float32 GPU tensor [clips, samples]");
+        TORCH_CHECK(window.is_cuda() && window.scalar_type() == at::kFloat && window.is_contiguous() && window.numel() == n_fft &&
+                    reinterpret_cast<uintptr_t>(window.data_ptr<float>()) % 8 == 0, "sot glue: window must hold n_fft float32 taps, 8-byte aligned");
+        const int64_t clips = audio.size(0), samples = audio.size(1);
+        const int64_t frames = g_api.stft_frames(samples, (int)hop), bins = n_fft / 2 + 1;
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(audio.device());
+        at::Tensor mag = at::empty({clips, frames, bins}, audio.options());
+        at::Tensor cplx = grad ? at::empty({clips, frames, bins, 2}, audio.options()) : at::Tensor();
+        check_status(g_api.stft_forward(audio.data_ptr<float>(), clips, samples, samples, window.data_ptr<float>(), (int)n_fft, (int)hop,
+                                        mag.data_ptr<float>(), grad ? cplx.data_ptr<float>() : nullptr, current_stream(audio)), 1.0);
+        if (grad) {
+            ctx->save_for_backward({window});
+            ctx->saved_data["cplx"] = cplx;
+            ctx->saved_data["n_fft"] = n_fft;
+            ctx->saved_data["hop"] = hop;
+            ctx->saved_data["samples"] = samples;
+        }
+        return mag;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs)
+    {
+        at::Tensor g = grad_outputs[0];
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        g = g.contiguous();
+        const at::Tensor cplx = ctx->saved_data["cplx"].toTensor();
+        const at::Tensor window = ctx->get_saved_variables()[0];
+        const int64_t n_fft = ctx->saved_data["n_fft"].toInt(), hop = ctx->saved_data["hop"].toInt(), samples = ctx->saved_data["samples"].toInt();
+        const int64_t clips = cplx.size(0);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.device());
+        at::Tensor grad_audio = at::empty({clips, samples}, g.options());
+        const size_t ws_bytes = g_api.stft_backward_ws(clips, samples, (int)n_fft, (int)hop);
+        at::Tensor ws = at::empty({(int64_t)(ws_bytes > 0 ? ws_bytes : 1)}, g.options().dtype(at::kByte));
+        check_status(g_api.stft_backward(nullptr, cplx.data_ptr<float>(), clips, samples, samples, window.data_ptr<float>(), (int)n_fft, (int)hop,
+                                         g.data_ptr<float>(), nullptr, grad_audio.data_ptr<float>(), 0, ws.data_ptr(), ws_bytes, current_stream(g)), 1.0);
+        return {grad_audio, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor stft_magnitude(const at::Tensor& audio, const at::Tensor& window, int64_t n_fft, int64_t hop)
+{
+    TORCH_CHECK(g_api.stft_forward != nullptr, "sot glue: bind() has not been called");
+    const bool grad = at::GradMode::is_enabled() && audio.requires_grad();   // decided here: forward() runs with grad mode off
+    return StftMagnitude::apply(audio, window, n_fft, hop, grad);
+}
+
+// MSSLoss in two launches (sot_mss_loss_and_grad): the loss and d loss / d estimate from the forward; the backward multiplies by the upstream
+// gradient (one scalar, or one value per clip for the `dims` = (1, 2) form)
+class MssLoss : public torch::autograd::Function<MssLoss> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate,
+                              const std::vector<at::Tensor>& windows, const std::vector<int64_t>& fft_sizes, double mag_weight, double logmag_weight,
+                              bool l2, bool per_clip, bool grad)
+    {
+        TORCH_CHECK(target.is_cuda() && target.scalar_type() == at::kFloat && target.dim() == 2 && estimate.is_cuda() &&
+                    estimate.scalar_type() == at::kFloat && estimate.sizes() == target.sizes() && target.stride(1) == 1 && estimate.stride(1) == 1,
+                    "sot glue: target and estimate must be float32 GPU tensors [clips, samples] of one shape with unit inner stride");
+        const int n = (int)fft_sizes.size();
+        TORCH_CHECK(n >= 1 && n <= 8 && (int)windows.size() == n, "sot glue: one window per FFT size, at most 8");
+        int sizes[8];
+        const float* wins[8];
+        for (int i = 0; i < n; ++i) {
+            sizes[i] = (int)fft_sizes[i];
+            TORCH_CHECK(windows[i].is_cuda() && windows[i].scalar_type() == at::kFloat && windows[i].is_contiguous() && windows[i].numel() == fft_sizes[i] &&
+                        reinterpret_cast<uintptr_t>(windows[i].data_ptr<float>()) % 8 == 0, "sot glue: window ", i, " must hold n_fft float32 taps, 8-byte aligned");
+            wins[i] = windows[i].data_ptr<float>();
+        }
+        const int64_t clips = target.size(0), samples = target.size(1);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(target.device());
+        const size_t ws_bytes = g_api.mss_ws(clips, samples, sizes, n);
+        TORCH_CHECK(ws_bytes > 0 || clips == 0, "libsot_hip: unsupported size (status ", (int)SOT_ERR_UNSUPPORTED_SIZE, ")");
+        at::Tensor ws = at::empty({(int64_t)(ws_bytes > 0 ? ws_bytes : 8)}, target.options().dtype(at::kByte));
+        at::Tensor loss = per_clip ? at::empty({clips}, target.options()) : at::empty({}, target.options());
+        at::Tensor gv = grad ? at::empty({clips, samples}, target.options()) : at::Tensor();
+        check_status(g_api.mss(target.data_ptr<float>(), clips > 1 ? target.stride(0) : samples, estimate.data_ptr<float>(),
+                               clips > 1 ? estimate.stride(0) : samples, clips, samples, sizes, wins, n, (float)mag_weight, (float)logmag_weight, 1e-5f,
+                               l2 ? 1 : 0, per_clip ? 1 : 0, loss.data_ptr<float>(), grad ? gv.data_ptr<float>() : nullptr, ws.data_ptr(), ws_bytes,
+                               current_stream(target)), 1.0);
+        if (grad) ctx->saved_data["gv"] = gv;
+        ctx->saved_data["per_clip"] = per_clip;
+        return loss;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs)
+    {
+        at::Tensor g = grad_outputs[0];
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        const at::Tensor gv = ctx->saved_data["gv"].toTensor();
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(gv.device());
+        at::Tensor out = ctx->saved_data["per_clip"].toBool() ? gv * g.reshape({-1, 1}) : gv * g;   // the stored gradient is never modified
+        return {at::Tensor(), out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor mss_loss(const at::Tensor& target, const at::Tensor& estimate, const std::vector<at::Tensor>& windows, const std::vector<int64_t>& fft_sizes,
+                    double mag_weight, double logmag_weight, bool l2, bool per_clip)
+{
+    TORCH_CHECK(g_api.mss != nullptr, "sot glue: bind() has not been called");
+    TORCH_CHECK(!(at::GradMode::is_enabled() && target.requires_grad()), "sot glue: a gradient w.r.t. the target is not this path's case");
+    const bool grad = at::GradMode::is_enabled() && estimate.requires_grad();
+    return MssLoss::apply(target, estimate, windows, fft_sizes, mag_weight, logmag_weight, l2, per_clip, grad);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -324,4 +443,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("mean_loss_fresh", &mean_loss_fresh, "mean_loss on raw 1-D position tensors: the plan is prepared inside the call (one allocation, one launch)");
     m.def("make_plan", &make_plan, "sot_prepare_positions into one allocation: (sorted x, sorted y, x permutation, y permutation, identity flags)");
     m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
+    m.def("stft_magnitude", &stft_magnitude, "[clips, samples] -> [clips, frames, n_fft / 2 + 1] magnitudes (features.TorchSTFT); differentiable w.r.t. the audio");
+    m.def("mss_loss", &mss_loss, "MSSLoss in two launches (sot_mss_loss_and_grad); differentiable w.r.t. the estimate's audio");
 }

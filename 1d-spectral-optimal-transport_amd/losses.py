@@ -643,7 +643,13 @@ class MSSLoss(torch.nn.Module):
                       "64..4096, shapes that differ, or both weights zero)")
         if native_ok and MSS_FUSED and len(self.fft_sizes) <= 8 and all(int(s) in nat.MSS_FUSED_SIZES for s in self.fft_sizes) and \
                 not (torch.is_grad_enabled() and target_audio.requires_grad):
-            return _MultiScaleSpectralFused.apply(target_audio.float(), audio.float(), tuple(int(s) for s in self.fft_sizes), float(self.mag_weight),
+            sizes = tuple(int(s) for s in self.fft_sizes)
+            glue = nat.glue() if (audio.dtype == torch.float32 and target_audio.dtype == torch.float32 and audio.stride(1) == 1 and
+                                  target_audio.stride(1) == 1 and audio.shape[0] > 0) else None
+            if glue is not None:   # ONE C++ call and a C++ autograd node (csrc/sot_torch_glue.cpp: MssLoss)
+                wins = [spectra._cached_window(None, size, audio.device) for size in sizes]
+                return glue.mss_loss(target_audio, audio, wins, list(sizes), float(self.mag_weight), float(self.logmag_weight), kind == "L2", per_item)
+            return _MultiScaleSpectralFused.apply(target_audio.float(), audio.float(), sizes, float(self.mag_weight),
                                                   float(self.logmag_weight), kind == "L2", per_item)
         if native_ok:
             return _MultiScaleSpectral.apply(target_audio.float(), audio.float(), self.fft_sizes, float(self.mag_weight),

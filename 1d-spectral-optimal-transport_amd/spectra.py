@@ -119,6 +119,11 @@ def stft_magnitude(audio: torch.Tensor, n_fft: int = 2048, hop: int = 256, windo
     (features.py:85-113).  GPU tensors run the HIP kernels (differentiable w.r.t. the audio); CPU tensors and sizes
     outside hip_stft_supported() run torch.stft."""
     if audio.is_cuda and audio.ndim == 2 and hip_stft_supported(n_fft, hop, audio.shape[1]):
+        if audio.dtype == torch.float32 and SAVE_SPECTRUM:
+            from . import _native as nat
+            glue = nat.glue()
+            if glue is not None:   # the same kernels behind ONE C++ call and a C++ autograd node (csrc/sot_torch_glue.cpp)
+                return glue.stft_magnitude(audio.contiguous(), _cached_window(window, n_fft, audio.device), int(n_fft), int(hop))
         return _StftMagnitude.apply(audio.float(), _cached_window(window, n_fft, audio.device), int(n_fft), int(hop))
     if audio.is_cuda:   # not silent: a GPU tensor that leaves the HIP path says so, once per size
         from .losses import warn_once

@@ -175,3 +175,36 @@ def test_target_gradient_takes_the_differentiating_chain():
     yd = y.to(device()).requires_grad_(True)
     MSSLoss(mag_weight=1.0)(xd, yd).backward()
     assert xd.grad is not None and float(xd.grad.abs().max()) > 0 and float(yd.grad.abs().max()) > 0
+
+
+def test_cpp_host_paths_equal_the_python_nodes():
+    """Round 5: spectra.stft_magnitude and MSSLoss go through _sot_glue.so (one C++ call, C++ autograd nodes: csrc/sot_torch_glue.cpp
+    StftMagnitude / MssLoss) -- same kernels, so values and gradients are bit for bit those of the Python autograd.Functions on ctypes."""
+    from gpu_util import device, native
+    import sot_amd.losses as L
+    from sot_amd import spectra
+    nat = native()
+    assert nat.glue() is not None, "the C++ host path must be built (python __graft_entry__.py)"
+    dev = device()
+    x, y = _clips(5, 4096, 31)
+    xd = x.to(dev)
+    for per_item in (False, True):
+        w = torch.linspace(0.5, 1.5, 5, device=dev) if per_item else torch.tensor(0.05, device=dev)
+        y1 = y.to(dev).requires_grad_(True)
+        a = L.MSSLoss(mag_weight=1.0, logmag_weight=0.5)(xd, y1, **({"dims": (1, 2)} if per_item else {}))
+        (a * w).sum().backward()
+        y2 = y.to(dev).requires_grad_(True)
+        b = L._MultiScaleSpectralFused.apply(xd, y2, SIZES, 1.0, 0.5, False, per_item)
+        (b * w).sum().backward()
+        assert torch.equal(a.detach(), b.detach()) and torch.equal(y1.grad, y2.grad)
+    for n_fft, hop, win in ((2048, 256, "flattop"), (512, 128, None)):
+        y1 = y.to(dev).requires_grad_(True)
+        m1 = spectra.stft_magnitude(y1, n_fft, hop, win)
+        up = torch.rand(m1.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        (m1 * up).sum().backward()
+        y2 = y.to(dev).requires_grad_(True)
+        m2 = spectra._StftMagnitude.apply(y2, spectra._cached_window(win, n_fft, dev), n_fft, hop)
+        (m2 * up).sum().backward()
+        assert torch.equal(m1.detach(), m2.detach()) and torch.equal(y1.grad, y2.grad)
+    with torch.no_grad():
+        assert torch.equal(spectra.stft_magnitude(xd, 2048, 256, "flattop"), nat.stft_mag_forward(xd, spectra._cached_window("flattop", 2048, dev), 2048, 256))

@@ -12,7 +12,14 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
-print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("stats_extras/**/*kernel_stats.csv"):
+    print("== kernel stats of the WHOLE bench command, extras included (rocprofv3 --kernel-trace --stats; library kernels only) ==")
+    for row in csv.DictReader(open(f)):
+        name = row.get("Name", "")
+        if "sot" in name:
+            print(f"{name[:110]:110s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} total_ns={row.get('TotalDurationNs')}")
+
+print("== kernel stats of the headline command (rocprofv3 --kernel-trace --stats) ==")
 for f in find("stats/**/*kernel_stats.csv"):
     for row in csv.DictReader(open(f)):
         name = row.get("Name", "")[:90]
