@@ -647,7 +647,7 @@ class MSSLoss(torch.nn.Module):
             glue = nat.glue() if (audio.dtype == torch.float32 and target_audio.dtype == torch.float32 and audio.stride(1) == 1 and
                                   target_audio.stride(1) == 1 and audio.shape[0] > 0) else None
             if glue is not None:   # ONE C++ call and a C++ autograd node (csrc/sot_torch_glue.cpp: MssLoss)
-                wins = [spectra._cached_window(None, size, audio.device) for size in sizes]
+                wins = spectra._cached_windows(None, sizes, audio.device)
                 return glue.mss_loss(target_audio, audio, wins, list(sizes), float(self.mag_weight), float(self.logmag_weight), kind == "L2", per_item)
             return _MultiScaleSpectralFused.apply(target_audio.float(), audio.float(), sizes, float(self.mag_weight),
                                                   float(self.logmag_weight), kind == "L2", per_item)

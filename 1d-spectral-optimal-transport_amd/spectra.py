@@ -81,6 +81,23 @@ def _cached_window(name, n_fft: int, device) -> torch.Tensor:
     return _WINDOWS.get((str(name), int(n_fft), str(device)), device, lambda: analysis_window(name, n_fft, device), host_side=True)
 
 
+_WINDOW_LISTS = {}
+
+
+def _cached_windows(name, sizes, device):
+    """The windows of several transform sizes as a list, cached per (sizes, device, STREAM): the first call on a stream goes through
+    _cached_window (which makes that stream wait for a table another stream built), later calls on it are one dictionary lookup
+    (MSSLoss asked for its six windows one by one on every call: ~20 us of host time per training step)."""
+    from . import _native as nat
+    key = (name, sizes, device.index, nat.stream_ptr(device))
+    hit = _WINDOW_LISTS.get(key)
+    if hit is None:
+        hit = [_cached_window(name, size, device) for size in sizes]
+        if not torch.cuda.is_current_stream_capturing():
+            _WINDOW_LISTS[key] = hit
+    return hit
+
+
 SAVE_SPECTRUM = True   # module switch (tests compare both forms): differentiated forwards also store the complex spectrum
 
 
