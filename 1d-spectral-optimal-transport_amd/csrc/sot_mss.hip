@@ -328,8 +328,8 @@ __device__ __forceinline__ void wave_task(const MssArgs& a, int s, int task, con
     MSS_STAMP(8);
 }
 
-// Persistent workgroups: each builds the two twiddle tables once (W_1024^t for the transforms; -i W_2048^k / 2 for the real-frame bins of
-// every scale); after that barrier its eight waves are on their own, each with a CONTIGUOUS range of tasks -- mostly one scale, so the
+// Persistent workgroups: each builds the two twiddle tables once (the stage twiddles in compact per-stage blocks, sot_wave_fft.hpp: tw_block; -i W_2048^k / 2 for the real-frame bins of
+// every scale); after that barrier its waves (4 or 16) are on their own, each with a CONTIGUOUS range of tasks -- mostly one scale, so the
 // scale's code stays in the instruction cache.
 template <bool GRAD, int KIND, int kWaves>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(MSS_WAVES_PER_EU, MSS_WAVES_PER_EU))) void mss_fused_kernel(const MssArgs a)
@@ -578,9 +578,9 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     void (*kern)(const MssArgs) =
         small ? (kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0, 4> : mss_fused_kernel<false, 0, 4>)
                            : (a.want_grad ? mss_fused_kernel<true, 1, 4> : mss_fused_kernel<false, 1, 4>))
-              : (kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0, 8> : mss_fused_kernel<false, 0, 8>)
-                           : (a.want_grad ? mss_fused_kernel<true, 1, 8> : mss_fused_kernel<false, 1, 8>));
-    const int wg_waves = small ? 4 : 8;
+              : (kind == 0 ? (a.want_grad ? mss_fused_kernel<true, 0, 16> : mss_fused_kernel<false, 0, 16>)
+                           : (a.want_grad ? mss_fused_kernel<true, 1, 16> : mss_fused_kernel<false, 1, 16>));
+    const int wg_waves = small ? 4 : 16;     // LDS: tables 16.4 KB + 8.7 KB per wave: three 4-wave workgroups or one of 16 waves per CU
     static bool attr_done[64][8] = {};
     const int which = 4 * (small ? 1 : 0) + 2 * kind + a.want_grad;
     if (dev < 0 || dev >= 64 || !attr_done[dev][which]) {   // idempotent per device; a benign race sets it twice

@@ -7,12 +7,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef WFFT_DIAG_TW_NOLANE
+#define WFFT_DIAG_TW_NOLANE 0
+#endif
+
 namespace sot_wfft {
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // one complex point; arithmetic maps to v_pk_*_f32
 
 constexpr int kBuf = 1088;            // complex points of one wave's exchange buffer: 1024 + pads (both address maps)
-constexpr int kTw = 768;              // table 1: W_1024^t, t < 768
+constexpr int kTw = 1530;             // table 1: the stage twiddles, one compact block per radix-4 stage position (tw_block)
 constexpr int kWnMax = 520;           // table 2: -i W_2048^k / 2, k <= 512 (scale M reads index k << (10 - M))
 
 __device__ __forceinline__ void wave_sync()
@@ -110,6 +114,10 @@ __host__ __device__ constexpr int addr_mid(int pos) { return pos + (pos >> 4) + 
 // ---- in-register stages -------------------------------------------------------------------------------------------------------------
 // radix-4 on position bits (BETA, BETA - 1), both carried by the register index in phase PH.  Register p = 2 b_BETA + b_(BETA-1) of each
 // group of four; lam = the position bits below the stage; twiddles W_(2^(BETA+1))^(q lam) = tw[q * (lam << (9 - BETA))] (index < 768).
+// first entry of the table block of the radix-4 stage on position bits (BETA, BETA - 1), BETA >= 2: blocks of 3 * 2^(BETA-1) entries in
+// ascending BETA (tests/wave_fft_model.py: tw_addr); BETA = 1 has no twiddle (q = 0)
+__host__ __device__ constexpr int tw_block(int beta) { return beta >= 2 ? 3 * ((1 << (beta - 1)) - 2) : 0; }
+
 // Forward (decimation in frequency): v0 = s02 + s13, v1 = (s02 - s13) w2, v2 = (d02 - i d13) w1, v3 = (d02 + i d13) w3.
 // INV: the transposed butterfly with conjugate twiddles applied first (the inverse network runs the forward one backwards).
 template <int M, int PH, int BETA, bool INV>
@@ -118,16 +126,21 @@ __device__ __forceinline__ void radix4_stage(v2f (&r)[16], const v2f* tw, int la
     using G = Geo<M>;
     constexpr int th = G::tbit(PH, BETA), tl = G::tbit(PH, BETA - 1);
     static_assert(th >= 0 && tl >= 0, "stage bits must be register bits");
-    constexpr int mask = (1 << (BETA - 1)) - 1, sh = 9 - BETA;
+    constexpr int mask = (1 << (BETA - 1)) - 1, half = 1 << (BETA - 1);
     constexpr bool lane_low = ((~G::reg_posmask(PH)) & mask) != 0;       // some of the bits below the stage are lane bits
-    const int ll = lane_low ? ((lanepos & mask) << sh) : 0;
-    const v2f* const t1 = tw + ll;
-    const v2f* const t2 = tw + 2 * ll;
-    const v2f* const t3 = tw + 3 * ll;
+    // q = the position bits below the stage; the stage's block of the table holds W^q, W^2q, W^3q (W = the 2^(BETA+1)-th root) as three runs
+    // of `half` consecutive entries: the lanes of a wave differ in the LOW bits of q and read consecutive slots -- no bank conflicts (the
+    // single strided table W_1024^(q << (9 - BETA)) of the first form had up to 8 lanes per bank: 35 % of the MSS kernel's LDS cycles)
+#if WFFT_DIAG_TW_NOLANE   /* diagnostic only (wrong values): lane-independent twiddle addresses, to price the reads' bank conflicts */
+    const int ll = 0;
+#else
+    const int ll = lane_low ? (lanepos & mask) : 0;
+#endif
+    const v2f* const t1 = tw + tw_block(BETA) + ll;
 #pragma unroll
     for (int base = 0; base < 16; ++base) {
         if (((base >> th) & 1) || ((base >> tl) & 1)) continue;
-        const int o = (G::pos_reg(PH, base) & mask) << sh;                // compile-time after unrolling
+        const int o = G::pos_reg(PH, base) & mask;                        // compile-time after unrolling
         const int i0 = base, i1 = base | (1 << tl), i2 = base | (1 << th), i3 = base | (1 << th) | (1 << tl);
         const bool trivial = !lane_low && o == 0;
         if (!INV) {
@@ -135,10 +148,10 @@ __device__ __forceinline__ void radix4_stage(v2f (&r)[16], const v2f* tw, int la
             r[i0] = s02 + s13;
             const v2f v1 = s02 - s13, v2 = add_mi(d02, d13), v3 = add_pi(d02, d13);
             if (trivial) { r[i1] = v1; r[i2] = v2; r[i3] = v3; }
-            else { r[i1] = cmul(v1, t2[2 * o]); r[i2] = cmul(v2, t1[o]); r[i3] = cmul(v3, t3[3 * o]); }
+            else { r[i1] = cmul(v1, t1[half + o]); r[i2] = cmul(v2, t1[o]); r[i3] = cmul(v3, t1[2 * half + o]); }
         } else {
             v2f v1 = r[i1], v2 = r[i2], v3 = r[i3];
-            if (!trivial) { v1 = cmul_conj(v1, t2[2 * o]); v2 = cmul_conj(v2, t1[o]); v3 = cmul_conj(v3, t3[3 * o]); }
+            if (!trivial) { v1 = cmul_conj(v1, t1[half + o]); v2 = cmul_conj(v2, t1[o]); v3 = cmul_conj(v3, t1[2 * half + o]); }
             const v2f s01 = r[i0] + v1, d01 = r[i0] - v1, s23 = v2 + v3, d23 = v2 - v3;
             r[i0] = s01 + s23; r[i2] = s01 - s23;
             r[i1] = add_pi(d01, d23); r[i3] = add_mi(d01, d23);
@@ -261,10 +274,16 @@ __device__ __forceinline__ void write_natural(const v2f (&r)[16], v2f* zl, int l
 template <int THREADS>
 __device__ __forceinline__ void build_tables(const float2* __restrict__ w4096, v2f* tw, v2f* wn)
 {
-    for (int t = threadIdx.x; t < kTw; t += THREADS) {     // W_1024^(256 a + b) = W_4096^(4 b) (-i)^a: exact quarter turns of the committed table
-        const float2 w0 = w4096[4 * (t & 255)];
+    for (int t = threadIdx.x; t < kTw; t += THREADS) {
+        // slot t = tw_block(beta) + (mult - 1) half + q, half = 2^(beta-1): W_(4 half)^(mult q) = W_1024^e, e = mult q (256 / half) < 768;
+        // W_1024^(256 a + b) = W_4096^(4 b) (-i)^a: exact quarter turns of the committed table (the values of the first form's table)
+        const int half = 1 << (31 - __builtin_clz((unsigned)(t / 3 + 2)));
+        const int rem = t - 3 * (half - 2);
+        const int mult = rem / half + 1, q = rem & (half - 1);
+        const int e = mult * q * (256 / half);
+        const float2 w0 = w4096[4 * (e & 255)];
         v2f w = (v2f){w0.x, w0.y};
-        const int qa = t >> 8;
+        const int qa = e >> 8;
         if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w;
         tw[t] = w;
     }

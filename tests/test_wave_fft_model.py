@@ -116,3 +116,19 @@ def test_addresses_are_lane_part_plus_register_part(M):
             j, k = wm.freq_of(geo, 0, reg)
             jj, kk = wm.freq_of(geo, lane, reg)
             assert geo.addr_nat(jj, kk) == geo.addr_nat(j0, k0) + geo.addr_nat(j, k)
+
+
+@pytest.mark.parametrize("M", range(5, 11))
+def test_twiddle_loads_are_conflict_free(M):
+    """The compact per-stage table: the lanes of a wave read consecutive (or equal) slots -- two LDS cycles per ds_read_b64, the minimum."""
+    cycles, reads = wm.twiddle_read_cycles(wm.Geometry(M))
+    assert reads > 0 and cycles == 2 * reads
+
+
+def test_compact_twiddle_table_layout():
+    seen = set()
+    for beta in range(2, 10):
+        for mult in (1, 2, 3):
+            for lam in range(1 << (beta - 1)):
+                seen.add(wm.tw_addr(beta, mult, lam))
+    assert seen == set(range(wm.TW_ENTRIES)) and wm.TW_ENTRIES == 1530

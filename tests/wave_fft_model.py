@@ -86,12 +86,61 @@ def stage_plan(phase_bits):
     return out
 
 
+def tw_addr(beta, mult, lam):
+    """Slot of W_{2^(beta+1)}^(mult * lam) in the COMPACT twiddle table of csrc/sot_wave_fft.hpp (round 5, second form): one block of
+    3 * 2^(beta-1) entries per radix-4 stage position beta >= 2 -- [mult - 1][lam], lam < 2^(beta-1) -- so that the lanes of a wave, which
+    differ in the LOW bits of lam, read consecutive slots (the strided single table W_1024^t had up to 8 lanes per bank)."""
+    half = 1 << (beta - 1)
+    assert beta >= 2 and 1 <= mult <= 3 and 0 <= lam < half
+    return 3 * (half - 2) + (mult - 1) * half + lam
+
+
+TW_ENTRIES = 3 * ((1 << 9) - 2)    # beta = 2 ... 9
+
+
+def tw_table():
+    tab = np.zeros(TW_ENTRIES, complex)
+    for beta in range(2, 10):
+        for mult in (1, 2, 3):
+            for lam in range(1 << (beta - 1)):
+                idx = mult * (lam << (9 - beta))          # the exponent on the 1024-point circle (what build_tables derives the entry from)
+                assert idx < 768
+                tab[tw_addr(beta, mult, lam)] = np.exp(-2j * np.pi * idx / 1024.0)
+    return tab
+
+
+_TW = tw_table()
+
+
 def twiddle(M, beta, lam, mult, inverse=False):
-    """W_{2^(beta+1)}^(mult * lam) = W_1024^(mult * lam << (9 - beta)); lam < 2^(beta-1) for radix-4 (index < 768), lam < 2^beta for radix-2 (mult = 1)."""
-    idx = mult * (lam << (9 - beta))
-    assert idx < 1024
-    w = np.exp(-2j * np.pi * idx / 1024.0)
+    """W_{2^(beta+1)}^(mult * lam) from the compact table (radix-4 stages: lam < 2^(beta-1)); beta = 1 and the radix-2 stage on bit 0 have lam = 0."""
+    if lam == 0:
+        w = 1.0 + 0j
+    else:
+        w = _TW[tw_addr(beta, mult, lam)]
+        assert abs(w - np.exp(-2j * np.pi * mult * lam / float(1 << (beta + 1)))) < 1e-15
     return np.conj(w) if inverse else w
+
+
+def twiddle_read_cycles(geo):
+    """(LDS cycles, reads) of the twiddle loads of one transform: per radix-4 butterfly three ds_read_b64 of the wave at
+    tw_addr(beta, mult, lam(lane, base)); 2 cycles per read = conflict-free (Lds.read's bank model)."""
+    table = Lds(TW_ENTRIES)
+    for layout, bits in zip(geo.layouts, geo.phase_bits):
+        for st in stage_plan(bits):
+            if len(st) != 2:
+                continue
+            tbit = {b: layout.regbits.index(b) for b in st}
+            beta, low = st[0], st[-1]
+            for base in range(REGS):
+                if any(base >> tbit[b] & 1 for b in st):
+                    continue
+                lams = [(layout.pos(lane, base) & ((1 << geo.M) - 1)) & ((1 << low) - 1) for lane in range(LANES)]
+                if beta < 2 or all(v == 0 for v in lams):
+                    continue                                # trivial butterfly: no loads
+                for mult in (1, 2, 3):
+                    table.read([tw_addr(beta, mult, v) for v in lams])
+    return table.read_cycles, table.read_ops
 
 
 def run_phase(geo, data, layout, bits, inverse=False):
