@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(MSS
     }
 }
 
-// Finish: the last workgroup turns the partial sums into the loss (per scale: fixed-order sum, mean as float32, `loss += mean` in the
+// Finish: the first workgroup turns the partial sums into the loss (per scale: fixed-order sum, mean as float32, `loss += mean` in the
 // reference's scale order, losses.py:411-424); every workgroup sums the wave spans covering its samples, scales and waves in order.
 constexpr int kFinishThreads = 256;
 __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArgs a)
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
             }
             a.loss[o] = total;
         }
-    } else if (blockIdx.x == gridDim.x - 1) {
+    } else if (blockIdx.x == 0) {      // (the FIRST workgroup: it is resident from the start, so the reduction runs beside the other workgroups' gathers, not behind them)
         // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves reduce by
         // shuffles, thread 0 adds the four wave sums per scale in order.  The loads of ALL scales of a pass (4 per thread and scale) are issued
         // before the first is used (a loop that waits per load: 48 serialised round trips for 256 clips).
