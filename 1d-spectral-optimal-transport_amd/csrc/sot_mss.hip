@@ -36,7 +36,10 @@ constexpr int kMaxScales = 8;
 // (tools/r5/mss_stamps.py reads them through sot_mss_debug_read_stamps)
 #ifdef MSS_STAMPS
 __device__ unsigned long long g_mss_stamps[64 * 16];
-#define MSS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) { __builtin_amdgcn_sched_barrier(0); g_mss_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#ifndef MSS_STAMP_EVERY
+#define MSS_STAMP_EVERY 1     /* sample workgroups 0, E, 2 E, ... (64 of them) */
+#endif
+#define MSS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x % MSS_STAMP_EVERY == 0 && blockIdx.x / MSS_STAMP_EVERY < 64) { __builtin_amdgcn_sched_barrier(0); g_mss_stamps[(blockIdx.x / MSS_STAMP_EVERY) * 16 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define MSS_STAMP(i) do { } while (0)
 #endif

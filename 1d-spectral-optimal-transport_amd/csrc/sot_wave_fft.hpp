@@ -270,24 +270,41 @@ __device__ __forceinline__ void write_natural(const v2f (&r)[16], v2f* zl, int l
     if (kl == 0) p[G::m] = r[0];
 }
 
-// the two tables from W_4096^j, j <= 1024 (csrc/sot_stft_tables.inc: kWn), by all THREADS threads of the workgroup; the caller synchronises
+// the two tables from W_4096^j, j <= 1024 (csrc/sot_stft_tables.inc: kWn), by all THREADS threads of the workgroup; the caller synchronises.
+// Every load of a thread is issued before the first is used (compile-time trip counts): ONE round trip to L2 -- a plain strided loop waits
+// per element, 9 serial round trips for a 256-thread workgroup (~5 us at the head of every workgroup of a short kernel).
 template <int THREADS>
 __device__ __forceinline__ void build_tables(const float2* __restrict__ w4096, v2f* tw, v2f* wn)
 {
-    for (int t = threadIdx.x; t < kTw; t += THREADS) {
+    constexpr int NT = (kTw + THREADS - 1) / THREADS, NW = (513 + THREADS - 1) / THREADS;
+    float2 a[NT], b[NW];
+    int quarter[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
         // slot t = tw_block(beta) + (mult - 1) half + q, half = 2^(beta-1): W_(4 half)^(mult q) = W_1024^e, e = mult q (256 / half) < 768;
         // W_1024^(256 a + b) = W_4096^(4 b) (-i)^a: exact quarter turns of the committed table (the values of the first form's table)
+        const int t = min((int)threadIdx.x + i * THREADS, kTw - 1);
         const int half = 1 << (31 - __builtin_clz((unsigned)(t / 3 + 2)));
         const int rem = t - 3 * (half - 2);
         const int mult = rem / half + 1, q = rem & (half - 1);
         const int e = mult * q * (256 / half);
-        const float2 w0 = w4096[4 * (e & 255)];
-        v2f w = (v2f){w0.x, w0.y};
-        const int qa = e >> 8;
-        if (qa == 1) w = mul_mi(w); else if (qa == 2) w = -w;
-        tw[t] = w;
+        quarter[i] = e >> 8;
+        a[i] = w4096[4 * (e & 255)];
     }
-    for (int k = threadIdx.x; k <= 512; k += THREADS) { const float2 w0 = w4096[2 * k]; wn[k] = (v2f){0.5f * w0.y, -0.5f * w0.x}; }   // -i W_2048^k / 2
+#pragma unroll
+    for (int i = 0; i < NW; ++i) b[i] = w4096[2 * min((int)threadIdx.x + i * THREADS, 512)];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = (int)threadIdx.x + i * THREADS;
+        v2f w = (v2f){a[i].x, a[i].y};
+        if (quarter[i] == 1) w = mul_mi(w); else if (quarter[i] == 2) w = -w;
+        if (t < kTw) tw[t] = w;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int k = (int)threadIdx.x + i * THREADS;
+        if (k <= 512) wn[k] = (v2f){0.5f * b[i].y, -0.5f * b[i].x};   // -i W_2048^k / 2
+    }
 }
 
 }  // namespace sot_wfft
