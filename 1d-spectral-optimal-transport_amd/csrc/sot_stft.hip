@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clip_ker
 //    for the batches BELOW the round-4 wave kernel's threshold (512 ... 3071 frames: the paper's 64 clips), where the slot kernel ran.
 // ---------------------------------------------------------------------------------------------
 constexpr size_t kClipwLdsBytes = ((size_t)16 * sot_wfft::kBuf + sot_wfft::kTw + sot_wfft::kWnMax) * sizeof(float2);
-constexpr int kFwdwThreads = 512, kFwdwWaves = 8;
+constexpr int kFwdwThreads = 256, kFwdwWaves = 4;   // 51.2 KB of LDS per workgroup (tables 16.4 KB + 8.7 KB per wave): three per CU; a 1088-frame launch reaches every CU
 constexpr size_t kFwdwLdsBytes = ((size_t)kFwdwWaves * sot_wfft::kBuf + sot_wfft::kTw + sot_wfft::kWnMax) * sizeof(float2);
 
 // Hermitian packing G of Zin_k = g_k X_k / |X_k| for the lane's bin pairs (k, m - k), k = 64 q + lane (q < 8) and k = m / 2 (lane 0), written to the
@@ -1295,6 +1295,14 @@ __device__ __forceinline__ void wavew_unpack_store(const sot_wfft::v2f* zl, cons
     }
 }
 
+// Diagnostic build only (-DSTFT_STAMPS; tools/r5/stft_stamps.py): wave 0 of workgroups 0 .. 63 of the wavew forward kernel stamps the shader clock
+#ifdef STFT_STAMPS
+__device__ unsigned long long g_stft_stamps[64 * 8];
+#define STFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) { __builtin_amdgcn_sched_barrier(0); g_stft_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STFT_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kFwdwThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mag_forward_wavew_kernel(const StftArgs a)
 {
     using namespace sot_wfft;
@@ -1307,8 +1315,12 @@ __global__ __launch_bounds__(kFwdwThreads) __attribute__((amdgpu_waves_per_eu(4,
     const float2* const win2 = reinterpret_cast<const float2*>(a.window);
     const unsigned total = (unsigned)(a.batch * a.frames), frames = (unsigned)a.frames;
     const unsigned stride = gridDim.x * kFwdwWaves;
+    STFT_STAMP(0);
+    // (the first frame's 32 loads issued ahead of the table build change nothing: the build then waits behind them -- tables + loads are
+    //  ~6 300 clocks of a wave's 13 000 either way, tools/r5/stft_stamps.py)
     build_tables<kFwdwThreads>(kWn, tw, wn);
     __syncthreads();
+    STFT_STAMP(1);
     const float scale = 1.0f / sqrtf((float)n);
     for (unsigned fr = blockIdx.x * kFwdwWaves + wave; fr < total; fr += stride) {
         int lane = threadIdx.x & 63;
@@ -1340,13 +1352,16 @@ __global__ __launch_bounds__(kFwdwThreads) __attribute__((amdgpu_waves_per_eu(4,
             amax = fmaxf(amax, fmaxf(fabsf(r[q].x), fabsf(r[q].y)));
         }
         const bool plain = __builtin_amdgcn_readfirstlane((int)frame_is_plain(wave_max_f32(amax))) != 0;   // one range test per FRAME
+        STFT_STAMP(2);
         forward_transform<10>(r, zl, tw, lane);
+        STFT_STAMP(3);
         write_natural<10>(r, zl, lane);
         wave_sync();
         float* const dst = a.mag + (int64_t)fr * nb;
         float2* const sp = (a.spec != nullptr && (int64_t)b >= a.spec_first) ? a.spec + ((int64_t)fr - a.spec_first * frames) * nb : nullptr;
         if (plain) wavew_unpack_store<true>(zl, wn, lane, scale, dst, sp);
         else wavew_unpack_store<false>(zl, wn, lane, scale, dst, sp);
+        STFT_STAMP(4);
         wave_sync();   // the unpack reads are issued before the next frame's exchange writes
     }
 }
@@ -1720,7 +1735,7 @@ static bool launch_forward_wavew(const StftArgs& a, int64_t frames_total, hipStr
             (void)hipGetLastError();
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
-    const int64_t want = (frames_total + kFwdwWaves - 1) / kFwdwWaves, cap = 2 * (int64_t)cu_count();   // two 512-thread workgroups per CU
+    const int64_t want = (frames_total + kFwdwWaves - 1) / kFwdwWaves, cap = 3 * (int64_t)cu_count();   // three 256-thread workgroups per CU (LDS)
     hipLaunchKernelGGL(stft_mag_forward_wavew_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(kFwdwThreads), kFwdwLdsBytes, st, a);
     return true;
 }
@@ -1749,6 +1764,14 @@ static bool launch_forward_wave(const StftArgs& a, int64_t frames_total, hipStre
 }  // namespace sot_stft
 
 extern "C" {
+
+#ifdef STFT_STAMPS
+int sot_stft_debug_read_stamps(unsigned long long* host_out, int count)   // diagnostic build only (synchronises)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sot_stft::g_stft_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int64_t sot_stft_frames(int64_t samples, int hop) { return (samples < 1 || hop < 1) ? 0 : (samples + hop - 1) / hop; }
 
