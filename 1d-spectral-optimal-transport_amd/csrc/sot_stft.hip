@@ -1161,6 +1161,14 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clip_ker
 //  * stft_mag_forward_wavew_kernel: forward (single or pair form, optional spectrum) with one wavefront per frame in 512-thread workgroups,
 //    for the batches BELOW the round-4 wave kernel's threshold (512 ... 3071 frames: the paper's 64 clips), where the slot kernel ran.
 // ---------------------------------------------------------------------------------------------
+// Diagnostic build only (-DSTFT_STAMPS; tools/r5/stft_stamps.py): wave 0 of workgroups 0 .. 63 of the wavew forward kernel (slots 0-4) and of the clipw backward kernel (slots 8-14) stamps the shader clock
+#ifdef STFT_STAMPS
+__device__ unsigned long long g_stft_stamps[64 * 16];
+#define STFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) { __builtin_amdgcn_sched_barrier(0); g_stft_stamps[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STFT_STAMP(i) do { } while (0)
+#endif
+
 constexpr size_t kClipwLdsBytes = ((size_t)16 * sot_wfft::kBuf + sot_wfft::kTw + sot_wfft::kWnMax) * sizeof(float2);
 constexpr int kFwdwThreads = 256, kFwdwWaves = 4;   // 51.2 KB of LDS per workgroup (tables 16.4 KB + 8.7 KB per wave): three per CU; a 1088-frame launch reaches every CU
 constexpr size_t kFwdwLdsBytes = ((size_t)kFwdwWaves * sot_wfft::kBuf + sot_wfft::kTw + sot_wfft::kWnMax) * sizeof(float2);
@@ -1175,13 +1183,23 @@ __device__ __forceinline__ void clipw_pack_gradient(const float2* __restrict__ s
     using namespace sot_wfft;
     constexpr int m = 1024;
     peak = 0.0f; least = INFINITY;
+    // every load of the pass first (34 per lane; bin m / 2 by all lanes: one address): ONE round trip.  Loads inside the pair loop were waited
+    // for pair by pair -- nine serial round trips, 10 000 of a wave's 29 000 clocks (tools/r5/stft_stamps.py)
+    float2 lpk[9], lpm[9];
+    float lgk[9], lgm[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int k = (q < 8) ? 64 * q + lane : m / 2;
+        lpk[q] = sp[k]; lpm[q] = sp[m - k];
+        lgk[q] = g[k]; lgm[q] = g[m - k];
+    }
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         if (q == 8 && lane != 0) break;
         const int k = (q < 8) ? 64 * q + lane : m / 2;
-        const float2 pk = sp[k], pm = sp[m - k];
+        const float2 pk = lpk[q], pm = lpm[q];
         const sot_wfft::v2f xk = (sot_wfft::v2f){pk.x, pk.y}, xm = (sot_wfft::v2f){pm.x, pm.y};
-        const float gk = g[k] * up, gm = g[m - k] * up;
+        const float gk = lgk[q] * up, gm = lgm[q] * up;
         float ck, cm;
         if (PLAIN) {
             const float ak = fmaxf(fabsf(pk.x), fabsf(pk.y)), am = fmaxf(fabsf(pm.x), fabsf(pm.y));
@@ -1215,8 +1233,10 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clipw_ke
     sot_wfft::v2f* const bufs = wn + kWnMax;                   // 16 frame buffers of kBuf points
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     sot_wfft::v2f* const zl = bufs + wave * kBuf;
+    STFT_STAMP(8);
     build_tables<kWave2Threads>(kWn, tw, wn);
     __syncthreads();
+    STFT_STAMP(9);
     const float scale = 1.0f / sqrtf((float)n);
     const float up = a.grad_scale ? *a.grad_scale : 1.0f;
     const int frames = (int)a.frames, hp = a.hop >> 1;        // hop in packed points (hop is even: host)
@@ -1237,6 +1257,7 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clipw_ke
                 clipw_pack_gradient<false>(sp, g, up, zl, wn, lane, peak, least);
             }
             wave_sync();
+            STFT_STAMP(10);
             sot_wfft::v2f r[16], wt[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) r[q] = zl[lane + 64 * brev4(q)];
@@ -1244,10 +1265,12 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clipw_ke
             for (int q = 0; q < 16; ++q) { const float2 wv = win2[64 * q + lane]; wt[q] = (sot_wfft::v2f){wv.x, wv.y}; }   // arrive during the transform
             wave_sync();
             inverse_transform<10>(r, zl, tw, lane);
+            STFT_STAMP(11);
 #pragma unroll
             for (int q = 0; q < 16; ++q) zl[64 * q + lane] = (wt[q] * r[q]) * scale;      // the windowed frame gradient, packed point 64 q + lane
         }
         __syncthreads();
+        STFT_STAMP(12);
         float* const dst = a.grad_audio + b * a.samples;
         for (int p = threadIdx.x; 2 * p < samples; p += kWave2Threads) {   // packed point p of the clip = samples 2 p, 2 p + 1
             const int f_hi = min(p / hp, frames - 1);
@@ -1269,7 +1292,9 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clipw_ke
                 dst[2 * p] = a.accumulate ? dst[2 * p] + sum.x : sum.x;
             }
         }
+        STFT_STAMP(13);
         __syncthreads();   // the frame buffers are read before the next clip overwrites them
+        STFT_STAMP(14);
     }
 }
 
@@ -1294,14 +1319,6 @@ __device__ __forceinline__ void wavew_unpack_store(const sot_wfft::v2f* zl, cons
         if (sp != nullptr) { sp[k] = make_float2(xk.x, xk.y); sp[m - k] = make_float2(xc.x, -xc.y); }
     }
 }
-
-// Diagnostic build only (-DSTFT_STAMPS; tools/r5/stft_stamps.py): wave 0 of workgroups 0 .. 63 of the wavew forward kernel stamps the shader clock
-#ifdef STFT_STAMPS
-__device__ unsigned long long g_stft_stamps[64 * 8];
-#define STFT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) { __builtin_amdgcn_sched_barrier(0); g_stft_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define STFT_STAMP(i) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(kFwdwThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mag_forward_wavew_kernel(const StftArgs a)
 {
