@@ -372,6 +372,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(MSS
 // Finish: the first workgroup turns the partial sums into the loss (per scale: fixed-order sum, mean as float32, `loss += mean` in the
 // reference's scale order, losses.py:411-424); every workgroup sums the wave spans covering its samples, scales and waves in order.
 constexpr int kFinishThreads = 256;
+constexpr int kLossLoads = 4;       // partial sums per thread, scale and pass of the loss workgroup (8: one pass for 256 clips, but 148 VGPRs for the whole kernel -- three workgroups per CU instead of four: 12.7 -> 14.2 us)
 __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArgs a)
 {
     __shared__ double red[(kFinishThreads / 64) * kMaxScales];
@@ -387,22 +388,22 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
         }
     } else if (blockIdx.x == 0) {      // (the FIRST workgroup: it is resident from the start, so the reduction runs beside the other workgroups' gathers, not behind them)
         // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves reduce by
-        // shuffles, thread 0 adds the four wave sums per scale in order.  The loads of ALL scales of a pass (4 per thread and scale) are issued
+        // shuffles, thread 0 adds the four wave sums per scale in order.  The loads of ALL scales of a pass (kLossLoads per thread and scale) are issued
         // before the first is used (a loop that waits per load: 48 serialised round trips for 256 clips).
         double acc[kMaxScales];
 #pragma unroll
         for (int s = 0; s < kMaxScales; ++s) acc[s] = 0.0;
         int longest = 0;
         for (int s = 0; s < a.n_scales; ++s) longest = max(longest, a.task_base[s + 1] - a.task_base[s]);
-        for (int i0 = 0; i0 < longest; i0 += 4 * kFinishThreads) {
-            double part[kMaxScales][4];
+        for (int i0 = 0; i0 < longest; i0 += kLossLoads * kFinishThreads) {
+            double part[kMaxScales][kLossLoads];
 #pragma unroll
             for (int s = 0; s < kMaxScales; ++s) {
                 const bool on = s < a.n_scales;               // uniform
                 const int count = on ? a.task_base[s + 1] - a.task_base[s] : 1;
                 const double* const src = a.partial_loss + (on ? a.task_base[s] : 0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kLossLoads; ++u) {
                     const int i = i0 + u * kFinishThreads + (int)threadIdx.x;
                     part[s][u] = 0.0;
                     if (on && i0 + u * kFinishThreads < count) part[s][u] = src[min(i, count - 1)];     // uniform branch
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
             for (int s = 0; s < kMaxScales; ++s) {
                 const int count = (s < a.n_scales) ? a.task_base[s + 1] - a.task_base[s] : 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[s] += (i0 + u * kFinishThreads + (int)threadIdx.x < count) ? part[s][u] : 0.0;
+                for (int u = 0; u < kLossLoads; ++u) acc[s] += (i0 + u * kFinishThreads + (int)threadIdx.x < count) ? part[s][u] : 0.0;
             }
         }
 #pragma unroll
@@ -451,14 +452,20 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
     // freshly written scratch takes ~2 us, so passes are what the gather costs).  (The fully unrolled form of this gather
     // -- 32 predicated loads, 19 KB of straight-line code -- took 10 us for 64 clips and 24 us for 256 however its loads were arranged:
     // every workgroup executes the code once, and the first workgroup of each CU fetches all of it from L2.)
-    if (threadIdx.x >= 128) return;                             // two packed points per thread: 16-byte loads
+    // two packed points per thread (16-byte loads): 128 threads per (clip, range), so each half of the workgroup takes a range of its own -- every
+    // thread works and 256 clips' 2048 ranges are 1024 workgroups: ONE round of a ~4 us gather (with one range per workgroup and half the threads idle the
+    // chip held 1280 of 2048 workgroups at a time: two rounds)
     MSS_STAMP(11);
     const int slots = a.slot_base[a.n_scales];
-    for (int64_t blk = blockIdx.x; blk < a.batch * ranges; blk += gridDim.x) {
+    const int side = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)), tid = (int)threadIdx.x & 127;
+    // (all clips: workgroup 0 is the loss reduction and nothing else -- its serial passes would otherwise sit in front of a gather)
+    const int first = a.per_clip ? 0 : 1;
+    if ((int)blockIdx.x < first) return;
+    for (int64_t blk = 2 * ((int64_t)blockIdx.x - first) + side; blk < a.batch * ranges; blk += 2 * ((int64_t)gridDim.x - first)) {
         const int b = (int)(blk / ranges), w_hi = (int)(blk - (int64_t)b * ranges);
-        const int t2 = 2 * (int)threadIdx.x;
+        const int t2 = 2 * tid;
         const int p = 256 * w_hi + t2;
-        const float4* const blk4 = reinterpret_cast<const float4*>(a.partial_grad) + (((int64_t)b * ranges + w_hi) * slots) * 128 + threadIdx.x;
+        const float4* const blk4 = reinterpret_cast<const float4*>(a.partial_grad) + (((int64_t)b * ranges + w_hi) * slots) * 128 + tid;
         float g0x = 0.0f, g0y = 0.0f, g1x = 0.0f, g1y = 0.0f;
 #pragma unroll 1
         for (int s0 = 0; s0 < slots; s0 += 16) {                 // slots in order = scales in order, pieces ascending (= waves descending)
@@ -597,8 +604,9 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves_needed + wg_waves - 1) / wg_waves)), dim3(64 * wg_waves), lds_bytes(wg_waves), st, a);
 #endif
     if (hipGetLastError() != hipSuccess) return SOT_ERR_LAUNCH;
-    const int64_t work = a.want_grad ? batch * ((((samples + 1) / 2) + 255) / 256) : 1;      // one workgroup per (clip, 256 packed points)
-    hipLaunchKernelGGL(mss_finish_kernel, dim3((unsigned)(work < 16384 ? (work < 1 ? 1 : work) : 16384)), dim3(kFinishThreads), 0, st, a);
+    const int64_t work = a.want_grad ? (batch * ((((samples + 1) / 2) + 255) / 256) + 1) / 2 : 1;      // one workgroup per TWO (clip, 256 packed points) blocks
+    const int64_t blocks = (work < 16384 ? (work < 1 ? 1 : work) : 16384) + ((a.want_grad && !per_clip) ? 1 : 0);      // + the loss workgroup
+    hipLaunchKernelGGL(mss_finish_kernel, dim3((unsigned)blocks), dim3(kFinishThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
