@@ -371,6 +371,9 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(MSS
 
 // Finish: the first workgroup turns the partial sums into the loss (per scale: fixed-order sum, mean as float32, `loss += mean` in the
 // reference's scale order, losses.py:411-424); every workgroup sums the wave spans covering its samples, scales and waves in order.
+#ifndef MSS_DIAG_NO_LOSS
+#define MSS_DIAG_NO_LOSS 0     /* diagnostic (timing only): the finish kernel without its loss reduction */
+#endif
 constexpr int kFinishThreads = 256;
 constexpr int kLossLoads = 4;       // partial sums per thread, scale and pass of the loss workgroup (8: one pass for 256 clips, but 148 VGPRs for the whole kernel -- three workgroups per CU instead of four: 12.7 -> 14.2 us)
 __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArgs a)
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
             }
             a.loss[o] = total;
         }
-    } else if (blockIdx.x == 0) {      // (the FIRST workgroup: it is resident from the start, so the reduction runs beside the other workgroups' gathers, not behind them)
+    } else if (blockIdx.x == 0 && !MSS_DIAG_NO_LOSS) {      // (the FIRST workgroup: it is resident from the start, so the reduction runs beside the other workgroups' gathers, not behind them)
         // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves reduce by
         // shuffles, thread 0 adds the four wave sums per scale in order.  The loads of ALL scales of a pass (kLossLoads per thread and scale) are issued
         // before the first is used (a loop that waits per load: 48 serialised round trips for 256 clips).
