@@ -142,6 +142,39 @@ def test_two_launches_equal_the_kernel_chain_and_are_deterministic():
     assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) <= 5e-3    # two float32 FFTs: the sign() kinks of |t - v| differ at a few bins
 
 
+def test_large_batches_take_the_sixteen_wave_workgroups_with_the_same_bits():
+    """Batches of more than one round of tasks (> 16 waves per CU: here 100 clips = 4800 tasks) run the fused kernel in 16-wave workgroups, small
+    ones in 4-wave workgroups: the same task arithmetic, so per-clip losses and gradients are bit-identical to the two halves evaluated on
+    their own; and the large launch agrees with the round-2 kernel chain like the small one does."""
+    from gpu_util import device, native
+    import sot_amd.losses as L
+    native()
+    x, y = _clips(100, 4096, 77)
+    xd = x.to(device())
+    mod = L.MSSLoss(mag_weight=1.0)
+
+    def per_clip(lo, hi):
+        yd = y[lo:hi].to(device()).requires_grad_(True)
+        v = mod(xd[lo:hi], yd, dims=(1, 2))
+        v.sum().backward()
+        return v.detach(), yd.grad
+
+    whole, halves = per_clip(0, 100), [per_clip(0, 50), per_clip(50, 100)]
+    assert torch.equal(whole[0], torch.cat([h[0] for h in halves])) and torch.equal(whole[1], torch.cat([h[1] for h in halves]))
+    res = []
+    for fused in (True, False):
+        L.MSS_FUSED = fused
+        try:
+            yd = y.to(device()).requires_grad_(True)
+            v = mod(xd, yd)
+            v.backward()
+            res.append((float(v), yd.grad.double()))
+        finally:
+            L.MSS_FUSED = True
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])
+    assert float(torch.linalg.norm(res[0][1] - res[1][1]) / torch.linalg.norm(res[1][1])) <= 5e-3    # (the sign() kinks of |t - v|, as above)
+
+
 def test_strided_rows_no_grad_and_upstream_gradient():
     from gpu_util import device, native
     from sot_amd.losses import MSSLoss
