@@ -312,6 +312,44 @@ def test_paper_loss_block_on_gpu_matches_reference():
 
 
 @pytest.mark.gpu
+def test_paper_loss_block_at_the_papers_batch():
+    """The block at the paper's batch -- 64 clips of 4096 samples: 3072 MSS tasks (exactly one round of the fused kernel's 4-wave workgroups),
+    1024-frame STFT launches (the wavefront-FFT forward), the one-workgroup-per-clip STFT backward, the SOT training form on 1024 x 1025
+    rows with fresh positions -- against the same function on CPU tensors (the torch-op route that test_paper_loss_block_on_cpu pins to the
+    reference).  MSS term to 1e-5, total to the audio-in chain's 2e-5, gradient by direction and peak error like the fixture test."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    native()
+    g = torch.Generator().manual_seed(64)
+    t = torch.arange(4096) / 16000.0
+    f0 = 80 + 600 * torch.rand(64, 1, generator=g)
+    ax = sum((0.5 / k) * torch.sin(2 * np.pi * k * f0 * t + k) for k in range(1, 8)) + 0.02 * torch.randn(64, 4096, generator=g)
+    f1 = f0 * (1 + 0.03 * torch.randn(64, 1, generator=g))
+    ay = sum((0.45 / k) * torch.sin(2 * np.pi * k * f1 * t + 0.2 * k) for k in range(1, 8)) + 0.02 * torch.randn(64, 4096, generator=g)
+    ax, ay = ax.float(), ay.float()
+    ref_y = ay.clone().requires_grad_(True)
+    mix_cpu = _paper_mix()
+    want = spectra.trainer_loss_step(mix_cpu, ax, ref_y)
+    want.backward()
+    with torch.no_grad():
+        want_mss = 0.05 * float(mix_cpu.losses[0](ax, ay))
+    dev = device()
+    mix = _paper_mix().to(dev)
+    got_y = ay.to(dev).requires_grad_(True)
+    got = spectra.trainer_loss_step(mix, ax.to(dev), got_y)
+    got.backward()
+    with torch.no_grad():
+        got_mss = 0.05 * float(mix.losses[0](ax.to(dev), ay.to(dev)))
+    print(f"paper loss block, 64 clips: total {float(got):.9g} (CPU route {float(want):.9g}), MSS term rel err {abs(got_mss - want_mss) / want_mss:.2e}")
+    assert abs(got_mss - want_mss) <= 1e-5 * want_mss
+    assert abs(float(got) - float(want)) <= 2e-5 * abs(float(want))      # observed 7.4e-7
+    a, b = got_y.grad.cpu().double().numpy(), ref_y.grad.double().numpy()
+    cos = float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    print(f"    audio gradient: cosine {cos:.6f}, max err / peak {np.abs(a - b).max() / np.abs(b).max():.2e}")
+    assert cos >= 0.9999 and np.abs(a - b).max() <= 5e-3 * np.abs(b).max()    # observed 1.000000 / 1.0e-3 (single rows of the cutoff's lottery + L1 sign kinks)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", list(MSS_CASES))
 def test_mssloss_hip_matches_reference(tag):
     """GPU tensors: STFT + spectral-distance HIP kernels behind one autograd node; scalar ≤ 1e-5 of the reference's.  The
