@@ -14,7 +14,7 @@ SRC = os.path.join(PKG_DIR, "csrc", "sot_hip.hip")
 STFT_SRC = os.path.join(PKG_DIR, "csrc", "sot_stft.hip")   # the STFT-magnitude producer: its own translation unit
 OSC_SRC = os.path.join(PKG_DIR, "csrc", "sot_osc.hip")     # the oscillator bank
 MSS_SRC = os.path.join(PKG_DIR, "csrc", "sot_mss.hip")     # MSSLoss with its gradient in two launches (round 5)
-DEPS = [SRC, STFT_SRC, OSC_SRC, MSS_SRC, os.path.join(PKG_DIR, "csrc", "sot_stft_tables.inc"), os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_wave_fft.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
+DEPS = [SRC, STFT_SRC, OSC_SRC, MSS_SRC, os.path.join(PKG_DIR, "csrc", "sot_stft_tables.inc"), os.path.join(PKG_DIR, "csrc", "sot_device.hpp"), os.path.join(PKG_DIR, "csrc", "sot_wave_sort.hpp"), os.path.join(PKG_DIR, "csrc", "sot_wave_fft.hpp"), os.path.join(PKG_DIR, "csrc", "sot_forward_full.inc"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "sot_hip.h")]
 LIB = os.path.join(PKG_DIR, "libsot_hip.so")
 

@@ -19,6 +19,7 @@
 
 #include "../../include/sot_hip.h"
 #include "sot_device.hpp"
+#include "sot_wave_sort.hpp"
 
 // The file can be compiled whole (default) or in parts that are linked into one library, so that the many
 // kernel instantiations build in parallel (build.py): bit 0 forward/shared positions, bit 1 forward/per-row
@@ -31,6 +32,9 @@
 #endif
 // Timing-only ablation builds (tools/ablate.py; results are WRONG on purpose): bit 0 no merge walk, bit 1 no partition
 // search, bit 2 no row mass, bit 3 no division, bit 4 no CDF scan.  Never defined in the product build.
+#ifndef SOT_WAVE_SORT
+#define SOT_WAVE_SORT 1   /* 0: the in-LDS merge sort of round 4 everywhere (A/B switch) */
+#endif
 #ifndef SOT_ABLATE
 #define SOT_ABLATE 0
 #endif
@@ -1805,6 +1809,116 @@ __global__ __launch_bounds__(1024) void sot_segmented_sort_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same sort, ONE WAVEFRONT per row (round 6; rows of <= 2048 keys): sot_wave_sort.hpp -- a payload-free network on one 32-bit
+// word per key in registers, no workgroup barrier; a row the fast path declines (clustered / non-finite keys) is sorted by the same
+// wavefront with the merge sort.  Four independent rows per 256-thread workgroup; the next row's keys are fetched while the
+// current one is stored.  FAST: n == 64 KPL, rows and outputs 16-byte aligned -- no validity tests, 16-byte loads and stores.
+// ---------------------------------------------------------------------------------------------
+template <int KPL>
+__host__ __device__ constexpr int wave_sort_row_cap()   // LDS dwords of ONE of the two arrays of a row (key | idx): fits either sort
+{
+    return align4(imax(sort16_capacity(sort16_npad(64 * KPL)), wave_sort_scratch(KPL)));
+}
+
+template <int KPL, bool FAST>
+__global__ __launch_bounds__(256, 2) void sot_segmented_sort_wave_kernel(const float* __restrict__ keys, int64_t B, int n, int64_t stride,
+                                                                         float* __restrict__ out_keys, int64_t* __restrict__ out_idx)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NPAD = 64 * KPL, CAP = wave_sort_row_cap<KPL>();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* key = smem + wv * 2 * CAP;
+    uint32_t* idx = reinterpret_cast<uint32_t*>(key + CAP);
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    float x[KPL];
+    auto fetch = [&](int64_t rw) {
+        const float* src = keys + rw * stride;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int r = 0; r < KPL; r += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + wsort_elem<true>(r, lane));
+                x[r] = v.x; x[r + 1] = v.y; x[r + 2] = v.z; x[r + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) { const int e = r * 64 + lane; const float v = src[min(e, n - 1)]; x[r] = (e < n) ? v : INFINITY; }
+        }
+    };
+    if (row < B) fetch(row);
+    for (; row < B; row += step) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int r = 0; r < KPL; r += 4) *reinterpret_cast<float4*>(key + wsort_elem<true>(r, lane)) = make_float4(x[r], x[r + 1], x[r + 2], x[r + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) key[r * 64 + lane] = x[r];
+        }
+        row_sync<1>();
+        float sk[KPL]; uint32_t si[KPL];
+        const bool fast = wave_sort_kv<KPL, false, FAST, FAST>(x, key, idx, n, lane, sk, si);
+        if (!fast) {   // clustered / non-finite keys: the merge sort, by this wavefront alone (nothing of the fast path is live across it)
+            constexpr int MAXB = (NPAD / 16 + 63) / 64;
+            const SortJob job{key, reinterpret_cast<int*>(idx), n, sort16_npad(n)}, none{nullptr, nullptr, 0, 0};
+            row_sync<1>();
+            merge_sort16_kv2<MAXB>(job, none, lane, 64, [] { row_sync<1>(); });
+            row_sync<1>();
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) { sk[r] = key[wsort_elem<FAST>(r, lane)]; si[r] = idx[wsort_elem<FAST>(r, lane)]; }
+        }
+        if (row + step < B) fetch(row + step);   // the next row's keys travel while this one is stored
+        if constexpr (FAST) {
+            float* ok_row = out_keys ? out_keys + row * (int64_t)n : nullptr;
+            int64_t* oi_row = out_idx ? out_idx + row * (int64_t)n : nullptr;
+#pragma unroll
+            for (int r = 0; r < KPL; r += 4) {
+                const int e = wsort_elem<true>(r, lane);
+                if (ok_row) *reinterpret_cast<float4*>(ok_row + e) = make_float4(sk[r], sk[r + 1], sk[r + 2], sk[r + 3]);
+                if (oi_row) {   // (NaN keys: a pad's index never leaves the kernel)
+                    typedef long long ll2 __attribute__((ext_vector_type(2)));
+                    ll2 a, b;
+                    a.x = min((int)si[r], n - 1); a.y = min((int)si[r + 1], n - 1); b.x = min((int)si[r + 2], n - 1); b.y = min((int)si[r + 3], n - 1);
+                    *reinterpret_cast<ll2*>(oi_row + e) = a;
+                    *reinterpret_cast<ll2*>(oi_row + e + 2) = b;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) {
+                const int e = r * 64 + lane;
+                if (e < n) {
+                    if (out_keys) out_keys[row * (int64_t)n + e] = sk[r];
+                    if (out_idx) out_idx[row * (int64_t)n + e] = (int64_t)min((int)si[r], n - 1);
+                }
+            }
+        }
+        row_sync<1>();
+    }
+}
+
+template <int KPL>
+int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stride, float* out_keys, int64_t* out_idx, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)wave_sort_row_cap<KPL>() * 8 * 4;   // 4 waves x (key | idx)
+    constexpr bool CAN_VEC = KPL % 4 == 0;
+    const bool fast = CAN_VEC && n == 64 * KPL && stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(out_keys) |
+                                                                     reinterpret_cast<uintptr_t>(out_idx)) & 15) == 0;
+    static GridCache cache[2];
+    const void* fn = fast ? reinterpret_cast<const void*>(sot_segmented_sort_wave_kernel<KPL, CAN_VEC>)
+                          : reinterpret_cast<const void*>(sot_segmented_sort_wave_kernel<KPL, false>);
+    allow_full_lds_once(cache[fast ? 1 : 0], fn);
+    int per_cu = (int)(kLdsLimit / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t groups = (B + 3) / 4, cap = (int64_t)device_cu_count() * per_cu;
+    const int grid = (int)(groups < cap ? groups : cap);
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
+    if (fast) hipLaunchKernelGGL((sot_segmented_sort_wave_kernel<KPL, CAN_VEC>), dim3(grid), dim3(256), lds, s, keys, B, n, stride, out_keys, out_idx);
+    else hipLaunchKernelGGL((sot_segmented_sort_wave_kernel<KPL, false>), dim3(grid), dim3(256), lds, s, keys, B, n, stride, out_keys, out_idx);
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                           hipStream_t s)
 {
@@ -2197,6 +2311,13 @@ int sot_segmented_sort(const float* keys, int64_t B, int32_t n, int64_t row_stri
     if (B < 0 || n < 1 || row_stride < n) return SOT_ERR_BAD_SHAPE;
     if (B == 0) return SOT_OK;
     if (keys == nullptr) return SOT_ERR_NULL_POINTER;
+    if (SOT_WAVE_SORT && n <= 2048) {   // one wavefront per row (round 6)
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (n <= 128) return sot::launch_segmented_sort_wave<2>(keys, B, (int)n, row_stride, sorted_keys, indices, st);
+        if (n <= 512) return sot::launch_segmented_sort_wave<8>(keys, B, (int)n, row_stride, sorted_keys, indices, st);
+        if (n <= 1024) return sot::launch_segmented_sort_wave<16>(keys, B, (int)n, row_stride, sorted_keys, indices, st);
+        return sot::launch_segmented_sort_wave<32>(keys, B, (int)n, row_stride, sorted_keys, indices, st);
+    }
     const int npad = sot::sort16_npad((int)n);
     if (npad > 16 * 1024) return SOT_ERR_UNSUPPORTED_SIZE;   // one block of 16 elements per thread
     const size_t lds = (size_t)((sot::sort16_capacity(npad) + 3) & ~3) * 8;

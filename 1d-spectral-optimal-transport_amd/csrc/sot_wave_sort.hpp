@@ -1,0 +1,285 @@
+// sot_wave_sort.hpp -- ONE wavefront sorts a whole array of up to 64 KPL keys in its registers (round 6; gfx950, wave64).
+//
+// torch.sort(positions, 1) of losses.py:286-290 with the indices bit-exact, on a structurally cheaper footing than the in-LDS merge
+// sort of sot_device.hpp (merge_sort16_kv2: ~170 lane instructions per key, every compare-exchange on a 64-bit (key, index) pair,
+// seven barrier-separated merge rounds):
+//
+//  * every key becomes ONE 32-bit word -- a row-adaptive, MONOTONE quantisation q = trunc((x - min) C / (max - min)) in the high
+//    32 - IDXBITS bits, the element's index in the low IDXBITS = 6 + log2(KPL) bits -- so ordering the words orders (q, index) and a
+//    compare-exchange is v_min_u32 + v_max_u32, no payload.  (Quantising the RANGE of the row, not the float's bit pattern: the
+//    order bits of a float spend 9 of their top 21 bits on sign and exponent, which would put ~128 colliding pairs into a row of
+//    2048 uniform positions; 2^21 equal bins over [min, max] leave ~1.)
+//  * a bitonic network in "flip" form (every exchange ascending) on the blocked layout position = lane KPL + register: exchanges
+//    between registers are two full-rate VALU instructions per pair; exchanges between lanes are ONE cross-lane move (DPP quad_perm /
+//    row_mirror / row_half_mirror, ds_swizzle, one ds_bpermute: the source is lane ^ m) plus ONE v_med3_u32 against a per-lane bound
+//    (0 keeps the minimum, ~0 the maximum).  No barrier, no bisection, no LDS traffic but the swizzles: 45 + 21 VALU + 21 moves per
+//    key for 2048 keys (KPL = 32).
+//  * the words leave the registers through a skewed LDS image (position p at p + p / 32: both the blocked store and the striped
+//    load are bank-conflict-free with immediate offsets) so that everything after it addresses position r 64 + lane;
+//  * EXACTNESS: neighbours that share q (x ^ y < 2^IDXBITS, x != y) form a run; the lane whose block holds the run's first position
+//    insertion-sorts it in LDS by the full key (strict ">": stable, the network left the run in index order).  A run longer than
+//    kWaveSortRunLimit, NaN / infinite keys or a degenerate range make the function return false with key[] untouched: the caller
+//    takes the merge sort (clustered positions pay the old price, nothing else changes).
+//
+// tests/wave_sort_model.py is the lane-by-lane CPU model of this file (network, bounds, skewed image, run repair).
+#pragma once
+#include "sot_device.hpp"
+
+#ifndef SOT_WSORT_DPP
+#define SOT_WSORT_DPP 1   /* 1: lane ^ 1, 2, 3, 7, 15 by DPP (VALU moves); 0: every move through the LDS crossbar (ds_swizzle) */
+#endif
+
+namespace sot {
+
+constexpr int kWaveSortRunLimit = 8;
+
+__host__ __device__ constexpr int wsort_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+// LDS dwords the index / scratch array of a wave sort needs (the key array needs 64 KPL)
+__host__ __device__ constexpr int wave_sort_scratch(int kpl) { return 64 * kpl + 2 * kpl + 2; }
+
+// value of lane ^ M
+template <int M>
+__device__ __forceinline__ uint32_t wsort_lane_xor(uint32_t v, uint32_t addr63)
+{
+    (void)addr63;
+    if constexpr (SOT_WSORT_DPP && M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (SOT_WSORT_DPP && M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (SOT_WSORT_DPP && M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    else if constexpr (SOT_WSORT_DPP && M == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (SOT_WSORT_DPP && M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); // row_mirror
+    else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (M << 10));                    // bit-mask mode: lane ^ M within 32
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr63, (int)v);                                               // M == 63: addr63 = 4 (lane ^ 63)
+}
+
+// v_med3_u32 (the backend matches this shape; inline asm would make the hazard recogniser pad every DPP move behind it with s_nop)
+__device__ __forceinline__ uint32_t wsort_med3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));
+}
+
+// half cleaners between registers at distances J, J / 2, ..., 1
+template <int KPL, int J>
+__device__ __forceinline__ void wsort_reg_tail(uint32_t (&w)[KPL])
+{
+    if constexpr (J >= 1) {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            if ((r & J) == 0) {
+                const uint32_t lo = min(w[r], w[r | J]), hi = max(w[r], w[r | J]);
+                w[r] = lo; w[r | J] = hi;
+            }
+        }
+        wsort_reg_tail<KPL, J / 2>(w);
+    }
+}
+
+// merges inside one lane's registers: runs of K / 2 -> K, K = 2 ... KPL
+template <int KPL, int K>
+__device__ __forceinline__ void wsort_reg_merges(uint32_t (&w)[KPL])
+{
+    if constexpr (K <= KPL) {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int q = r ^ (K - 1);
+            if (r < q) {
+                const uint32_t lo = min(w[r], w[q]), hi = max(w[r], w[q]);
+                w[r] = lo; w[q] = hi;
+            }
+        }
+        wsort_reg_tail<KPL, K / 4>(w);
+        wsort_reg_merges<KPL, 2 * K>(w);
+    }
+}
+
+// half cleaners between lanes at distances D, D / 2, ..., 1
+template <int KPL, int D>
+__device__ __forceinline__ void wsort_lane_tail(uint32_t (&w)[KPL], int lane, uint32_t addr63)
+{
+    if constexpr (D >= 1) {
+        const uint32_t bound = (lane & D) ? 0xFFFFFFFFu : 0u;
+        uint32_t t[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) t[r] = wsort_lane_xor<D>(w[r], addr63);
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) w[r] = wsort_med3(w[r], t[r], bound);
+        wsort_lane_tail<KPL, D / 2>(w, lane, addr63);
+    }
+}
+
+// merges across lanes: runs of (S / 2) KPL -> S KPL, S = 2 ... 64
+template <int KPL, int S>
+__device__ __forceinline__ void wsort_lane_merges(uint32_t (&w)[KPL], int lane, uint32_t addr63)
+{
+    if constexpr (S <= 64) {
+        const uint32_t bound = (lane & (S / 2)) ? 0xFFFFFFFFu : 0u;
+        uint32_t t[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) t[r] = wsort_lane_xor<S - 1>(w[KPL - 1 - r], addr63);   // flip: partner (lane ^ (S - 1), KPL - 1 - r)
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) w[r] = wsort_med3(w[r], t[r], bound);
+        wsort_lane_tail<KPL, S / 4>(w, lane, addr63);
+        wsort_reg_tail<KPL, KPL / 2>(w);
+        wsort_lane_merges<KPL, 2 * S>(w, lane, addr63);
+    }
+}
+
+// the whole network: w[r] of lane l is position l KPL + r afterwards
+template <int KPL>
+__device__ __forceinline__ void wsort_network(uint32_t (&w)[KPL], int lane)
+{
+    const uint32_t addr63 = (uint32_t)(lane ^ 63) << 2;
+    wsort_reg_merges<KPL, 2>(w);
+    wsort_lane_merges<KPL, 2>(w, lane, addr63);
+}
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float wsort_dpp_keep(float v)   // the DPP source lane's value; a lane without one reads its own
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wsort_wave_min(float v)
+{
+    v = fminf(v, wsort_dpp_keep<kRowShr1>(v)); v = fminf(v, wsort_dpp_keep<kRowShr2>(v));
+    v = fminf(v, wsort_dpp_keep<kRowShr4>(v)); v = fminf(v, wsort_dpp_keep<kRowShr8>(v));
+    v = fminf(v, wsort_dpp_keep<kRowBcast15, 0xA>(v)); v = fminf(v, wsort_dpp_keep<kRowBcast31, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wsort_wave_max(float v)
+{
+    v = fmaxf(v, wsort_dpp_keep<kRowShr1>(v)); v = fmaxf(v, wsort_dpp_keep<kRowShr2>(v));
+    v = fmaxf(v, wsort_dpp_keep<kRowShr4>(v)); v = fmaxf(v, wsort_dpp_keep<kRowShr8>(v));
+    v = fmaxf(v, wsort_dpp_keep<kRowBcast15, 0xA>(v)); v = fmaxf(v, wsort_dpp_keep<kRowBcast31, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register <-> element maps.  VEC = false: register r of lane l is element (position) r 64 + l.  VEC = true (KPL % 4 == 0): element
+// (r / 4) 256 + 4 l + r % 4 -- four consecutive elements per lane, i.e. 16-byte loads / stores in global memory and LDS.
+// ---------------------------------------------------------------------------------------------
+template <bool VEC>
+__device__ __forceinline__ int wsort_elem(int r, int lane) { return VEC ? ((r >> 2) << 8) + 4 * lane + (r & 3) : r * 64 + lane; }
+
+// ---------------------------------------------------------------------------------------------
+// x[r]: the key of element wsort_elem<VEC>(r, lane) (any value for e >= n); key[0 .. 64 KPL): the same keys in LDS in natural order
+// with +inf behind the n real ones; idx: LDS scratch of wave_sort_scratch(KPL) dwords.  All 64 lanes of ONE wavefront call it; nobody
+// else touches key / idx meanwhile.  FULL: n == 64 KPL is known at compile time (no validity tests).  Returns (wave-uniform) true:
+// ok[r] / oi[r] are the sorted key and its original index at position wsort_elem<VEC>(r, lane) (pads: +inf / 64 KPL - 1) and, with
+// STORE_LDS, key[] / idx[] hold the same in natural order on [0, 64 KPL); false: declined, key[] is untouched (idx[] is not).
+// ---------------------------------------------------------------------------------------------
+template <int KPL, bool STORE_LDS = true, bool FULL = false, bool VEC = false>
+__device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
+{
+    static_assert(!VEC || KPL % 4 == 0, "VEC needs four registers per 16-byte group");
+    constexpr int NPAD = 64 * KPL, IDXBITS = 6 + wsort_ilog2(KPL), QBITS = 32 - IDXBITS;
+    constexpr uint32_t QMAX = (1u << QBITS) - 1u, MASK = (1u << IDXBITS) - 1u;
+    // ---- pre-pass: range of the real keys; NaN / infinite keys decline (0 x = NaN for both)
+    float mn = INFINITY, mx = -INFINITY, det = 0.0f;
+    const bool full = FULL || (n == NPAD);    // wave-uniform: no pads, no validity tests
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) { mn = fminf(mn, x[r]); mx = fmaxf(mx, x[r]); det = fmaf(x[r], 0.0f, det); }
+    } else {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const bool real = wsort_elem<VEC>(r, lane) < n;
+            mn = fminf(mn, real ? x[r] : INFINITY); mx = fmaxf(mx, real ? x[r] : -INFINITY); det = fmaf(real ? x[r] : 0.0f, 0.0f, det);
+        }
+    }
+    mn = wsort_wave_min(mn); mx = wsort_wave_max(mx);
+    const float range = mx - mn;
+    const float scale = (float)(QMAX - 8u) / range;
+    const bool bad = __builtin_amdgcn_ballot_w64(det != det) != 0ull;
+    if (bad || !(range > 0.0f) || !(range < INFINITY) || !(scale < INFINITY)) return false;
+    // ---- one word per key: (q << IDXBITS) + element, in two shift-adds with inline constants
+    uint32_t w[KPL];
+    uint32_t low[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) low[c] = VEC ? (uint32_t)(4 * lane + c) : (uint32_t)lane;
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const uint32_t q = (uint32_t)((x[r] - mn) * scale);
+        const uint32_t word = VEC ? (((q << (IDXBITS - 8)) + (uint32_t)(r >> 2)) << 8) + low[r & 3]
+                                  : (((q << (IDXBITS - 6)) + (uint32_t)r) << 6) + low[0];
+        w[r] = (full || wsort_elem<VEC>(r, lane) < n) ? word : 0xFFFFFFFFu;   // every pad is the same word: behind the data, never a run
+    }
+    wsort_network<KPL>(w, lane);
+    // ---- neighbours that share q: (a ^ b) - 1 < MASK (a == b: two pads)
+    uint32_t cmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r + 1 < KPL; ++r) cmin = min(cmin, (w[r] ^ w[r + 1]) - 1u);
+    // the first word of the next lane (lane 63 reads its own last word: xor 0, no collision)
+    const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp((int)w[KPL - 1], (int)w[0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    cmin = min(cmin, (w[KPL - 1] ^ nxt) - 1u);
+    const bool any_run = __builtin_amdgcn_ballot_w64(cmin < MASK) != 0ull;
+    uint32_t cm = 0;                           // bit r: positions lane KPL + r and + r + 1 share q (only built when the wave has a run)
+    if (any_run) {
+#pragma unroll
+        for (int r = 0; r + 1 < KPL; ++r) cm |= (((w[r] ^ w[r + 1]) - 1u) < MASK) ? (1u << r) : 0u;
+        cm |= (((w[KPL - 1] ^ nxt) - 1u) < MASK) ? (1u << (KPL - 1)) : 0u;
+    }
+    // ---- blocked -> striped through the skewed image: position p lives at p + p / 32
+    const uint32_t sbase = lds_addr(idx);
+    {
+        const uint32_t p0 = (uint32_t)(lane * KPL);
+        const uint32_t wa = sbase + 4u * (p0 + (p0 >> 5));          // KPL <= 32: p0 + r never crosses a multiple of 32 inside one lane's block
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) lds_st_u32(wa + 4u * r, w[r]);
+    }
+    row_sync<1>();
+    if (any_run) {
+        // the exact order inside runs of equal q, in LDS on the skewed image: the lane whose block holds a run's first position sorts it
+        bool over = false;
+        auto W = [&](int p) -> uint32_t& { return idx[p + (p >> 5)]; };
+        while (cm != 0u) {
+            const int r = __builtin_ctz(cm);
+            const int p = lane * KPL + r;
+            const uint32_t wp = W(p);
+            const bool start = (p == 0) || !(((W(max(p - 1, 0)) ^ wp) - 1u) < MASK);
+            int e = p + 1;
+            while (e + 1 < NPAD && e - p < kWaveSortRunLimit && (((W(e + 1) ^ wp) - 1u) < MASK)) ++e;
+            const int len = e - p + 1;
+            if (start) {
+                if (len > kWaveSortRunLimit) {
+                    over = true;
+                } else {
+                    for (int i = 1; i < len; ++i) {        // insertion sort, strict ">": stable
+                        const uint32_t wi = W(p + i);
+                        const uint32_t ki = float_order_bits(key[wi & MASK]);
+                        int j = i;
+                        while (j > 0) {
+                            const uint32_t wj = W(p + j - 1);
+                            if (float_order_bits(key[wj & MASK]) > ki) { W(p + j) = wj; --j; } else break;
+                        }
+                        W(p + j) = wi;
+                    }
+                }
+            }
+            cm &= ~(((1u << (len - 1)) - 1u) << r);          // the pairs of this run inside this lane's block are done (len - 1 <= 8)
+        }
+        row_sync<1>();
+        if (__builtin_amdgcn_ballot_w64(over) != 0ull) return false;
+    }
+    // position p = wsort_elem<VEC>(r, lane) at p + p / 32: one base per lane, immediate offsets, every 32-lane half on 32 banks
+    const uint32_t ra = sbase + 4u * (uint32_t)(VEC ? 4 * lane + (lane >> 3) : lane + (lane >> 5));
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) w[r] = lds_ld_u32(ra + 4u * (uint32_t)(VEC ? 264 * (r >> 2) + (r & 3) : 66 * r));
+    // ---- indices and sorted keys (every gather is issued before the first store: one wave, in-order LDS)
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) { oi[r] = w[r] & MASK; ok[r] = key[oi[r]]; }
+    if constexpr (STORE_LDS) {
+        row_sync<1>();
+        if constexpr (VEC) {
+#pragma unroll
+            for (int r = 0; r < KPL; r += 4) {
+                *reinterpret_cast<float4*>(key + wsort_elem<true>(r, lane)) = make_float4(ok[r], ok[r + 1], ok[r + 2], ok[r + 3]);
+                *reinterpret_cast<uint4*>(idx + wsort_elem<true>(r, lane)) = make_uint4(oi[r], oi[r + 1], oi[r + 2], oi[r + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < KPL; ++r) { key[r * 64 + lane] = ok[r]; idx[r * 64 + lane] = oi[r]; }
+        }
+    }
+    return true;
+}
+
+}  // namespace sot
