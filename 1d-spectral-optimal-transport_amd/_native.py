@@ -391,6 +391,14 @@ def _want_tail(fused_mean):
     return FUSED_MEAN if fused_mean is None else bool(fused_mean)
 
 
+def _needs_workspace(pr: SotProblem, flags, plan) -> bool:
+    """Shared positions that still have to be planned; or per-row positions nobody has sorted (no row_perm_in / row_perm_out): the
+    library's pre-sort kernel leaves the rows' permutations in the workspace (optional there -- without it the row kernel sorts in LDS)."""
+    if not (flags & FLAG_REQUIRE_SORT) or plan is not None:
+        return False
+    return pr.xpos_row_stride == 0 or (not pr.row_perm_in and not pr.row_perm_out)
+
+
 def workspace(pr: SotProblem, device) -> torch.Tensor:
     nbytes = load().sot_workspace_bytes(ctypes.byref(pr))
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
@@ -404,7 +412,7 @@ def forward_rows(x, y, xpos, ypos, p, flags, plan=None, out=None, perm_out=None,
     B = x.shape[0]
     row_loss = out if out is not None else torch.empty(B, dtype=torch.float32, device=dev)
     pr = make_problem(x, y, xpos, ypos, p, flags, plan, perm_out, perm_in)
-    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    need_ws = _needs_workspace(pr, flags, plan)
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
         rc = lib.sot_w1d_forward(ctypes.byref(pr), row_loss.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0,
@@ -425,7 +433,7 @@ def loss_fused(x, y, xpos, ypos, p, flags, plan=None, denom=None, hinge=None, wa
     mean = mean_out if mean_out is not None else torch.empty((), dtype=torch.float32, device=dev)
     total = sum_out if sum_out is not None else (torch.empty((), dtype=torch.float64, device=dev) if want_sum else None)
     pr = make_problem(x, y, xpos, ypos, p, flags, plan)
-    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    need_ws = _needs_workspace(pr, flags, plan)
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
         rc = lib.sot_w1d_loss(ctypes.byref(pr), row_loss.data_ptr(), float(B if denom is None else denom),
@@ -472,7 +480,7 @@ def loss_and_grad(x, y, xpos, ypos, p, flags, plan=None, fused_mean=None):
     mean = torch.empty((), dtype=torch.float32, device=dev)
     gy = torch.empty(B, m, dtype=torch.float32, device=dev)
     pr = make_problem(x, y, xpos, ypos, p, flags, plan)
-    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    need_ws = _needs_workspace(pr, flags, plan)
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
         rc = lib.sot_w1d_loss_and_grad(ctypes.byref(pr), row_loss.data_ptr(), float(B), mean.data_ptr(), None, 1.0 / B, gy.data_ptr(),
@@ -528,7 +536,7 @@ def backward_rows(x, y, xpos, ypos, p, flags, grad_row, need_gx=True, need_gy=Tr
     gx = torch.empty(B, n, dtype=torch.float32, device=dev) if need_gx else None
     gy = torch.empty(B, m, dtype=torch.float32, device=dev) if need_gy else None
     pr = make_problem(x, y, xpos, ypos, p, flags, plan, perm_in=perm_in)
-    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    need_ws = _needs_workspace(pr, flags, plan)
     ws = workspace(pr, dev) if need_ws else None
     g = grad_row.contiguous()
     stride = 0 if g.numel() == 1 else 1
@@ -551,7 +559,7 @@ def position_grads(x, y, xpos, ypos, p, flags, grad_row, need_x=True, need_y=Tru
     gxp = torch.empty(B, n, dtype=torch.float32, device=dev) if need_x else None
     gyp = torch.empty(B, m, dtype=torch.float32, device=dev) if need_y else None
     pr = make_problem(x, y, xpos, ypos, p, flags, plan, perm_in=perm_in)
-    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    need_ws = _needs_workspace(pr, flags, plan)
     ws = workspace(pr, dev) if need_ws else None
     g = grad_row.contiguous()
     stride = 0 if g.numel() == 1 else 1
@@ -584,7 +592,7 @@ def quantiles(x, y, xpos, ypos, p, flags, plan=None):
     U = torch.empty(B, n, dtype=torch.float32, device=dev)
     V = torch.empty(B, m, dtype=torch.float32, device=dev)
     pr = make_problem(x, y, xpos, ypos, p, flags, plan)
-    need_ws = (flags & FLAG_REQUIRE_SORT) and plan is None and (xpos.ndim == 1)
+    need_ws = _needs_workspace(pr, flags, plan)
     ws = workspace(pr, dev) if need_ws else None
     with _on_device(dev):
         rc = lib.sot_w1d_quantiles(ctypes.byref(pr), uq.data_ptr(), vq.data_ptr(), Q.data_ptr(), U.data_ptr(),

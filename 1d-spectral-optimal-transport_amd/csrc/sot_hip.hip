@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/sot_hip.h"
 #include "sot_device.hpp"
@@ -289,7 +290,12 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
                                                int (&ix)[CPT], int (&iy)[CPT], const uint16_t* perm_in = nullptr, uint16_t* perm_out = nullptr)
 {
     const int n = c.n, m = c.m, t = c.t;
-    if (perm_in != nullptr && c.do_sort) {            // workgroup-uniform
+    // A handed-over row whose first two entries are equal carries the pre-sort's SENTINEL (sot_rowpos_sort_kernel: both arrays arrived sorted,
+    // or the wave sort declined one): the row is then processed as if nothing had been handed over.  Row groups that share workgroup
+    // barriers decide together (any sentinel in the workgroup: all of its rows take the self-contained path, which is always correct).
+    bool gather = perm_in != nullptr && c.do_sort;
+    if (gather && nmax >= 2) gather = !row_any<G / kWave>(perm_in[0] == perm_in[1]);
+    if (gather) {            // uniform over the threads that share barriers
         float gx[CPT], gy[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
@@ -1162,6 +1168,9 @@ static inline int validate(const sot_problem* pr)
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout { size_t sx, sy, px, py, ident, total; };
+// the permutation image of a per-row-position call (setup_launch: the pre-sort kernel's output when the caller passes no row_perm_out)
+static inline size_t rowpos_perm_bytes(int64_t B, int n, int m) { return align_up((size_t)B * ((size_t)n + (size_t)m) * sizeof(uint16_t), 256); }
+
 static inline WsLayout ws_layout(int n, int m)
 {
     WsLayout w;
@@ -1919,6 +1928,134 @@ int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stri
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-row positions, sorted AHEAD of the row kernels (round 6): one wavefront per row sorts the row's two position arrays with the wave
+// sort (sot_wave_sort.hpp) and leaves their permutations in the [B, n + m] uint16 image the row kernels gather through (row_perm_in).
+// Inside the row kernels the same network cost their other phases the registers (loop invariants spilled on paths that never sort:
+// sorted rows 71 -> 90 us, backward 276 -> 348 us at 4096 x 2048, measured inlined and as a call); a kernel of its own has its own
+// allocation, every wavefront of it sorts, and it needs 8.5 KB of LDS per wavefront (the transposition image; the run repair reads the
+// full keys from global memory).
+// A row whose arrays are BOTH already sorted, or one of whose arrays the wave sort declines (clustered / non-finite positions), gets the
+// SENTINEL perm[row][0] == perm[row][1] == 0xFFFF: the row kernel then treats the row as if no permutation had been handed over
+// (sortedness test, in-LDS merge sort) -- and, when the image is the caller's row_perm_out, stores the real permutations over it.
+// ---------------------------------------------------------------------------------------------
+constexpr uint16_t kRowPermSentinel = 0xFFFFu;
+#ifndef SOT_ROWPOS_SORT_WAVES
+#define SOT_ROWPOS_SORT_WAVES 4   /* wavefronts per SIMD the pre-sort kernel is compiled for */
+#endif
+
+// VEC: n, m multiples of 4, position rows 16-byte aligned, permutation rows 8-byte aligned (16-byte loads, 8-byte stores); FULL: n == m == 64 KPL
+template <int KPL, bool FULL, bool VEC>
+__global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_kernel(const float* __restrict__ xpos, const float* __restrict__ ypos, int64_t B, int n, int m,
+                                                                 int64_t xps, int64_t yps, uint16_t* __restrict__ perm)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SCR = align4(wave_sort_scratch(KPL));
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* const idx = reinterpret_cast<uint32_t*>(smem) + wv * SCR;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < B; row += (int64_t)gridDim.x * 4) {
+        uint16_t* const prow = perm + row * ((int64_t)n + m);
+        int states = 0;   // two bits per array -- 0: it arrived sorted (nothing written yet), 1: its permutation is stored, 2: declined
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const float* src = which ? ypos + row * yps : xpos + row * xps;
+            const int len = which ? m : n;
+            uint16_t* const dst = prow + (which ? n : 0);
+            float x[KPL];
+            if constexpr (VEC) {
+#pragma unroll
+                for (int r = 0; r < KPL; r += 4) {
+                    const int e = wsort_elem<true>(r, lane);
+                    const float4 v = *reinterpret_cast<const float4*>(src + (FULL ? e : min(e, len - 4)));
+                    const bool real = FULL || e < len;   // whole groups of four: len % 4 == 0
+                    x[r] = real ? v.x : INFINITY; x[r + 1] = real ? v.y : INFINITY; x[r + 2] = real ? v.z : INFINITY; x[r + 3] = real ? v.w : INFINITY;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) { const int e = r * 64 + lane; const float v = src[min(e, len - 1)]; x[r] = (e < len) ? v : INFINITY; }
+            }
+            // sortedness (as the row kernels test it: an element greater than its right neighbour; +inf behind the last one)
+            bool unsorted = false;
+            if constexpr (VEC) {   // (pads are +inf: never greater than their right neighbour)
+#pragma unroll
+                for (int g4 = 0; g4 < KPL; g4 += 4) {
+                    // the element after this lane's four: the next lane's first; for lane 63 the first of the next block of 256 (lane 0)
+                    float nxt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[g4]), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+                    const float wrap = (g4 + 4 < KPL) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[g4 + 4 < KPL ? g4 + 4 : 0]))) : INFINITY;
+                    nxt = (lane == 63) ? wrap : nxt;
+                    unsorted |= (x[g4] > x[g4 + 1]) | (x[g4 + 1] > x[g4 + 2]) | (x[g4 + 2] > x[g4 + 3]) | (x[g4 + 3] > nxt);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    float nxt = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[r]), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+                    const float wrap = (r + 1 < KPL) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x[r + 1 < KPL ? r + 1 : 0]))) : INFINITY;
+                    nxt = (lane == 63) ? wrap : nxt;
+                    unsorted |= (r * 64 + lane + 1 < len) && (x[r] > nxt);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(unsorted) == 0ull) continue;
+            float sk[KPL]; uint32_t si[KPL];
+            const bool done = wave_sort_core<KPL, false, FULL, VEC, false>(x, [src](uint32_t i) { return src[i]; }, nullptr, idx, len, lane, sk, si);
+            row_sync<1>();   // the scratch image is free again
+            if (!done) { states |= 2 << (2 * which); continue; }
+            states |= 1 << (2 * which);
+            if constexpr (VEC) {
+#pragma unroll
+                for (int r = 0; r < KPL; r += 4) {
+                    uint2 pk;
+                    pk.x = si[r] | (si[r + 1] << 16); pk.y = si[r + 2] | (si[r + 3] << 16);
+                    const int e = wsort_elem<true>(r, lane);
+                    if (FULL || e < len) *reinterpret_cast<uint2*>(dst + e) = pk;   // (positions < len never hold a pad: no clamp)
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) { const int e = r * 64 + lane; if (e < len) dst[e] = (uint16_t)min((int)si[r], len - 1); }
+            }
+        }
+        // (wave-uniform decisions; the stores of one wavefront to one address keep their program order)
+        if ((states & 0xA) != 0 || states == 0) {
+            if (lane < 2) prow[lane] = kRowPermSentinel;
+        } else {
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) {
+                if (((states >> (2 * which)) & 3) != 0) continue;   // sorted beside an unsorted one: the identity
+                const int len = which ? m : n;
+                uint16_t* const dst = prow + (which ? n : 0);
+                for (int e = lane; e < len; e += 64) dst[e] = (uint16_t)e;
+            }
+        }
+    }
+}
+
+// dest: [B, n + m] uint16.  n, m in [2, 2048].
+int launch_rowpos_sort(const float* xpos, const float* ypos, int64_t B, int n, int m, int64_t xps, int64_t yps, uint16_t* dest, hipStream_t s)
+{
+    const int N = n > m ? n : m;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(xpos) | reinterpret_cast<uintptr_t>(ypos)) & 15) == 0 && (xps & 3) == 0 && (yps & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(dest) & 7) == 0 && (n & 3) == 0 && (m & 3) == 0;
+    (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
+    auto go = [&](auto kern, int kpl) {
+        const size_t lds = (size_t)align4(wave_sort_scratch(kpl)) * 4 * 4;   // 4 waves x the transposition image
+        static GridCache cache;   // (one per lambda instantiation, i.e. per kernel)
+        allow_full_lds_once(cache, reinterpret_cast<const void*>(kern));
+        int per_cu = (int)(kLdsLimit / lds);
+        if (per_cu > SOT_ROWPOS_SORT_WAVES) per_cu = SOT_ROWPOS_SORT_WAVES;   // four-wave workgroups: one wave of each per SIMD
+        const int64_t groups = (B + 3) / 4, cap = (int64_t)device_cu_count() * per_cu;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, s, xpos, ypos, B, n, m, xps, yps, dest);
+    };
+    auto pick = [&](auto kpl_tag) {
+        constexpr int KP = decltype(kpl_tag)::value;
+        if (aligned && n == 64 * KP && m == 64 * KP) go(sot_rowpos_sort_kernel<KP, true, true>, KP);
+        else if (aligned) go(sot_rowpos_sort_kernel<KP, false, true>, KP);
+        else go(sot_rowpos_sort_kernel<KP, false, false>, KP);
+    };
+    if (N <= 512) pick(std::integral_constant<int, 8>{});
+    else if (N <= 1024) pick(std::integral_constant<int, 16>{});
+    else pick(std::integral_constant<int, 32>{});
+    return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
+}
+
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
                           hipStream_t s)
 {
@@ -1952,6 +2089,19 @@ int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t 
     a.xs = pr->x_row_stride; a.ys = pr->y_row_stride; a.xps = pr->xpos_row_stride; a.yps = pr->ypos_row_stride;
     a.p = pr->p; a.flags = pr->flags;
     if (l.rowpos && (pr->flags & SOT_FLAG_REQUIRE_SORT)) { a.perm_out = pr->row_perm_out; a.perm_in = pr->row_perm_in; }
+    // per-row positions nobody has sorted yet: the wave-sort kernel runs first (round 6) and the row kernel gathers through its
+    // permutations -- into the caller's row_perm_out, else into the workspace when it is large enough (sot_workspace_bytes), else the
+    // row kernel sorts in LDS as before
+    if (SOT_WAVE_SORT && l.rowpos && (pr->flags & SOT_FLAG_REQUIRE_SORT) && a.perm_in == nullptr && pr->B > 0 && n >= 2 && m >= 2 && n <= 2048 &&
+        m <= 2048 && !(pr->flags & SOT_FLAG_NO_SPECIALIZE)) {
+        uint16_t* dest = pr->row_perm_out;
+        if (dest == nullptr && workspace != nullptr && workspace_bytes >= rowpos_perm_bytes(pr->B, n, m)) dest = reinterpret_cast<uint16_t*>(workspace);
+        if (dest != nullptr) {
+            rc = launch_rowpos_sort(pr->xpos, pr->ypos, pr->B, n, m, pr->xpos_row_stride, pr->ypos_row_stride, dest, l.s);
+            if (rc != SOT_OK) return rc;
+            a.perm_in = dest;   // (a.perm_out stays the caller's image: rows that carry the sentinel store their permutations over it)
+        }
+    }
 
     if (need_prep && pr->perm_is_identity != nullptr) {  // caller-provided plan: positions are already sorted
         a.xperm = pr->xperm; a.yperm = pr->yperm; a.ident = pr->perm_is_identity;
@@ -2197,6 +2347,9 @@ const char* sot_status_string(int status)
 size_t sot_workspace_bytes(const sot_problem* prob)
 {
     if (prob == nullptr || prob->n < 1 || prob->m < 1) return 0;
+    if (prob->xpos_row_stride != 0)   // per-row positions: room for the pre-sort's permutations (optional: without it the row kernel sorts in LDS)
+        return (prob->flags & SOT_FLAG_REQUIRE_SORT) && prob->row_perm_in == nullptr && prob->row_perm_out == nullptr && prob->B > 0
+                   ? sot::rowpos_perm_bytes(prob->B, prob->n, prob->m) : 0;
     return sot::ws_layout(prob->n, prob->m).total;
 }
 

@@ -26,7 +26,22 @@
 #include "sot_device.hpp"
 
 #ifndef SOT_WSORT_DPP
-#define SOT_WSORT_DPP 1   /* 1: lane ^ 1, 2, 3, 7, 15 by DPP (VALU moves); 0: every move through the LDS crossbar (ds_swizzle) */
+#define SOT_WSORT_DPP 0x808E   /* bit m: the move from lane ^ m is a DPP (a VALU instruction) -- possible for m = 1, 2, 3, 7, 15; else a ds_swizzle (LDS crossbar) */
+#endif
+
+// Between two stages of the network the instruction scheduler may not move anything (1): a stage is 32 independent exchanges -- all the
+// parallelism a wave can use -- while a scheduler left free overlaps stages until it has used every register the occupancy target
+// allows (256 in the stand-alone kernel), and inlined into the row kernels that pushed THEIR long-lived values into scratch.
+#ifndef SOT_WSORT_GROUP
+#define SOT_WSORT_GROUP 8   /* registers per cross-lane group (moves in flight) */
+#endif
+#ifndef SOT_WSORT_FENCED
+#define SOT_WSORT_FENCED 1
+#endif
+#if SOT_WSORT_FENCED
+#define SOT_WSORT_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SOT_WSORT_STAGE_FENCE() do { } while (0)
 #endif
 
 namespace sot {
@@ -42,11 +57,11 @@ template <int M>
 __device__ __forceinline__ uint32_t wsort_lane_xor(uint32_t v, uint32_t addr63)
 {
     (void)addr63;
-    if constexpr (SOT_WSORT_DPP && M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
-    else if constexpr (SOT_WSORT_DPP && M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    else if constexpr (SOT_WSORT_DPP && M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
-    else if constexpr (SOT_WSORT_DPP && M == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
-    else if constexpr (SOT_WSORT_DPP && M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); // row_mirror
+    if constexpr (((SOT_WSORT_DPP >> 1) & 1) && M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (((SOT_WSORT_DPP >> 2) & 1) && M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (((SOT_WSORT_DPP >> 3) & 1) && M == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    else if constexpr (((SOT_WSORT_DPP >> 7) & 1) && M == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (((SOT_WSORT_DPP >> 15) & 1) && M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); // row_mirror
     else if constexpr (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (M << 10));                    // bit-mask mode: lane ^ M within 32
     else return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr63, (int)v);                                               // M == 63: addr63 = 4 (lane ^ 63)
 }
@@ -69,39 +84,53 @@ __device__ __forceinline__ void wsort_reg_tail(uint32_t (&w)[KPL])
                 w[r] = lo; w[r | J] = hi;
             }
         }
+        SOT_WSORT_STAGE_FENCE();
         wsort_reg_tail<KPL, J / 2>(w);
     }
 }
 
-// merges inside one lane's registers: runs of K / 2 -> K, K = 2 ... KPL
-template <int KPL, int K>
-__device__ __forceinline__ void wsort_reg_merges(uint32_t (&w)[KPL])
+// the lane's own KPL registers, sorted ascending: Batcher's odd-even merge sort (191 exchanges for 32 registers where the bitonic
+// merges of the rest of the network would take 240; Knuth's iterative form, every loop bound a compile-time constant)
+template <int KPL>
+__device__ __forceinline__ void wsort_reg_sort(uint32_t (&w)[KPL])
 {
-    if constexpr (K <= KPL) {
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) {
-            const int q = r ^ (K - 1);
-            if (r < q) {
-                const uint32_t lo = min(w[r], w[q]), hi = max(w[r], w[q]);
-                w[r] = lo; w[q] = hi;
+    for (int p = 1; p < KPL; p *= 2) {
+#pragma unroll
+        for (int k = p; k >= 1; k /= 2) {
+#pragma unroll
+            for (int j = k % p; j + k < KPL; j += 2 * k) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) {
+                    const int a = i + j, b = i + j + k;
+                    if (b < KPL && a / (2 * p) == b / (2 * p)) {
+                        const uint32_t lo = min(w[a], w[b]), hi = max(w[a], w[b]);
+                        w[a] = lo; w[b] = hi;
+                    }
+                }
             }
+            SOT_WSORT_STAGE_FENCE();
         }
-        wsort_reg_tail<KPL, K / 4>(w);
-        wsort_reg_merges<KPL, 2 * K>(w);
     }
 }
 
-// half cleaners between lanes at distances D, D / 2, ..., 1
+// half cleaners between lanes at distances D, D / 2, ..., 1 (groups of SOT_WSORT_GROUP registers: that many moves in flight, no more
+// temporaries than that)
 template <int KPL, int D>
 __device__ __forceinline__ void wsort_lane_tail(uint32_t (&w)[KPL], int lane, uint32_t addr63)
 {
     if constexpr (D >= 1) {
+        constexpr int GRP = KPL < SOT_WSORT_GROUP ? KPL : SOT_WSORT_GROUP;
         const uint32_t bound = (lane & D) ? 0xFFFFFFFFu : 0u;
-        uint32_t t[KPL];
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) t[r] = wsort_lane_xor<D>(w[r], addr63);
+        for (int g = 0; g < KPL; g += GRP) {
+            uint32_t t[GRP];
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) w[r] = wsort_med3(w[r], t[r], bound);
+            for (int r = 0; r < GRP; ++r) t[r] = wsort_lane_xor<D>(w[g + r], addr63);
+#pragma unroll
+            for (int r = 0; r < GRP; ++r) w[g + r] = wsort_med3(w[g + r], t[r], bound);
+            SOT_WSORT_STAGE_FENCE();
+        }
         wsort_lane_tail<KPL, D / 2>(w, lane, addr63);
     }
 }
@@ -111,12 +140,22 @@ template <int KPL, int S>
 __device__ __forceinline__ void wsort_lane_merges(uint32_t (&w)[KPL], int lane, uint32_t addr63)
 {
     if constexpr (S <= 64) {
+        // flip: partner (lane ^ (S - 1), KPL - 1 - r); registers r and KPL - 1 - r only need each other: groups of pairs
+        constexpr int GRP = (KPL / 2 < SOT_WSORT_GROUP / 2) ? (KPL / 2 > 0 ? KPL / 2 : 1) : SOT_WSORT_GROUP / 2;
         const uint32_t bound = (lane & (S / 2)) ? 0xFFFFFFFFu : 0u;
-        uint32_t t[KPL];
+        if constexpr (KPL == 1) {
+            w[0] = wsort_med3(w[0], wsort_lane_xor<S - 1>(w[0], addr63), bound);
+        } else {
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) t[r] = wsort_lane_xor<S - 1>(w[KPL - 1 - r], addr63);   // flip: partner (lane ^ (S - 1), KPL - 1 - r)
+            for (int g = 0; g < KPL / 2; g += GRP) {
+                uint32_t ta[GRP], tb[GRP];
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) w[r] = wsort_med3(w[r], t[r], bound);
+                for (int r = 0; r < GRP; ++r) { ta[r] = wsort_lane_xor<S - 1>(w[KPL - 1 - (g + r)], addr63); tb[r] = wsort_lane_xor<S - 1>(w[g + r], addr63); }
+#pragma unroll
+                for (int r = 0; r < GRP; ++r) { w[g + r] = wsort_med3(w[g + r], ta[r], bound); w[KPL - 1 - (g + r)] = wsort_med3(w[KPL - 1 - (g + r)], tb[r], bound); }
+                SOT_WSORT_STAGE_FENCE();
+            }
+        }
         wsort_lane_tail<KPL, S / 4>(w, lane, addr63);
         wsort_reg_tail<KPL, KPL / 2>(w);
         wsort_lane_merges<KPL, 2 * S>(w, lane, addr63);
@@ -128,7 +167,7 @@ template <int KPL>
 __device__ __forceinline__ void wsort_network(uint32_t (&w)[KPL], int lane)
 {
     const uint32_t addr63 = (uint32_t)(lane ^ 63) << 2;
-    wsort_reg_merges<KPL, 2>(w);
+    wsort_reg_sort<KPL>(w);
     wsort_lane_merges<KPL, 2>(w, lane, addr63);
 }
 
@@ -166,23 +205,37 @@ __device__ __forceinline__ int wsort_elem(int r, int lane) { return VEC ? ((r >>
 // ok[r] / oi[r] are the sorted key and its original index at position wsort_elem<VEC>(r, lane) (pads: +inf / 64 KPL - 1) and, with
 // STORE_LDS, key[] / idx[] hold the same in natural order on [0, 64 KPL); false: declined, key[] is untouched (idx[] is not).
 // ---------------------------------------------------------------------------------------------
-template <int KPL, bool STORE_LDS = true, bool FULL = false, bool VEC = false>
-__device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
+// wave_sort_core: the same with the full keys behind a functor (keyof(i): the key of original element i -- LDS, or global memory when no
+// natural copy is kept) and WANT_KEYS = false for callers that only want the permutation (ok[] is then not written).
+template <int KPL, bool STORE_LDS, bool FULL, bool VEC, bool WANT_KEYS, typename KeyOf>
+__device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyof, float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
 {
+    static_assert(!STORE_LDS || WANT_KEYS, "the natural-order stores need the sorted keys");
     static_assert(!VEC || KPL % 4 == 0, "VEC needs four registers per 16-byte group");
     constexpr int NPAD = 64 * KPL, IDXBITS = 6 + wsort_ilog2(KPL), QBITS = 32 - IDXBITS;
     constexpr uint32_t QMAX = (1u << QBITS) - 1u, MASK = (1u << IDXBITS) - 1u;
     // ---- pre-pass: range of the real keys; NaN / infinite keys decline (0 x = NaN for both)
+    // (pads without compare masks -- 32 SGPR pairs the allocator would have to keep: pm = all ones where element >= n, by sign extension of
+    // n - 1 - element; a pad's key is replaced by the wave's first key for the range and its word is OR-ed to all ones)
     float mn = INFINITY, mx = -INFINITY, det = 0.0f;
     const bool full = FULL || (n == NPAD);    // wave-uniform: no pads, no validity tests
+    uint32_t low[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) low[c] = VEC ? (uint32_t)(4 * lane + c) : (uint32_t)lane;
+    auto pad_mask = [&](int r) -> uint32_t {   // element(r) = base(r) + low: base is a compile-time constant
+        const int base = VEC ? ((r >> 2) << 8) : r * 64;
+        return (uint32_t)((n - 1 - base - (int)low[VEC ? (r & 3) : 0]) >> 31);
+    };
     if (full) {
 #pragma unroll
         for (int r = 0; r < KPL; ++r) { mn = fminf(mn, x[r]); mx = fmaxf(mx, x[r]); det = fmaf(x[r], 0.0f, det); }
     } else {
+        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(x[0]));   // element 0 (n >= 1): a real key
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
-            const bool real = wsort_elem<VEC>(r, lane) < n;
-            mn = fminf(mn, real ? x[r] : INFINITY); mx = fmaxf(mx, real ? x[r] : -INFINITY); det = fmaf(real ? x[r] : 0.0f, 0.0f, det);
+            const uint32_t pm = pad_mask(r);
+            const float xe = __uint_as_float((__float_as_uint(x[r]) & ~pm) | (x0 & pm));   // v_bfi_b32
+            mn = fminf(mn, xe); mx = fmaxf(mx, xe); det = fmaf(xe, 0.0f, det);
         }
     }
     mn = wsort_wave_min(mn); mx = wsort_wave_max(mx);
@@ -192,15 +245,12 @@ __device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, 
     if (bad || !(range > 0.0f) || !(range < INFINITY) || !(scale < INFINITY)) return false;
     // ---- one word per key: (q << IDXBITS) + element, in two shift-adds with inline constants
     uint32_t w[KPL];
-    uint32_t low[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) low[c] = VEC ? (uint32_t)(4 * lane + c) : (uint32_t)lane;
 #pragma unroll
     for (int r = 0; r < KPL; ++r) {
-        const uint32_t q = (uint32_t)((x[r] - mn) * scale);
+        const uint32_t q = (uint32_t)((x[r] - mn) * scale);   // (a pad's q is garbage: its word is overwritten below)
         const uint32_t word = VEC ? (((q << (IDXBITS - 8)) + (uint32_t)(r >> 2)) << 8) + low[r & 3]
                                   : (((q << (IDXBITS - 6)) + (uint32_t)r) << 6) + low[0];
-        w[r] = (full || wsort_elem<VEC>(r, lane) < n) ? word : 0xFFFFFFFFu;   // every pad is the same word: behind the data, never a run
+        w[r] = full ? word : (word | pad_mask(r));   // every pad is the same word 0xFFFFFFFF: behind the data, never a run
     }
     wsort_network<KPL>(w, lane);
     // ---- neighbours that share q: (a ^ b) - 1 < MASK (a == b: two pads)
@@ -244,11 +294,11 @@ __device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, 
                 } else {
                     for (int i = 1; i < len; ++i) {        // insertion sort, strict ">": stable
                         const uint32_t wi = W(p + i);
-                        const uint32_t ki = float_order_bits(key[wi & MASK]);
+                        const uint32_t ki = float_order_bits(keyof(wi & MASK));
                         int j = i;
                         while (j > 0) {
                             const uint32_t wj = W(p + j - 1);
-                            if (float_order_bits(key[wj & MASK]) > ki) { W(p + j) = wj; --j; } else break;
+                            if (float_order_bits(keyof(wj & MASK)) > ki) { W(p + j) = wj; --j; } else break;
                         }
                         W(p + j) = wi;
                     }
@@ -265,7 +315,7 @@ __device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, 
     for (int r = 0; r < KPL; ++r) w[r] = lds_ld_u32(ra + 4u * (uint32_t)(VEC ? 264 * (r >> 2) + (r & 3) : 66 * r));
     // ---- indices and sorted keys (every gather is issued before the first store: one wave, in-order LDS)
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) { oi[r] = w[r] & MASK; ok[r] = key[oi[r]]; }
+    for (int r = 0; r < KPL; ++r) { oi[r] = w[r] & MASK; if constexpr (WANT_KEYS) ok[r] = keyof(oi[r]); }
     if constexpr (STORE_LDS) {
         row_sync<1>();
         if constexpr (VEC) {
@@ -280,6 +330,12 @@ __device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, 
         }
     }
     return true;
+}
+
+template <int KPL, bool STORE_LDS = true, bool FULL = false, bool VEC = false>
+__device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
+{
+    return wave_sort_core<KPL, STORE_LDS, FULL, VEC, true>(x, [key](uint32_t i) { return key[i]; }, key, idx, n, lane, ok, oi);
 }
 
 }  // namespace sot

@@ -510,6 +510,95 @@ def test_segmented_sort_bit_exact_indices(n):
     assert torch.equal(got_v.cpu(), want_v) and torch.equal(got_i.cpu(), want_i)
 
 
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 129, 257, 500, 512, 513, 1024, 1025, 1500, 2047, 2048])
+def test_segmented_sort_adversarial_keys(n):
+    """Round 6: rows of <= 2048 keys are sorted by ONE wavefront on one packed word per key (quantised key | index), exact by a repair of
+    the runs that share a quantisation bin, with the in-LDS merge sort as the fallback (csrc/sot_wave_sort.hpp).  Values AND indices
+    bit-identical to torch.sort(stable=True) on the cases that exercise each branch: the adaptive range (all keys in one 2^-14 interval),
+    the repair (near-ties), the fallback (everything but one key in ONE bin; all keys equal; +-inf; an overflowing range; a denormal
+    range), -0 == +0, and NaN rows beside clean rows (NaN has no defined place; indices stay inside the row, clean rows stay exact)."""
+    nat = native()
+    dev = device()
+    g = torch.Generator().manual_seed(1000 + n)
+    B = 19
+    u = torch.rand(B, n, generator=g)
+
+    def same(keys):
+        got_v, got_i = nat.segmented_sort(keys.to(dev))
+        want_v, want_i = torch.sort(keys, dim=1, stable=True)
+        assert torch.equal(got_v.cpu(), want_v) and torch.equal(got_i.cpu(), want_i)   # (value equality: the merge-sort fallback returns +0 for -0)
+
+    same(u)
+    same(torch.randn(B, n, generator=g) * 3)
+    same(torch.round(u * 50) / 50)                                         # ties: long runs of equal keys (declined: merge sort) and short ones
+    same(torch.sort(u, dim=1, descending=True)[0].contiguous())
+    same(0.5 + u * 2.0 ** -14)                                             # one bin of the float's own top bits; separated by the row's range
+    near = u.clone(); near[:, 1::2] = torch.nextafter(near[:, 0::2][:, :near[:, 1::2].shape[1]], torch.tensor(2.0)); same(near)   # pairs one ulp apart
+    same(torch.cat([u[:, :-1] * 1e-9, torch.ones(B, 1)], 1))               # everything but one key in ONE bin: the fallback
+    same(torch.full((B, n), 0.25))
+    z = u.clone(); z[:, ::3] = 0.0; z[:, 1::5] = -0.0; same(z)
+    for bad in (float("inf"), float("-inf")):
+        w = u.clone(); w[:, n // 2] = bad; same(w)
+    same((u - 0.5) * 6e38)                                                 # max - min overflows
+    same(u * 1e-42)                                                        # a denormal range: the scale overflows
+    if n > 2:
+        w = u.clone(); w[::2, 1] = float("nan")
+        got_v, got_i = nat.segmented_sort(w.to(dev))
+        assert int(got_i.min()) >= 0 and int(got_i.max()) < n
+        want_v, want_i = torch.sort(w[1::2], dim=1, stable=True)
+        assert torch.equal(got_v.cpu()[1::2], want_v) and torch.equal(got_i.cpu()[1::2], want_i)
+    # strided rows and a base pointer off the 16-byte grid (the scalar-load variant)
+    wide = torch.rand(B, n + 5, generator=g).to(dev)
+    got_v, got_i = nat.segmented_sort(wide[:, 1:n + 1])
+    want_v, want_i = torch.sort(wide[:, 1:n + 1].cpu(), dim=1, stable=True)
+    assert torch.equal(got_v.cpu(), want_v) and torch.equal(got_i.cpu(), want_i)
+
+
+@pytest.mark.parametrize("shape", [(9, 2, 2), (5, 50, 70), (7, 300, 411), (6, 512, 512), (5, 1000, 1024), (4, 1025, 1025), (4, 1536, 1400), (6, 2048, 2048), (5, 2048, 2000)])
+@pytest.mark.parametrize("mode", ["p1", "cutoff"])
+def test_rowpos_presort_kernel_and_its_sentinel(shape, mode):
+    """Round 6: per-row positions that nobody has sorted are sorted AHEAD of the row kernel by sot_rowpos_sort_kernel (one wavefront per row,
+    permutations into the caller's row_perm_out or the workspace); the row kernels gather through them.  Rows whose arrays both arrive
+    sorted, and rows the wave sort declines (clustered / tied / non-finite positions), carry a sentinel and are handled by the row kernel
+    itself.  Every route must give the same bits: default (pre-sort) == SOT_FLAG_NO_SPECIALIZE (the row kernel's own merge sort) == the
+    oracle within the forward tolerance; the permutations left in row_perm_out are the stable argsort on EVERY row, sentinel rows included."""
+    from oracle import sot_oracle as so
+    from oracle.inputs import gen_inputs
+    from oracle.make_golden import MODES
+    nat = native()
+    dev = device()
+    B, n, m = shape
+    x, y = gen_inputs("peaky", B, n, m, 300 + n + m)
+    g = torch.Generator().manual_seed(n * 3 + m)
+    xp, yp = torch.rand(B, n, generator=g), torch.rand(B, m, generator=g)
+    xp[0], yp[0] = torch.sort(xp[0]).values, torch.sort(yp[0]).values          # both sorted: sentinel
+    xp[1] = torch.sort(xp[1]).values                                            # one sorted, one not: identity + permutation
+    if n > 12:
+        xp[2, : n - 1] *= 1e-9; xp[2, n - 1] = 1.0                              # clustered: the wave sort declines (sentinel; merge sort in the row kernel)
+        yp[3] = torch.round(yp[3] * 3) / 3                                      # long runs of ties: declined
+    p, flags = ctor_to_flags(MODES[mode])
+    xd, yd, xpd, ypd = x.to(dev), y.to(dev), xp.to(dev), yp.to(dev)
+    want = so.forward(x.numpy(), y.numpy(), xp.numpy(), yp.numpy(), p=p, flags=flags)
+    rows_pre = nat.forward_rows(xd, yd, xpd, ypd, p, flags, None)                         # pre-sort into the workspace
+    rows_own = nat.forward_rows(xd, yd, xpd, ypd, p, flags | nat.FLAG_NO_SPECIALIZE, None)  # the row kernel's own sort
+    perm = nat.row_permutations(xd, yd, xpd, ypd, flags)
+    perm.fill_(12345 % 65536)
+    rows_out = nat.forward_rows(xd, yd, xpd, ypd, p, flags, None, perm_out=perm)           # pre-sort into the caller's image
+    rows_in = nat.forward_rows(xd, yd, xpd, ypd, p, flags, None, perm_in=perm)
+    assert torch.equal(rows_pre, rows_own) and torch.equal(rows_out, rows_own) and torch.equal(rows_in, rows_own)
+    np.testing.assert_allclose(rows_pre.cpu().numpy(), want, rtol=RTOL)
+    got = perm.cpu().to(torch.int64)
+    assert torch.equal(got[:, :n], torch.sort(xp, dim=1, stable=True).indices) and torch.equal(got[:, n:], torch.sort(yp, dim=1, stable=True).indices)
+    one = torch.ones(1, device=dev)
+    gx0, gy0 = nat.backward_rows(xd, yd, xpd, ypd, p, flags | nat.FLAG_NO_SPECIALIZE, one)
+    gx1, gy1 = nat.backward_rows(xd, yd, xpd, ypd, p, flags, one)                          # pre-sort into ITS workspace
+    gx2, gy2 = nat.backward_rows(xd, yd, xpd, ypd, p, flags, one, perm_in=perm)
+    assert torch.equal(gx0, gx1) and torch.equal(gy0, gy1) and torch.equal(gx0, gx2) and torch.equal(gy0, gy2)
+    px0 = nat.position_grads(xd, yd, xpd, ypd, p, flags | nat.FLAG_NO_SPECIALIZE, one)
+    px1 = nat.position_grads(xd, yd, xpd, ypd, p, flags, one)
+    assert torch.equal(px0[0], px1[0]) and torch.equal(px0[1], px1[1])
+
+
 @pytest.mark.parametrize("shape", [(5, 50, 70), (3, 300, 300), (9, 1025, 1025), (2, 2048, 2048)])
 @pytest.mark.parametrize("mode", ["p1", "cutoff"])
 def test_unsorted_positions_shared_and_per_row(shape, mode):

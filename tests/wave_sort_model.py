@@ -81,11 +81,19 @@ def network(w, kpl, stats=None):
             ce_regs([(r, r | j) for r in range(kpl) if not r & j])
             j >>= 1
 
-    k = 2
-    while k <= kpl:                        # merges inside one lane's registers
-        ce_regs([(r, r ^ (k - 1)) for r in range(kpl) if r < r ^ (k - 1)])
-        tail(k >> 2)
-        k <<= 1
+    p = 1
+    while p < kpl:                         # the lane's own registers: Batcher's odd-even merge sort (Knuth's iterative form, as the kernel)
+        k = p
+        while k >= 1:
+            pairs = []
+            for j in range(k % p, kpl - k, 2 * k):
+                for i in range(k):
+                    a, b = i + j, i + j + k
+                    if b < kpl and a // (2 * p) == b // (2 * p):
+                        pairs.append((a, b))
+            ce_regs(pairs)
+            k //= 2
+        p *= 2
     s = 2
     while s <= 64:                         # merges across lanes: runs of (s / 2) kpl -> s kpl
         src = lane_xor(w, s - 1)           # flip: partner = (lane ^ (s - 1), kpl - 1 - r)
