@@ -789,11 +789,12 @@ def mss_loss_and_grad(target: torch.Tensor, value: torch.Tensor, fft_sizes, wind
     lib = load()
     if target.ndim != 2 or target.shape != value.shape:
         raise RuntimeError("mss_loss_and_grad expects two [batch, samples] tensors of one shape")
-    if target.stride(1) != 1:
-        target = target.contiguous()
-    if value.stride(1) != 1:
-        value = value.contiguous()
+    # rows the library can address: unit inner stride and a row stride of at least one row (an expanded target -- stride 0 -- or an
+    # overlapping as_strided view is copied, as the reference's own ops would do); a single row's stride is meaningless to torch
+    target, value = rows_view(target), rows_view(value)
     batch, samples = value.shape
+    t_stride = target.stride(0) if batch > 1 else samples
+    v_stride = value.stride(0) if batch > 1 else samples
     n = len(fft_sizes)
     sizes = (ctypes.c_int * n)(*[int(s) for s in fft_sizes])
     wins = [_aligned8(w) for w in windows]
@@ -803,9 +804,11 @@ def mss_loss_and_grad(target: torch.Tensor, value: torch.Tensor, fft_sizes, wind
         raise SotError(f"sot_mss_loss_and_grad does not take fft_sizes={tuple(fft_sizes)} (powers of two in [64, 2048], at most 8)")
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=value.device)
     loss = torch.empty(batch if per_clip else (), dtype=torch.float32, device=value.device)
+    if batch == 0:   # nothing is launched: the mean over an empty batch is NaN (what the reference's torch.mean returns); per clip: no entries
+        loss.fill_(float("nan"))
     grad = torch.empty((batch, samples), dtype=torch.float32, device=value.device) if want_grad else None
     with _on_device(value.device):
-        check(lib.sot_mss_loss_and_grad(target.data_ptr(), target.stride(0), value.data_ptr(), value.stride(0), batch, samples,
+        check(lib.sot_mss_loss_and_grad(target.data_ptr(), t_stride, value.data_ptr(), v_stride, batch, samples,
                                         ctypes.cast(sizes, ctypes.c_void_p), ctypes.cast(wptr, ctypes.c_void_p), n, float(mag_weight), float(logmag_weight),
                                         float(eps), int(bool(l2)), int(bool(per_clip)), loss.data_ptr(), _ptr(grad), ws.data_ptr(), ws.numel(),
                                         stream_ptr(value.device)))

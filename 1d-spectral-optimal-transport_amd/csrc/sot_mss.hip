@@ -541,8 +541,10 @@ static int fill(const float* target, int64_t stride_t, const float* value, int64
     gfloats = 2 * 256 * gfloats * a->ranges * batch;            // floats: [clip][range][slot][256 points][2]
     a->task_base[n_scales] = (int)blocks;
     if (blocks > 0x7fffffffLL) return SOT_ERR_UNSUPPORTED_SIZE;
-    *workspace_bytes = sizeof(double) * (size_t)ldoubles + sizeof(float) * (size_t)gfloats;
-    *grad_offset_bytes = sizeof(double) * (size_t)ldoubles;    // workspace = [partial sums (double) | spans (float)]
+    // workspace = [partial sums (double) | padding to 16 bytes | spans (float)]: mss_finish_kernel reads the spans with 16-byte loads
+    const size_t sums = (sizeof(double) * (size_t)ldoubles + 15) & ~(size_t)15;
+    *workspace_bytes = sums + sizeof(float) * (size_t)gfloats;
+    *grad_offset_bytes = sums;
     return SOT_OK;
 }
 
@@ -575,7 +577,7 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     if (batch == 0) return SOT_OK;
     if (target == nullptr || value == nullptr || loss == nullptr || workspace == nullptr) return SOT_ERR_NULL_POINTER;
     if (workspace_bytes < need) return SOT_ERR_WORKSPACE;
-    if (reinterpret_cast<uintptr_t>(workspace) % 8 != 0) return SOT_ERR_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return SOT_ERR_BAD_SHAPE;   // 16-byte loads of the span pieces
     a.partial_loss = reinterpret_cast<double*>(workspace);
     a.partial_grad = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + grad_off);
     a.loss = loss; a.grad = grad_value; a.want_grad = grad_value != nullptr;

@@ -1250,7 +1250,8 @@ __global__ __launch_bounds__(kWave2Threads) void stft_mag_backward_spec_clipw_ke
             const float* const g = a.grad_mag + (b * a.frames + wave) * nb;
             float peak, least;
             clipw_pack_gradient<true>(sp, g, up, zl, wn, lane, peak, least);
-            // re^2 + im^2 of every non-zero bin must be a normal number that cannot overflow (NaNs fail the test): else the careful form
+            // re^2 + im^2 of every non-zero bin must be a normal number that cannot overflow: else the careful form.  (A NaN bin does NOT fail
+            // this test -- the maxima drop NaN operands -- and needs no care: it propagates through either form.)
             const float wpeak = wave_max_f32(peak), wleast = -wave_max_f32(-least);
             if (__builtin_amdgcn_readfirstlane((int)(wpeak < 1e15f && wleast > 1e-18f)) == 0) {
                 wave_sync();

@@ -14,6 +14,7 @@ dtype-agnostic (losses.py:129-211) and `accelerator: cpu` has to keep working.
 """
 from __future__ import annotations
 
+import typing
 import warnings
 
 import torch
@@ -357,6 +358,23 @@ def wasserstein_1d_csr(x_weights, x_positions, x_offsets, y_weights, y_positions
                                 float(p), flags)
 
 
+class _HotCall(typing.NamedTuple):
+    """What Wasserstein1D.forward remembers of its last default call (round-5 review: a 13-slot positional tuple before)."""
+    x_pos: torch.Tensor          # the position tensors of that call, by identity ...
+    y_pos: torch.Tensor
+    x_version: int               # ... and their in-place-modification counters then
+    y_version: int
+    settings: tuple              # Wasserstein1D._settings() then
+    plan: object                 # the position plan (sorted grids, permutations, identity flags)
+    flag_word: int               # the call's flag word as the library takes it (with SOT_FLAG_SAME_GRID where the plan says so)
+    glue: object                 # the C++ host path (_sot_glue)
+    n: int                       # row lengths
+    m: int
+    fresh_ok: bool               # the fresh-positions branch applies: caller-passed positions (not the fixed_x buffer) and the extension has mean_loss_fresh
+    flags_no_same_grid: int      # the flag word without the same-grid bit (two fresh tensors: the C++ side puts it back when both are one tensor)
+    area_ok: bool                # the merge-free kernel may be asked for (p = 1, no cutoff)
+
+
 class Wasserstein1D(torch.nn.Module):
     """Drop-in for losses.Wasserstein1D (losses.py:89-211); see that docstring for the arguments."""
 
@@ -379,7 +397,7 @@ class Wasserstein1D(torch.nn.Module):
         else:
             self.register_buffer("fixed_x", None)
         self._plans = _PlanCache()
-        self._hot = None   # the last default call's (positions, their versions, module settings, plan, flag word, extension, n, m): see forward
+        self._hot = None   # the last default call, a _HotCall: see forward
 
     def __getstate__(self):
         # the caches hold device events and the extension module: a copy / pickle of the module (copy.deepcopy for an EMA model,
@@ -462,28 +480,28 @@ class Wasserstein1D(torch.nn.Module):
                 and y.is_cuda):
             xp = self.fixed_x if x_pos is None else x_pos
             yp = self.fixed_x if y_pos is None else y_pos
-            if (xp is hot[0] and yp is hot[1] and _version_of(xp) == hot[2] and _version_of(yp) == hot[3] and self._settings() == hot[4]
+            if (xp is hot.x_pos and yp is hot.y_pos and _version_of(xp) == hot.x_version and _version_of(yp) == hot.y_version and self._settings() == hot.settings
                     and 2 <= x.ndim <= 3 and x.ndim == y.ndim):
                 x2 = x if x.ndim == 2 else x.reshape(-1, x.shape[-1])
                 y2 = y if y.ndim == 2 else y.reshape(-1, y.shape[-1])
-                if (x2.stride(1) == 1 and y2.stride(1) == 1 and x2.shape[1] == hot[8] and y2.shape[1] == hot[9]
+                if (x2.stride(1) == 1 and y2.stride(1) == 1 and x2.shape[1] == hot.n and y2.shape[1] == hot.m
                         and not (torch.is_grad_enabled() and (x2.requires_grad or xp.requires_grad or yp.requires_grad))):
-                    plan = hot[5]
+                    plan = hot.plan
                     plan.use_on_current_stream(x2.device)
-                    return hot[7].mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), hot[6])
-            elif (x_pos is not None and y_pos is not None and self._settings() == hot[4] and 2 <= x.ndim <= 3 and x.ndim == y.ndim
-                  and hot[10] and _fresh_grid_ok(xp, x, hot[8]) and _fresh_grid_ok(yp, x, hot[9])):
+                    return hot.glue.mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), hot.flag_word)
+            elif (x_pos is not None and y_pos is not None and self._settings() == hot.settings and 2 <= x.ndim <= 3 and x.ndim == y.ndim
+                  and hot.fresh_ok and _fresh_grid_ok(xp, x, hot.n) and _fresh_grid_ok(yp, x, hot.m)):
                 # FRESH position tensors of the shapes seen last time -- the reference's trainer rebuilds its grid on every step
                 # (trainer.py:187-197: x_pos = torch.tensor(freqs).to(device) / max, y_pos = x_pos.clone()).  Their content cannot be
                 # compared on the host without a synchronisation, so the call gets its own plan, but inside the SAME C++ call as the loss
                 # (one allocation, one two-workgroup launch in front of the row kernel): no Python plan object, no cache bookkeeping, no
-                # general path.  hot[11]: the flag word WITHOUT the same-grid bit (whether two fresh tensors hold one grid is device-side
+                # general path.  flags_no_same_grid: the flag word WITHOUT the same-grid bit (whether two fresh tensors hold one grid is device-side
                 # knowledge; the C++ side puts it back when both arguments are one tensor).
                 x2 = x if x.ndim == 2 else x.reshape(-1, x.shape[-1])
                 y2 = y if y.ndim == 2 else y.reshape(-1, y.shape[-1])
-                if (x2.stride(1) == 1 and y2.stride(1) == 1 and x2.shape[1] == hot[8] and y2.shape[1] == hot[9]
+                if (x2.stride(1) == 1 and y2.stride(1) == 1 and x2.shape[1] == hot.n and y2.shape[1] == hot.m
                         and not (torch.is_grad_enabled() and (x2.requires_grad or xp.requires_grad or yp.requires_grad))):
-                    return hot[7].mean_loss_fresh(x2, y2, xp, yp, float(self.p), hot[11] | (nat.FLAG_SAME_GRID if (xp is yp and hot[12]) else 0))
+                    return hot.glue.mean_loss_fresh(x2, y2, xp, yp, float(self.p), hot.flags_no_same_grid | (nat.FLAG_SAME_GRID if (xp is yp and hot.area_ok) else 0))
         x_pos_, y_pos_ = self._positions(x_pos, y_pos)
         if not _hip_domain(x, y, x_pos_, y_pos_) or _beyond_one_cu(x, y, x_pos_, y_pos_):
             return self._torch_forward(x, y, x_pos_, y_pos_, kwargs)
@@ -510,11 +528,11 @@ class Wasserstein1D(torch.nn.Module):
                 # remembering it and the flag word frozen here would lack SOT_FLAG_SAME_GRID for good
                 if (not kwargs and x_pos_.ndim == 1 and y_pos_.ndim == 1 and x2.shape[1] + y2.shape[1] <= 12000
                         and not torch.cuda.is_current_stream_capturing()):
-                    # [10]: the fresh-positions branch of forward() applies (caller-passed positions, not the fixed_x buffer; the extension has it);
-                    # [11]: the flag word without the same-grid bit; [12]: the merge-free kernel may be asked for (p = 1, no cutoff)
-                    self._hot = (x_pos_, y_pos_, _version_of(x_pos_), _version_of(y_pos_), self._settings(), plan, fl, glue, x2.shape[1], y2.shape[1],
-                                 x_pos is not None and y_pos is not None and hasattr(glue, "mean_loss_fresh"), int(flags),
-                                 self.p == 1 and not (flags & (nat.FLAG_LIMIT_Q | nat.FLAG_NO_AREA | nat.FLAG_PRENORMALIZED)))
+                    self._hot = _HotCall(
+                        x_pos=x_pos_, y_pos=y_pos_, x_version=_version_of(x_pos_), y_version=_version_of(y_pos_), settings=self._settings(), plan=plan,
+                        flag_word=fl, glue=glue, n=x2.shape[1], m=y2.shape[1],
+                        fresh_ok=x_pos is not None and y_pos is not None and hasattr(glue, "mean_loss_fresh"), flags_no_same_grid=int(flags),
+                        area_ok=self.p == 1 and not (flags & (nat.FLAG_LIMIT_Q | nat.FLAG_NO_AREA | nat.FLAG_PRENORMALIZED)))
                 return glue.mean_loss(x2, y2, plan.xpos_sorted, plan.ypos_sorted, plan.xperm, plan.yperm, plan.ident, float(self.p), fl)
             if grad_on and any(t.requires_grad for t in (x2, y2, x_pos_, y_pos_)):
                 return _FusedMeanLoss.apply(x2, y2, x_pos_, y_pos_, float(self.p), flags, plan)
@@ -635,7 +653,7 @@ class MSSLoss(torch.nn.Module):
         per_item = (dims is not None and not isinstance(dims, int) and all(isinstance(d, int) and -3 <= d < 3 for d in dims)
                     and sorted(d % 3 for d in dims) == [1, 2])
         native_ok = (audio.is_cuda and target_audio.is_cuda and (dims is None or per_item) and audio.ndim == 2 and audio.shape == target_audio.shape and
-                     (self.mag_weight > 0 or self.logmag_weight > 0) and
+                     audio.shape[0] > 0 and (self.mag_weight > 0 or self.logmag_weight > 0) and   # (an empty batch: torch's mean of nothing, NaN)
                      all(spectra.hip_stft_supported(s, int(s * 0.25), audio.shape[1]) for s in self.fft_sizes))
         if audio.is_cuda and not native_ok:
             warn_once(("mss", dims is not None, self.fft_sizes),
@@ -644,6 +662,8 @@ class MSSLoss(torch.nn.Module):
         if native_ok and MSS_FUSED and len(self.fft_sizes) <= 8 and all(int(s) in nat.MSS_FUSED_SIZES for s in self.fft_sizes) and \
                 not (torch.is_grad_enabled() and target_audio.requires_grad):
             sizes = tuple(int(s) for s in self.fft_sizes)
+            # rows the kernels can address: an expanded target (row stride 0) or an overlapping view is copied, as the reference's ops would
+            target_audio, audio = nat.rows_view(target_audio), nat.rows_view(audio)
             glue = nat.glue() if (audio.dtype == torch.float32 and target_audio.dtype == torch.float32 and audio.stride(1) == 1 and
                                   target_audio.stride(1) == 1 and audio.shape[0] > 0) else None
             if glue is not None:   # ONE C++ call and a C++ autograd node (csrc/sot_torch_glue.cpp: MssLoss)

@@ -320,7 +320,7 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     with torch.no_grad():
         out[f"b{B}n{N}_unsorted_shared_forward"] = entry(timed(unsorted_shared, n), forward_kernel_name(N, "cutoff", batch=B) + " (gathers through the plan's permutation)",
                                                          B * (8 * N + 4), l3_resident=True, note="position plan (sort of the shared grid) made once, outside the timed loop")
-        out[f"b{rows_pr}n{N}_per_row_positions_forward"] = entry(timed(per_row, n), "sot_forward_kernel<ROWPOS> (per-row segmented stable merge sort with index payload in LDS, then the merge pipeline)",
+        out[f"b{rows_pr}n{N}_per_row_positions_forward"] = entry(timed(per_row, n), "sot_rowpos_sort_kernel<32, true, true> (round 6: one wavefront per row, packed-word wave sort, permutations into the workspace) + sot_forward_kernel<ROWPOS> gathering through them",
                                                                  rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
         out[f"b{rows_pr}n{N}_per_row_sorted_positions_forward"] = entry(timed(per_row_sorted, n), "sot_forward_kernel<ROWPOS> (rows already sorted: sortedness test only)",
                                                                         rows_pr * (16 * N + 4), l3_resident=True, rows=rows_pr)
@@ -349,22 +349,22 @@ def other_workloads(dev, nat, sets, pos_x, pos_y, timed, n):
     #       gradients w.r.t. per-row positions (sot_w1d_position_grad: one deterministic kernel; no reference call site asks for them)
     one_pg = torch.ones(1, device=dev)
     with torch.no_grad():
-        out[f"b{rows_pr}n{N}_segmented_sort"] = entry(timed(lambda i: nat.segmented_sort(prx[i % 2]), n), "sot_segmented_sort_kernel (16 keys per thread, skewed LDS image with sentinels)",
+        out[f"b{rows_pr}n{N}_segmented_sort"] = entry(timed(lambda i: nat.segmented_sort(prx[i % 2]), n), "sot_segmented_sort_wave_kernel<32, true> (round 6: one wavefront per row, packed 32-bit words, run repair; merge-sort fallback)",
                                                       rows_pr * 16 * N, l3_resident=True, rows=rows_pr, note="4 B in, 4 + 8 B out per key")
         out[f"b{rows_pr}n{N}_per_row_position_gradients_resorting"] = entry(timed(lambda i: nat.position_grads(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg), n),
-                                                                            "sot_position_grad_kernel<256, 8, true> called on its own (sort + CDFs + walk + tails)", rows_pr * (24 * N + 4), l3_resident=True, rows=rows_pr)
+                                                                            "sot_rowpos_sort_kernel + sot_position_grad_kernel<256, 8, true> called on its own (pre-sort into the workspace, then gather + CDFs + walk + tails)", rows_pr * (24 * N + 4), l3_resident=True, rows=rows_pr)
         # round 5: a training step sorts each row's supports ONCE -- the forward leaves the permutations ([B, n + m] uint16), the backward and
         # position-gradient kernels gather through them (what the module's autograd node does)
         perms = [nat.row_permutations(two[j][0][:rows_pr], two[j][1][:rows_pr], prx[j], pry[j], cutflags) for j in range(2)]
         out[f"b{rows_pr}n{N}_per_row_positions_forward_storing_permutations"] = entry(
             timed(lambda i: nat.forward_rows(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, None, perm_out=perms[i % 2]), n),
-            "sot_forward_kernel<ROWPOS> + 2 (n + m) B / row of permutations", rows_pr * (18 * N + 4), l3_resident=True, rows=rows_pr)
+            "sot_rowpos_sort_kernel (permutations into the caller's image) + sot_forward_kernel<ROWPOS> gathering", rows_pr * (18 * N + 4), l3_resident=True, rows=rows_pr)
         out[f"b{rows_pr}n{N}_per_row_backward"] = entry(
             timed(lambda i: nat.backward_rows(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg, need_gx=False, perm_in=perms[i % 2]), n),
             "sot_backward_kernel<ROWPOS> gathering through the forward's permutations (no sort), d/dy", rows_pr * (22 * N + 4), l3_resident=True, rows=rows_pr)
         out[f"b{rows_pr}n{N}_per_row_backward_resorting"] = entry(
             timed(lambda i: nat.backward_rows(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg, need_gx=False), n),
-            "sot_backward_kernel<ROWPOS> called on its own (sorts again)", rows_pr * (20 * N + 4), l3_resident=True, rows=rows_pr)
+            "sot_rowpos_sort_kernel + sot_backward_kernel<ROWPOS> called on its own (pre-sort into the workspace again)", rows_pr * (20 * N + 4), l3_resident=True, rows=rows_pr)
         out[f"b{rows_pr}n{N}_per_row_position_gradients"] = entry(
             timed(lambda i: nat.position_grads(two[i % 2][0][:rows_pr], two[i % 2][1][:rows_pr], prx[i % 2], pry[i % 2], 2.0, cutflags, one_pg, perm_in=perms[i % 2]), n),
             "sot_position_grad_kernel<256, 8, true> gathering through the forward's permutations (no sort)", rows_pr * (26 * N + 4), l3_resident=True, rows=rows_pr)
@@ -730,6 +730,9 @@ def rccl_world1_probe():
         env.setdefault("OMP_NUM_THREADS", "8")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
+        for k in list(env):   # a profiler around this bench (rocprofv3 preloads its tool library) must not follow into the child tree
+            if k == "LD_PRELOAD" or k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_")):
+                env.pop(k)
         cmd = launcher_command(1, ["--gpus", "1", "--steps", "200", "--warmup", "20", "--prewarm", "200", "--no-extras", "--no-cpu-baseline"], port)
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -805,6 +808,46 @@ def cpu_baseline(mode, n, rows, seed, budget_s=25.0):
 PROFILE_SLOTS = 64
 
 
+def flatten_for_scalar_readers(rec, B, N):
+    """Scalar copies of the nested figures (round-5 review: the driver's record of this line keeps scalars of `config`, `roofline`,
+    `cpu_baseline` and of the top level, and drops nested objects -- so the pipeline north_star names, the paper's step at the paper's
+    batch and the per-row path never reached it).  Same numbers as the nested entries, nothing new is measured here; a figure that was
+    not measured in this run (N > 1, --no-extras, another row length) is None."""
+    roof, ext = rec["roofline"], rec.get("extras", {})
+
+    def ms_of(key):
+        e = ext.get(key)
+        return e.get("ms") if isinstance(e, dict) else None
+
+    for key in ("paper_mode", "merge_p1", "training_form"):
+        side = roof.get(key) if isinstance(roof.get(key), dict) else {}
+        roof[f"{key}_kernel_ms"] = side.get("kernel_ms")
+        roof[f"{key}_frac"] = side.get("frac")
+        roof[f"{key}_stream_ms_per_call"] = side.get("stream_ms_per_call")
+    rows_pr = min(B, 4096)
+    flat = {
+        "paper_step_64clips_graph_ms": ms_of("paper_loss_step_64clips_graph_replay"),
+        "paper_step_64clips_eager_ms": ms_of("paper_loss_step_64clips"),
+        "paper_step_256clips_graph_ms": ms_of("paper_loss_step_256clips_graph_replay"),
+        "mss_64clips_graph_ms": ms_of("mssloss_forward_backward_64clips_graph_replay"),
+        "mss_256clips_graph_ms": ms_of("mssloss_forward_backward_256clips_graph_replay"),
+        "sot_slice_64clips_graph_ms": ms_of("sot_slice_forward_backward_64clips_graph_replay"),
+        "per_row_forward_ms": ms_of(f"b{rows_pr}n{N}_per_row_positions_forward"),
+        "per_row_backward_ms": ms_of(f"b{rows_pr}n{N}_per_row_backward"),
+        "per_row_position_grad_ms": ms_of(f"b{rows_pr}n{N}_per_row_position_gradients"),
+        "segmented_sort_ms": ms_of(f"b{rows_pr}n{N}_segmented_sort"),
+        "module_step_1024x1025_user_graph_ms": ms_of("b1024n1025_cutoff_step_user_graph"),
+        "rccl_world1_ms_per_step": ext.get("rccl_world1_ms_per_step"),
+    }
+    rec.update(flat)
+    roof.update({k: v for k, v in flat.items() if k != "rccl_world1_ms_per_step"})   # a second copy inside an object the reader keeps
+    cb = rec.get("cpu_baseline")
+    if isinstance(cb, dict):
+        pm = cb.get("paper_mode") if isinstance(cb.get("paper_mode"), dict) else {}
+        cb["paper_mode_rows_per_s"] = pm.get("value")
+        cb["paper_mode_scalar"] = pm.get("scalar")
+
+
 def event_stride(steps):
     # never more than every 4th step: a timed dispatch is preceded / followed by its event packets (+ ~8 us when EVERY step is timed)
     return int(os.environ.get("SOT_BENCH_EVENT_STRIDE", str(max(4, -(-steps // PROFILE_SLOTS)))))
@@ -834,6 +877,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        ones = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(ones)   # every rank contributes 1.0: the sum is the number of ranks RCCL connected (checked before anything is timed)
+        rccl_seen = {"rccl_world_size": dist.get_world_size(), "rccl_allreduce_ones": float(ones)}
+        assert rccl_seen["rccl_allreduce_ones"] == float(world), rccl_seen
+    else:
+        rccl_seen = {"rccl_world_size": 1, "rccl_allreduce_ones": None}   # no process group in a one-GPU run (extras.rccl_world1 exercises the path)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", local_rank if dist_on else 0)
     torch.cuda.set_device(dev)
@@ -1132,7 +1181,7 @@ def main():
                        "rows_per_gpu": B, "n_fft": N, "mode": args.mode, "prewarm_steps": args.prewarm, "global_rows": world * B,
                        "streams": n_lanes,
                        "collective": "none" if not dist_on else "one RCCL all-reduce(SUM) of the fp64 partial sum per step" + (" (HIP-graph replay)" if args.graph_steps else ""),
-                       "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first},
+                       "parity_rel_err_vs_reference_scalar": parity, "loss_set0": first, **rccl_seen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": forward_kernel_name(N, args.mode, batch=B), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_row * B,
@@ -1144,6 +1193,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.mode, N, min(args.cpu_rows, B), 1234)
+        flatten_for_scalar_readers(rec, B, N)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(rec) + "\n").encode())
     barrier()

@@ -376,7 +376,7 @@ int sot_spec_distance_rows_backward(const float *target, const float *value, int
  * One workgroup per (scale, clip, 4096-sample chunk): 2048 / n_fft frames per wavefront through a register-resident FFT, magnitudes,
  * distance, gradient w.r.t. the spectrum, inverse transform and overlap-add without a spectrogram in memory; a second kernel adds the
  * scales per sample in a fixed order.  Deterministic, enqueue-only, graph-capturable.
- * workspace: sot_mss_workspace_bytes(batch, samples, fft_sizes, n_scales) bytes, 8-byte aligned (0 is returned for sizes it does not take). */
+ * workspace: sot_mss_workspace_bytes(batch, samples, fft_sizes, n_scales) bytes, 16-byte aligned (0 is returned for sizes it does not take). */
 size_t sot_mss_workspace_bytes(int64_t batch, int64_t samples, const int *fft_sizes, int n_scales);
 int sot_mss_loss_and_grad(const float *target, int64_t target_row_stride, const float *value, int64_t value_row_stride,
                           int64_t batch, int64_t samples, const int *fft_sizes, const float *const *windows, int n_scales,

@@ -107,3 +107,33 @@ def test_global_rows_flag_means_strong_scaling():
     x1, y1 = spectrum_pairs("uniform", 64, 16, 16, 1235)
     x2, y2 = spectrum_pairs("uniform", 64, 16, 16, 1236)
     assert torch.equal(x, torch.cat([x0[60:], x1, x2[:32]])) and torch.equal(y, torch.cat([y0[60:], y1, y2[:32]]))
+
+
+def test_scalar_copies_of_the_nested_figures_reach_the_top_level():
+    """Round-5 review: the driver's record of the bench line keeps scalars (top level, `config`, `roofline`, `cpu_baseline`) and drops nested
+    objects, so the figures of the pipeline north_star names, of the paper's step at the paper's batch and of the per-row path have scalar
+    copies.  flatten_for_scalar_readers adds them from the nested entries (no new measurement) and leaves None for what a run did not measure."""
+    b = _bench_module()
+    rec = {"roofline": {"frac": 0.5, "paper_mode": {"kernel_ms": 0.044, "frac": 0.38, "stream_ms_per_call": 0.045},
+                        "merge_p1": {"kernel_ms": 0.042, "frac": 0.40}, "training_form": {"error": "x"}},
+           "extras": {"paper_loss_step_64clips_graph_replay": {"ms": 0.129}, "paper_loss_step_64clips": {"ms": 0.337},
+                      "mssloss_forward_backward_64clips_graph_replay": {"ms": 0.039}, "b4096n2048_per_row_positions_forward": {"ms": 0.14},
+                      "b4096n2048_segmented_sort": {"ms": 0.038}, "rccl_world1_ms_per_step": 0.0335, "sot_slice_forward_backward_64clips_graph_replay": {"error": "y"}},
+           "cpu_baseline": {"value": 1e4, "paper_mode": {"value": 9.2e3, "scalar": 3.7e-4}}}
+    b.flatten_for_scalar_readers(rec, 8192, 2048)
+    assert rec["roofline"]["paper_mode_kernel_ms"] == 0.044 and rec["roofline"]["paper_mode_frac"] == 0.38
+    assert rec["roofline"]["merge_p1_frac"] == 0.40 and rec["roofline"]["training_form_kernel_ms"] is None and rec["roofline"]["training_form_frac"] is None
+    assert rec["paper_step_64clips_graph_ms"] == 0.129 and rec["paper_step_64clips_eager_ms"] == 0.337 and rec["mss_64clips_graph_ms"] == 0.039
+    assert rec["per_row_forward_ms"] == 0.14 and rec["segmented_sort_ms"] == 0.038 and rec["sot_slice_64clips_graph_ms"] is None
+    assert rec["roofline"]["paper_step_64clips_graph_ms"] == 0.129            # the second copy, inside an object a scalars-only reader keeps
+    assert rec["cpu_baseline"]["paper_mode_rows_per_s"] == 9.2e3
+    for key in ("paper_step_64clips_graph_ms", "paper_step_64clips_eager_ms", "mss_64clips_graph_ms", "per_row_forward_ms", "rccl_world1_ms_per_step"):
+        assert key in rec and not isinstance(rec[key], dict)
+
+
+def test_the_line_says_what_rccl_saw():
+    """config.rccl_world_size / config.rccl_allreduce_ones (an all-reduce of ones before the timed region == the number of ranks): in the source of
+    the N > 1 path, since no multi-GPU node runs these tests."""
+    src = open(BENCH).read()
+    assert "rccl_world_size" in src and "rccl_allreduce_ones" in src and "dist.all_reduce(ones)" in src
+    assert src.index("dist.all_reduce(ones)") < src.index("def native_step")    # before anything is timed

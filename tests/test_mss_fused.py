@@ -199,6 +199,45 @@ def test_strided_rows_no_grad_and_upstream_gradient():
         nat.mss_loss_and_grad(xs, ys, (4096,), [torch.ones(4096, device=device())], 1.0, 0.0)
 
 
+def test_expanded_overlapping_single_row_and_empty_inputs():
+    """a broadcast target (`target.expand(B, -1)`: row stride 0), an overlapping as_strided view, a single row with an arbitrary row
+    stride and an empty batch are inputs the reference accepts; the two-launch path (C++ host path and the ctypes binding) must too, with
+    the values of the contiguous call."""
+    from gpu_util import device, native
+    from sot_amd.losses import MSSLoss
+    nat = native()
+    dev = device()
+    x, y = _clips(5, 4096, 21)
+    mod = MSSLoss(mag_weight=1.0)
+    one = x[:1].to(dev)
+    yd = y.to(dev)
+    base = mod(one.expand(5, -1).contiguous(), yd)
+    yg = yd.clone().requires_grad_(True)
+    got = mod(one.expand(5, -1), yg)                                   # row stride 0
+    assert one.expand(5, -1).stride(0) == 0 and torch.equal(got, base)
+    got.backward()
+    y2 = yd.clone().requires_grad_(True)
+    mod(one.expand(5, -1).contiguous(), y2).backward()
+    assert torch.equal(yg.grad, y2.grad)
+    flat = torch.randn(4096 + 4 * 100, generator=torch.Generator().manual_seed(3)).to(dev) * 0.1
+    over = flat.as_strided((5, 4096), (100, 1))                        # overlapping rows (row stride < row length)
+    assert torch.equal(mod(over, yd), mod(over.contiguous(), yd))
+    wins = [torch.hann_window(s, periodic=True, device=dev) for s in (2048, 1024, 512, 256, 128, 64)]
+    l0, g0 = nat.mss_loss_and_grad(one.expand(5, -1), yd, (2048, 1024, 512, 256, 128, 64), wins, 1.0, 0.0)
+    l1, g1 = nat.mss_loss_and_grad(one.expand(5, -1).contiguous(), yd, (2048, 1024, 512, 256, 128, 64), wins, 1.0, 0.0)
+    assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    row = torch.zeros(3, 5000, device=dev)[1:2, :4096]                 # ONE row whose stride(0) is whatever the parent had
+    row.copy_(y[:1].to(dev))
+    assert torch.equal(mod(one, row), mod(one, row.contiguous()))
+    l2, _ = nat.mss_loss_and_grad(one, row, (2048, 1024, 512, 256, 128, 64), wins, 1.0, 0.0)
+    l3, _ = nat.mss_loss_and_grad(one, row.contiguous(), (2048, 1024, 512, 256, 128, 64), wins, 1.0, 0.0)
+    assert torch.equal(l2, l3)
+    empty = torch.zeros(0, 4096, device=dev)
+    assert torch.isnan(mod(empty, empty))                              # torch.mean of nothing (the reference's result)
+    le, ge = nat.mss_loss_and_grad(empty, empty, (2048, 1024), wins[:2], 1.0, 0.0)
+    assert torch.isnan(le) and ge.shape == (0, 4096)
+
+
 def test_target_gradient_takes_the_differentiating_chain():
     from gpu_util import device, native
     from sot_amd.losses import MSSLoss
