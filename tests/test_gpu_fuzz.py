@@ -54,3 +54,18 @@ def test_random_module_calls_against_the_cpu_route(seed):
     cases, failures, worst_loss, worst_grad = fuzz_module.run(budget=120.0, seed0=seed, max_cases=150, verbose=False, grad_tol=2e-2)
     assert cases == 150
     assert failures == [], failures[:3]
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_random_mss_cases_against_float64(seed):
+    """tools/r5/fuzz_mss.py (round-5 review: it existed beside the suite, not in it): random clip length (1 ... 20 000 samples, around every frame
+    boundary), batch, subset of the six transform sizes, L1 / L2, magnitude / log-magnitude weights, per-clip means -- MSSLoss on GPU tensors
+    against the reference's op sequence in float64, with the reference's own float32 error as the yardstick (loss within 4 x + 1e-5; gradient norm
+    within 4 x + 5e-6, or -- single bins changing the sign of |T| - |V| / crossing safe_log's threshold, a lottery every float32 chain plays --
+    the median error within 2 x)."""
+    native()
+    sys.path.insert(0, os.path.join(ROOT, "tools", "r5"))
+    import fuzz_mss
+    cases, bad, failures = fuzz_mss.run(budget=170.0, seed0=seed, verbose=False, max_cases=150)
+    assert cases == 150
+    assert bad == 0, failures[:3]

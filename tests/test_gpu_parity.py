@@ -1223,35 +1223,40 @@ def test_config5_full_size_training_step_matches_reference():
     # rounds 2-3 (134 clean clips), 1.35e-3 with the one-wave-per-frame forward kernel of round 4 (139 clean clips; the backward kernel
     # does not change it: round 4 GPU call 13, docs/HISTORY.md §13))
     assert np.median(err[clean]) <= 5e-6 and np.percentile(err[clean], 99) <= 1e-4
-    # The maximum, PROVEN rather than allowed (round-4 review): every clean clip with an entry off by more than 1e-4 of its peak is re-evaluated
-    # with the REFERENCE'S arithmetic on the HIP kernels' OWN spectra -- C oracle backward (stable tie order) on the 16 rows, then torch.stft's
-    # autograd on the CPU.  (a) the HIP gradient must agree with that to 1e-4: nothing of the outlier is the kernels' own doing;
-    # (b) what remains, reference arithmetic on HIP spectra vs reference arithmetic on torch.stft spectra (two float32 STFTs, 3e-7 apart), is the
-    # conditioning of the reference's gradient itself: a 1-ulp perturbation of its own spectra that leaves every row loss within 1e-6 moves its
-    # audio gradient by up to 4.5e-3 of a clip's peak (median 3.9e-6; measured with the oracle over 64 clips x 3 seeds, round 5) -- the cap.
+    # THE KERNELS' PARITY STATEMENT, over ALL 256 clips (round-5 review; rounds 4-5 did this for the clean clips' outliers only and held the other
+    # 117 clips to a cosine): the whole batch is re-evaluated with the REFERENCE'S arithmetic on the HIP kernels' OWN spectra -- C oracle backward
+    # (stable tie order) on the 4096 rows, then torch.stft's autograd on the CPU -- and the HIP gradient must agree with that to 1e-4 of each
+    # clip's peak, clean or not: the cutoff's lottery (which rows a last-bit difference between two float32 STFTs flips) is then out of the
+    # kernels' statement altogether, because both sides see the same spectra.
     from oracle import sot_oracle as so
-    outliers = [int(c) for c in np.nonzero(clean)[0] if err[c].max() > 1e-4]
-    assert len(outliers) <= 24, len(outliers)
     with torch.no_grad():
-        hip_t = spectra.stft_magnitude(target.to(dev)).cpu().numpy()
-        hip_e = spectra.stft_magnitude(estimate.to(dev)).cpu().numpy()
+        hip_t = spectra.stft_magnitude(target.to(dev)).cpu().numpy().reshape(4096, 1025)
+        hip_e = spectra.stft_magnitude(estimate.to(dev)).cpu().numpy().reshape(4096, 1025)
     pos_np = spectra.unit_frequencies(2048, 16000.0, "cpu").numpy()
     oflags = so.make_flags(True, True, True, True)
-    own_max = cond_max = 0.0
+    _, gspec = so.backward(hip_t, hip_e, pos_np, pos_np, np.full(4096, 1.0 / 4096, np.float32), p=2.0, flags=oflags)
+    e_cpu = estimate.clone().requires_grad_(True)
+    (spectra.stft_magnitude_torch(e_cpu) * torch.as_tensor(gspec).reshape(256, 16, 1025)).sum().backward()
+    via_ref_full = e_cpu.grad.numpy().astype(np.float64)
+    got_full = est.grad.cpu().numpy().astype(np.float64)
+    peak_full = np.abs(via_ref_full).max(axis=1, keepdims=True)
+    own = np.abs(got_full - via_ref_full).max(axis=1) / peak_full[:, 0]
+    print(f"config 5, all 256 clips, HIP vs the reference's arithmetic on the HIP spectra: max {own.max():.2e}, median {np.median(own):.2e} of the clip's peak "
+          f"(clean clips max {own[clean].max():.2e}, the other {int((~clean).sum())} max {own[~clean].max() if (~clean).any() else 0:.2e})")
+    assert own.max() <= 1e-4, (int(own.argmax()), float(own.max()))
+    # Second: against the reference FIXTURE (its own spectra).  What remains between the two is reference arithmetic on HIP spectra vs reference
+    # arithmetic on torch.stft spectra (two float32 STFTs, 3e-7 apart): the conditioning of the reference's gradient itself -- a 1-ulp perturbation
+    # of its own spectra that leaves every row loss within 1e-6 moves its audio gradient by up to 4.5e-3 of a clip's peak (median 3.9e-6; measured
+    # with the oracle over 64 clips x 3 seeds, round 5).  On the clean clips every outlier beyond 1e-4 must BE that conditioning.
+    via_ref = via_ref_full[:, ::stride]
+    cond = np.abs(via_ref - ref).max(axis=1) / clip_peak[:, 0]
+    outliers = [int(c) for c in np.nonzero(clean)[0] if err[c].max() > 1e-4]
+    assert len(outliers) <= 24, len(outliers)
     for c in outliers:
-        _, gspec = so.backward(hip_t[c], hip_e[c], pos_np, pos_np, np.full(16, 1.0 / 4096, np.float32), p=2.0, flags=oflags)
-        e = estimate[c:c + 1].clone().requires_grad_(True)
-        (spectra.stft_magnitude_torch(e)[0] * torch.as_tensor(gspec)).sum().backward()
-        via_ref = e.grad[0, ::stride].numpy().astype(np.float64)
-        own = float(np.abs(got[c] - via_ref).max() / clip_peak[c, 0])
-        cond = float(np.abs(via_ref - ref[c]).max() / clip_peak[c, 0])
-        own_max, cond_max = max(own_max, own), max(cond_max, cond)
-        assert own <= 1e-4, (c, own, cond)
-        assert abs(float(err[c].max()) - cond) <= 2e-4, (c, float(err[c].max()), cond)     # the outlier IS the reference's conditioning
-    print(f"config 5 outliers: {len(outliers)} clean clips beyond 1e-4; HIP vs reference arithmetic on HIP spectra <= {own_max:.2e}; "
-          f"reference arithmetic, HIP spectra vs torch.stft spectra <= {cond_max:.2e}")
+        assert abs(float(err[c].max()) - cond[c]) <= 2e-4, (c, float(err[c].max()), float(cond[c]))
+    print(f"config 5 vs the fixture: {len(outliers)} clean clips beyond 1e-4, each explained by the reference's conditioning (<= {max([cond[c] for c in outliers], default=0.0):.2e}); "
+          f"overall cosine {cos:.6f} (reported, not asserted: flipped rows move single clips)")
     assert err[clean].max() <= 5e-3
-    assert cos >= 0.99                                        # all clips: flipped rows move single clips, not the batch
 
 
 @pytest.mark.gpu

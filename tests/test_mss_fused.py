@@ -29,7 +29,13 @@ def _mss_torch(mod, x, y, dims, dtype):
     l2 = mod.loss_type.upper() == "L2"
     for size in mod.fft_sizes:
         hop = int(size * 0.25)
-        win = torch.hann_window(size).to(dtype)
+        # the window the reference uses for tensors on the module's device (utils.py:200-201: torch.hann_window(frame_size, device=audio.device)), as
+        # float32 VALUES: torch computes it on that device, and its first taps -- 0.5 - 0.5 cos(2 pi k / N), relative rounding error 1e-5 ... 1e-4 in
+        # float32 -- differ between a CPU and a GPU evaluation in the last bits.  A clip shorter than a frame meets only those taps, and a
+        # log-magnitude term turns that into 2e-5 of the gradient's norm: the round-5 'accuracy hole' was this yardstick's CPU window
+        # (tools/r6/mss_debug.py: 2.1e-5 against the CPU window, 2.3e-6 against the device's, torch.stft's own float32 error 1.2e-6).
+        from gpu_util import device
+        win = torch.hann_window(size, device=device()).cpu().to(dtype)
 
         def mag(a):
             a = spectra.end_padded(a.to(dtype), size, hop)
@@ -53,7 +59,7 @@ def _reference(mod, x, y, dims=None, weights=None, dtype=torch.float64):
     return out.detach(), yy.grad
 
 
-def _check(mod, x, y, dims=None, weights=None, loss_tol=1e-5):
+def _check(mod, x, y, dims=None, weights=None, loss_tol=1e-5, grad_factor=1.5):
     from gpu_util import device
     want64, g64 = _reference(mod, x, y, dims, weights)
     want32, g32 = _reference(mod, x, y, dims, weights, torch.float32)
@@ -69,11 +75,9 @@ def _check(mod, x, y, dims=None, weights=None, loss_tol=1e-5):
     g = yd.grad.cpu().double()
     ref_err = float(torch.linalg.norm(g32.double() - g64) / torch.linalg.norm(g64))
     hip_err = float(torch.linalg.norm(g - g64) / torch.linalg.norm(g64))
-    # the HIP gradient is as close to float64 as the reference's own float32 gradient is.  Per scale and in most cases the two errors are
-    # equal (3e-6; tools/r5/mss_accuracy.py); a bin whose |V| sits at the rounding floor hands its gradient g V / |V| a direction that is noise
-    # in ANY float32 FFT -- there both errors jump (reference 2.4e-5, HIP 4e-5 ... 9e-5 depending on the rounding of the products: observed at
-    # one bin of n_fft 128 in the 5 x 4096 case), hence the factor 4 rather than 1.5
-    assert hip_err <= 4.0 * ref_err + 5e-6, (hip_err, ref_err)
+    # the HIP gradient is as close to float64 as the reference's own float32 gradient is: 1.5 x its error (per scale and in most cases the two
+    # errors are equal, 3e-6; tools/r5/mss_accuracy.py).  grad_factor: the cases that need more name themselves and say why.
+    assert hip_err <= grad_factor * ref_err + 5e-6, (hip_err, ref_err)
     med_hip = float((g - g64).abs().median() / g64.abs().max())
     med_ref = float((g32.double() - g64).abs().median() / g64.abs().max())
     assert med_hip <= 1.5 * med_ref + 1e-8, (med_hip, med_ref)
@@ -96,7 +100,10 @@ def test_clip_lengths_and_chunks(samples, batch):
     from sot_amd.losses import MSSLoss
     native()
     x, y = _clips(batch, samples, samples)
-    _check(MSSLoss(mag_weight=1.0), x, y)
+    # THE NAMED EXCEPTION to the 1.5 x criterion: in the 5 x 4096 case ONE bin of n_fft 128 has |V| at the rounding floor, where the direction
+    # V / |V| of its gradient is noise in ANY float32 FFT -- both errors jump there (reference 2.4e-5, HIP 4e-5 ... 9e-5 depending on how the
+    # products round), and the criterion is 4 x for this case alone (the median criterion, which single bins do not move, stays at 1.5 x)
+    _check(MSSLoss(mag_weight=1.0), x, y, grad_factor=4.0 if (samples, batch) == (4096, 5) else 1.5)
 
 
 @pytest.mark.parametrize("kw", [dict(mag_weight=1.0, logmag_weight=0.5), dict(mag_weight=0.7, logmag_weight=0.3, loss_type="L2"),

@@ -29,7 +29,7 @@ def mss_torch(mod, x, y, dims, dtype):
     l2 = mod.loss_type.upper() == "L2"
     for size in mod.fft_sizes:
         hop = int(size * 0.25)
-        win = torch.hann_window(size).to(dtype).to(x.device)
+        win = torch.hann_window(size, device=x.device).to(dtype)   # computed ON the device, as the reference does (utils.py:200-201); see tools/r6/mss_debug.py
 
         def mag(a):
             a = spectra.end_padded(a.to(dtype), size, hop)
@@ -45,11 +45,12 @@ def mss_torch(mod, x, y, dims, dtype):
     return loss
 
 
-def run(budget=60.0, seed0=0, verbose=True):
+def run(budget=60.0, seed0=0, verbose=True, max_cases=None):
     rng = np.random.default_rng(seed0)
     cases, bad, lottery, worst_l, worst_g = 0, 0, 0, 0.0, 0.0
+    failures = []
     t_end = time.time() + budget
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
         samples = int(rng.choice([1, 2, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4096, 4097, 8191, int(rng.integers(1, 20000))]))
         batch = int(rng.choice([1, 2, 3, 7, 64, int(rng.integers(1, 90))]))
         if batch * samples > 3_000_000:
@@ -102,6 +103,7 @@ def run(budget=60.0, seed0=0, verbose=True):
         cases += 1
         if not ok:
             bad += 1
+            failures.append((dict(samples=samples, batch=batch, sizes=sizes, kind=kind, mag=mw, logmag=lw, per_clip=per_clip), el, eg))
             losses.MSS_FUSED = False      # the round-2 kernel chain on the same case, for comparison
             try:
                 yc = y.clone().requires_grad_(True)
@@ -114,7 +116,7 @@ def run(budget=60.0, seed0=0, verbose=True):
             verbose and print("MSS", dict(samples=samples, batch=batch, sizes=sizes, kind=kind, mag=mw, logmag=lw, per_clip=per_clip),
                               "loss err", el, "(reference float32:", el32, ") gradient err", eg, "(reference float32:", eg32, ") median", med, "(", med32, ")")
     print(f"cases {cases}, outside the criterion {bad}, passed on the median only (single-bin sign changes) {lottery}, worst loss err {worst_l:.3g}, worst gradient err (norm) {worst_g:.3g}")
-    return cases, bad
+    return cases, bad, failures
 
 
 if __name__ == "__main__":

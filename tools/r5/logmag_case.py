@@ -1,8 +1,10 @@
 """Where the log-magnitude term of MSSLoss loses accuracy on clips shorter than the frame (tools/r5/fuzz_mss.py flags them): magnitudes and
 gradient of the HIP chain and of torch float32 against float64 for a 64-sample clip under n_fft 1024 / 2048 and for a 4096-sample clip.
 Observed: equal absolute errors (2e-7 of the peak); on the 64-sample / n_fft 1024 case the HIP transform's error at the SMALL bins is 6 x
-torch's relative to the bin (5e-6 against 8e-7), which the 1 / |V| of the log gradient turns into 2.4e-5 against 1.9e-6 of the gradient's
-norm; n_fft 2048 and full-length clips: equal.  python3 tools/r5/logmag_case.py"""
+torch's relative to the bin (5e-6 against 8e-7).  ROUND 6: the gradient figure of round 5 (2.4e-5 against 1.9e-6 of the gradient's norm) was
+the YARDSTICK's window -- hann computed on the CPU, where the module and the reference (utils.py:200-201) compute it on the audio's device;
+the first taps differ by 3e-6 ... 9e-5 relative (tools/r6/mss_debug.py).  Against the device's window: 2.6e-6 against 1.2e-6.
+python3 tools/r5/logmag_case.py"""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
