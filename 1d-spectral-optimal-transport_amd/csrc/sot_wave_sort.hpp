@@ -35,6 +35,9 @@
 #ifndef SOT_WSORT_GROUP
 #define SOT_WSORT_GROUP 8   /* registers per cross-lane group (moves in flight) */
 #endif
+#ifndef SOT_WSORT_TRANSPOSE_MIN
+#define SOT_WSORT_TRANSPOSE_MIN 4   /* merges whose largest lane distance S / 4 is at least this run their lane stages on the transposed layout (64: never) */
+#endif
 #ifndef SOT_WSORT_FENCED
 #define SOT_WSORT_FENCED 1
 #endif
@@ -135,9 +138,28 @@ __device__ __forceinline__ void wsort_lane_tail(uint32_t (&w)[KPL], int lane, ui
     }
 }
 
+// 32 registers x 64 lanes: register r of lane l <-> register (l & 31) of lane (l & 32) + r, through `scratch` (LDS byte address of
+// 2112 dwords owned by this wavefront).  An involution: blocked layout (position = 32 l + r) -> transposed layout (lane L, register R
+// hold position 32 (32 (L >> 5) + R) + (L & 31)) and back.  Position p lives at dword p + p / 32: the store (lanes 33 dwords apart) and
+// the load (consecutive lanes on consecutive dwords) both touch 32 banks per half wave.
+__device__ __forceinline__ void wsort_transpose32(uint32_t (&w)[32], int lane, uint32_t scratch)
+{
+    const uint32_t blocked = scratch + 4u * 33u * (uint32_t)lane;                                  // position 32 l + r     at 33 l + r
+    const uint32_t crossed = scratch + 4u * (33u * 32u * (uint32_t)(lane >> 5) + (uint32_t)(lane & 31));   // position 32 (32 h + R) + c  at 33 (32 h + R) + c
+    // (the caller's layout decides which map stores and which loads; both are bijections onto the same image, so a wave that stored with one and
+    //  loads with the other has exchanged the two index fields -- twice is the identity)
+#pragma unroll
+    for (int r = 0; r < 32; ++r) lds_st_u32(blocked + 4u * (uint32_t)r, w[r]);
+    row_sync<1>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) w[r] = lds_ld_u32(crossed + 4u * 33u * (uint32_t)r);
+    row_sync<1>();
+    SOT_WSORT_STAGE_FENCE();
+}
+
 // merges across lanes: runs of (S / 2) KPL -> S KPL, S = 2 ... 64
 template <int KPL, int S>
-__device__ __forceinline__ void wsort_lane_merges(uint32_t (&w)[KPL], int lane, uint32_t addr63)
+__device__ __forceinline__ void wsort_lane_merges(uint32_t (&w)[KPL], int lane, uint32_t addr63, uint32_t scratch)
 {
     if constexpr (S <= 64) {
         // flip: partner (lane ^ (S - 1), KPL - 1 - r); registers r and KPL - 1 - r only need each other: groups of pairs
@@ -156,19 +178,29 @@ __device__ __forceinline__ void wsort_lane_merges(uint32_t (&w)[KPL], int lane, 
                 SOT_WSORT_STAGE_FENCE();
             }
         }
-        wsort_lane_tail<KPL, S / 4>(w, lane, addr63);
+        if constexpr (KPL == 32 && S / 4 >= SOT_WSORT_TRANSPOSE_MIN) {
+            // The half cleaners between lanes at distances S / 4 ... 1 (lane bits 4 ... 0) as exchanges between REGISTERS: the lane's low five
+            // bits and the register index change places through the skewed LDS image (one store + one load per key each way, immediate
+            // offsets, bank-conflict-free both ways), the stages run as one VALU instruction per key instead of a move + a v_med3, and the
+            // image is read back in the blocked layout.  Pays from three stages on: 2 x 3 ... 5 VALU per key against 4 LDS operations.
+            wsort_transpose32(w, lane, scratch);
+            wsort_reg_tail<KPL, S / 4>(w);
+            wsort_transpose32(w, lane, scratch);
+        } else {
+            wsort_lane_tail<KPL, S / 4>(w, lane, addr63);
+        }
         wsort_reg_tail<KPL, KPL / 2>(w);
-        wsort_lane_merges<KPL, 2 * S>(w, lane, addr63);
+        wsort_lane_merges<KPL, 2 * S>(w, lane, addr63, scratch);
     }
 }
 
 // the whole network: w[r] of lane l is position l KPL + r afterwards
 template <int KPL>
-__device__ __forceinline__ void wsort_network(uint32_t (&w)[KPL], int lane)
+__device__ __forceinline__ void wsort_network(uint32_t (&w)[KPL], int lane, uint32_t scratch)
 {
     const uint32_t addr63 = (uint32_t)(lane ^ 63) << 2;
     wsort_reg_sort<KPL>(w);
-    wsort_lane_merges<KPL, 2>(w, lane, addr63);
+    wsort_lane_merges<KPL, 2>(w, lane, addr63, scratch);
 }
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -252,7 +284,9 @@ __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyo
                                   : (((q << (IDXBITS - 6)) + (uint32_t)r) << 6) + low[0];
         w[r] = full ? word : (word | pad_mask(r));   // every pad is the same word 0xFFFFFFFF: behind the data, never a run
     }
-    wsort_network<KPL>(w, lane);
+#if !defined(SOT_WSORT_DIAG_SKIP_NETWORK)   /* diagnostic (timing only, results are wrong): everything but the network */
+    wsort_network<KPL>(w, lane, lds_addr(idx));
+#endif
     // ---- neighbours that share q: (a ^ b) - 1 < MASK (a == b: two pads)
     uint32_t cmin = 0xFFFFFFFFu;
 #pragma unroll

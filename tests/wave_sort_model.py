@@ -57,6 +57,28 @@ def med3(a, b, c):
     return np.maximum(np.minimum(a, b), np.minimum(np.maximum(a, b), c))
 
 
+TRANSPOSE_MIN = 4        # sot_wave_sort.hpp: SOT_WSORT_TRANSPOSE_MIN
+
+
+def transpose32(w, count):
+    """register r of lane l <-> register (l & 31) of lane (l & 32) + r through the skewed image (position p at p + p / 32), as the kernel:
+    store with the blocked map (lane l, register r at 33 l + r), load with the crossed map (lane L, register R at 33 (32 (L >> 5) + R) + (L & 31))"""
+    lane = np.arange(64)
+    image = np.zeros(64 * 33 + 2, np.uint32)
+    for r in range(32):
+        addr = 33 * lane + r
+        assert len(set((addr[:32] % 32).tolist())) == 32 and len(set((addr[32:] % 32).tolist())) == 32
+        image[addr] = w[:, r]
+        count("lds_store")
+    out = np.empty_like(w)
+    for r in range(32):
+        addr = 33 * (32 * (lane >> 5) + r) + (lane & 31)
+        assert len(set((addr[:32] % 32).tolist())) == 32 and len(set((addr[32:] % 32).tolist())) == 32
+        out[:, r] = image[addr]
+        count("lds_load")
+    return out
+
+
 def network(w, kpl, stats=None):
     """the bitonic network on w[lane, r] (position = lane * kpl + r); returns the sorted image in the same layout"""
     w = w.copy()
@@ -69,7 +91,7 @@ def network(w, kpl, stats=None):
     def ce_regs(j_pairs):
         for a, b in j_pairs:
             lo, hi = np.minimum(w[:, a], w[:, b]), np.maximum(w[:, a], w[:, b])
-            w[:, a], w[:, b] = lo, hi
+            w[:, a], w[:, b] = lo, hi          # (in place: `w` is rebound by the cross-lane stages, and this closure follows the rebinding)
             count("valu_inreg", 2)
 
     def bound(bit):
@@ -103,16 +125,23 @@ def network(w, kpl, stats=None):
             new[:, r] = med3(w[:, r], src[:, kpl - 1 - r], b)
             count("move"); count("valu_med3")
         w = new
-        d = s >> 2
-        while d >= 1:                      # half cleaners between lanes at distance d
-            src = lane_xor(w, d)
-            b = bound(d)
-            new = np.empty_like(w)
-            for r in range(kpl):
-                new[:, r] = med3(w[:, r], src[:, r], b)
-                count("move"); count("valu_med3")
-            w = new
-            d >>= 1
+        if kpl == 32 and (s >> 2) >= TRANSPOSE_MIN:
+            # the lane stages at distances s / 4 ... 1 as exchanges between REGISTERS on the transposed layout (the lane's low five bits and the
+            # register index change places through the skewed LDS image), then back
+            w = transpose32(w, count)
+            tail(s >> 2)
+            w = transpose32(w, count)
+        else:
+            d = s >> 2
+            while d >= 1:                  # half cleaners between lanes at distance d
+                src = lane_xor(w, d)
+                b = bound(d)
+                new = np.empty_like(w)
+                for r in range(kpl):
+                    new[:, r] = med3(w[:, r], src[:, r], b)
+                    count("move"); count("valu_med3")
+                w = new
+                d >>= 1
         tail(kpl >> 1)
         s <<= 1
     return w
