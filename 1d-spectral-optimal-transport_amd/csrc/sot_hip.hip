@@ -296,18 +296,50 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
     bool gather = perm_in != nullptr && c.do_sort;
     if (gather && nmax >= 2) gather = !row_any<G / kWave>(perm_in[0] == perm_in[1]);
     if (gather) {            // uniform over the threads that share barriers
+        // The row's positions arrive COALESCED (element t + k G per thread), are staged in natural order in the U / V regions (free until the
+        // weights arrive) and gathered from LDS through the permutation: 16 scattered 4-byte loads per thread from global memory -- up to 64
+        // cache lines per wave instruction -- cost the gathering forward 83 us where rows that arrive sorted take 71 (4096 x 2048, round 6).
+        float vx[CPT], vy[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t + k * G;
+            vx[k] = (e < n) ? xp[e] : 0.0f;
+            vy[k] = (e < m) ? yp[e] : 0.0f;
+        }
+        // this thread's CPT consecutive entries of each permutation: one 16-byte load where eight 16-bit entries are 16-byte aligned
+        const bool vec = CPT == 8 && ((n | m) & 7) == 0 && (reinterpret_cast<uintptr_t>(perm_in) & 15) == 0;
+        if (vec) {
+            uint4 qx = make_uint4(0, 0, 0, 0), qy = make_uint4(0, 0, 0, 0);
+            if (t * CPT < n) qx = *reinterpret_cast<const uint4*>(perm_in + t * CPT);
+            if (t * CPT < m) qy = *reinterpret_cast<const uint4*>(perm_in + n + t * CPT);
+            const uint32_t wx[4] = {qx.x, qx.y, qx.z, qx.w}, wy[4] = {qy.x, qy.y, qy.z, qy.w};
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int e = t * CPT + k;
+                ix[k] = (e < n) ? (int)((wx[(k >> 1) & 3] >> (16 * (k & 1))) & 0xFFFFu) : e;
+                iy[k] = (e < m) ? (int)((wy[(k >> 1) & 3] >> (16 * (k & 1))) & 0xFFFFu) : e;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int e = t * CPT + k;
+                ix[k] = (e < n) ? (int)perm_in[e] : e;
+                iy[k] = (e < m) ? (int)perm_in[n + e] : e;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = t + k * G;
+            if (e < n) c.U[e] = vx[k];
+            if (e < m) c.V[e] = vy[k];
+        }
+        row_sync<G / kWave>();
         float gx[CPT], gy[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int e = t * CPT + k;
-            ix[k] = (e < n) ? (int)perm_in[e] : e;
-            iy[k] = (e < m) ? (int)perm_in[n + e] : e;
-        }
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int e = t * CPT + k;
-            gx[k] = (e < n) ? xp[ix[k]] : 0.0f;
-            gy[k] = (e < m) ? yp[iy[k]] : 0.0f;
+            gx[k] = (e < n) ? c.U[min(ix[k], n - 1)] : 0.0f;     // (clamped: a stale or foreign image must not become a wild LDS address)
+            gy[k] = (e < m) ? c.V[min(iy[k], m - 1)] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
