@@ -31,7 +31,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 10                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 11                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p

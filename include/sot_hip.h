@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 10   /* bumped on every change of a signature below; the binding checks it */
+#define SOT_ABI_VERSION 11   /* bumped on every change of a signature or of a buffer contract below; the binding checks it
+                              * (11, round 6: sot_workspace_bytes covers the per-row pre-sort; the MSS workspace is 16-byte aligned) */
 
 typedef enum sot_status {
     SOT_OK = 0,
@@ -92,7 +93,12 @@ typedef struct sot_problem {
      * ONCE per training step.  row_perm_out (or NULL): a call that sorts stores each row's two sort permutations here, [B, n + m] uint16 (the n
      * original columns of x's sorted supports, then the m of y's; n, m <= 16384).  row_perm_in (or NULL): permutations an earlier call produced
      * for the SAME position tensors -- sot_w1d_backward / sot_w1d_position_grad (and the forward itself) then gather the sorted supports
-     * through them instead of sorting again.  Ignored for shared positions. */
+     * through them instead of sorting again.  Ignored for shared positions.
+     * Round 6: rows of 2 ... 2048 positions are sorted AHEAD of the row kernel by a kernel of their own (one wavefront per row, a packed-word
+     * network in registers: csrc/sot_wave_sort.hpp) whenever there is a place for the permutations -- row_perm_out, else the call's workspace
+     * when it holds sot_workspace_bytes() bytes, else the row kernel sorts in LDS as before.  An image that kernel wrote may hold a SENTINEL
+     * row (first two entries 0xFFFF: both arrays arrived sorted, or clustered / non-finite positions): a row kernel handed such an image treats
+     * that row as unsorted input, and a forward whose row_perm_out it is stores the real permutations over the sentinel. */
     uint16_t *row_perm_out;
     const uint16_t *row_perm_in;
 } sot_problem;
@@ -100,7 +106,10 @@ typedef struct sot_problem {
 int sot_abi_version(void);
 const char *sot_status_string(int status);
 
-/* Bytes of device workspace the calls below need for this problem (host-side arithmetic only). */
+/* Bytes of device workspace the calls below need for this problem (host-side arithmetic only).  Shared positions with
+ * SOT_FLAG_REQUIRE_SORT and no plan: required.  Per-row positions with SOT_FLAG_REQUIRE_SORT and neither row_perm_in nor row_perm_out
+ * (round 6): room for the pre-sort's [B, n + m] uint16 permutations -- OPTIONAL: a call with a smaller (or no) workspace sorts inside the
+ * row kernel.  0 otherwise. */
 size_t sot_workspace_bytes(const sot_problem *prob);
 
 /*
