@@ -1856,23 +1856,26 @@ __global__ __launch_bounds__(1024) void sot_segmented_sort_kernel(const float* _
 // wavefront with the merge sort.  Four independent rows per 256-thread workgroup; the next row's keys are fetched while the
 // current one is stored.  FAST: n == 64 KPL, rows and outputs 16-byte aligned -- no validity tests, 16-byte loads and stores.
 // ---------------------------------------------------------------------------------------------
+// LDS dwords of a row's key array (natural keys; the merge-sort fallback's skewed image) and of its index / scratch array (either sort's)
 template <int KPL>
-__host__ __device__ constexpr int wave_sort_row_cap()   // LDS dwords of ONE of the two arrays of a row (key | idx): fits either sort
-{
-    return align4(imax(sort16_capacity(sort16_npad(64 * KPL)), wave_sort_scratch(KPL)));
-}
+__host__ __device__ constexpr int wave_sort_key_cap() { return align4(sort16_capacity(sort16_npad(64 * KPL))); }
+template <int KPL>
+__host__ __device__ constexpr int wave_sort_idx_cap() { return align4(imax(sort16_capacity(sort16_npad(64 * KPL)), wave_sort_scratch(KPL))); }
+// waves per workgroup (the segmented sort runs the network: 17.4 KB per wave, two workgroups per CU; its 16 B per key of traffic bound it)
+template <int KPL>
+__host__ __device__ constexpr int wave_sort_wg_waves() { return 4; }
 
 template <int KPL, bool FAST>
-__global__ __launch_bounds__(256, 2) void sot_segmented_sort_wave_kernel(const float* __restrict__ keys, int64_t B, int n, int64_t stride,
+__global__ __launch_bounds__(64 * wave_sort_wg_waves<KPL>(), 2) void sot_segmented_sort_wave_kernel(const float* __restrict__ keys, int64_t B, int n, int64_t stride,
                                                                          float* __restrict__ out_keys, int64_t* __restrict__ out_idx)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NPAD = 64 * KPL, CAP = wave_sort_row_cap<KPL>();
+    constexpr int NPAD = 64 * KPL, KCAP = wave_sort_key_cap<KPL>(), ICAP = wave_sort_idx_cap<KPL>(), WGW = wave_sort_wg_waves<KPL>();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* key = smem + wv * 2 * CAP;
-    uint32_t* idx = reinterpret_cast<uint32_t*>(key + CAP);
-    const int64_t step = (int64_t)gridDim.x * 4;
-    int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    float* key = smem + wv * (KCAP + ICAP);
+    uint32_t* idx = reinterpret_cast<uint32_t*>(key + KCAP);
+    const int64_t step = (int64_t)gridDim.x * WGW;
+    int64_t row = (int64_t)blockIdx.x * WGW + wv;
     float x[KPL];
     auto fetch = [&](int64_t rw) {
         const float* src = keys + rw * stride;
@@ -1941,7 +1944,8 @@ __global__ __launch_bounds__(256, 2) void sot_segmented_sort_wave_kernel(const f
 template <int KPL>
 int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stride, float* out_keys, int64_t* out_idx, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)wave_sort_row_cap<KPL>() * 8 * 4;   // 4 waves x (key | idx)
+    constexpr int WGW = wave_sort_wg_waves<KPL>();
+    constexpr size_t lds = (size_t)(wave_sort_key_cap<KPL>() + wave_sort_idx_cap<KPL>()) * 4 * WGW;   // waves x (key | idx)
     constexpr bool CAN_VEC = KPL % 4 == 0;
     const bool fast = CAN_VEC && n == 64 * KPL && stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(out_keys) |
                                                                      reinterpret_cast<uintptr_t>(out_idx)) & 15) == 0;
@@ -1950,13 +1954,13 @@ int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stri
                           : reinterpret_cast<const void*>(sot_segmented_sort_wave_kernel<KPL, false>);
     allow_full_lds_once(cache[fast ? 1 : 0], fn);
     int per_cu = (int)(kLdsLimit / lds);
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 16 / WGW) per_cu = 16 / WGW;
     if (per_cu < 1) per_cu = 1;
-    const int64_t groups = (B + 3) / 4, cap = (int64_t)device_cu_count() * per_cu;
+    const int64_t groups = (B + WGW - 1) / WGW, cap = (int64_t)device_cu_count() * per_cu;
     const int grid = (int)(groups < cap ? groups : cap);
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
-    if (fast) hipLaunchKernelGGL((sot_segmented_sort_wave_kernel<KPL, CAN_VEC>), dim3(grid), dim3(256), lds, s, keys, B, n, stride, out_keys, out_idx);
-    else hipLaunchKernelGGL((sot_segmented_sort_wave_kernel<KPL, false>), dim3(grid), dim3(256), lds, s, keys, B, n, stride, out_keys, out_idx);
+    if (fast) hipLaunchKernelGGL((sot_segmented_sort_wave_kernel<KPL, CAN_VEC>), dim3(grid), dim3(64 * WGW), lds, s, keys, B, n, stride, out_keys, out_idx);
+    else hipLaunchKernelGGL((sot_segmented_sort_wave_kernel<KPL, false>), dim3(grid), dim3(64 * WGW), lds, s, keys, B, n, stride, out_keys, out_idx);
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -1972,8 +1976,11 @@ int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stri
 // (sortedness test, in-LDS merge sort) -- and, when the image is the caller's row_perm_out, stores the real permutations over it.
 // ---------------------------------------------------------------------------------------------
 constexpr uint16_t kRowPermSentinel = 0xFFFFu;
+#ifndef SOT_ROWPOS_SORT_MAX_WG
+#define SOT_ROWPOS_SORT_MAX_WG 4
+#endif
 #ifndef SOT_ROWPOS_SORT_WAVES
-#define SOT_ROWPOS_SORT_WAVES 4   /* wavefronts per SIMD the pre-sort kernel is compiled for */
+#define SOT_ROWPOS_SORT_WAVES 2   /* wavefronts per SIMD the pre-sort kernel is compiled for (LDS: 16.9 KB per wave of the 32-keys-per-lane form = 8 waves per CU) */
 #endif
 
 // VEC: n, m multiples of 4, position rows 16-byte aligned, permutation rows 8-byte aligned (16-byte loads, 8-byte stores); FULL: n == m == 64 KPL
@@ -1982,7 +1989,7 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
                                                                  int64_t xps, int64_t yps, uint16_t* __restrict__ perm)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SCR = align4(wave_sort_scratch(KPL));
+    constexpr int SCR = align4(wave_sort_scratch(KPL, true));
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* const idx = reinterpret_cast<uint32_t*>(smem) + wv * SCR;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < B; row += (int64_t)gridDim.x * 4) {
@@ -2028,7 +2035,7 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
             }
             if (__builtin_amdgcn_ballot_w64(unsorted) == 0ull) continue;
             float sk[KPL]; uint32_t si[KPL];
-            const bool done = wave_sort_core<KPL, false, FULL, VEC, false>(x, [src](uint32_t i) { return src[i]; }, nullptr, idx, len, lane, sk, si);
+            const bool done = wave_sort_core<KPL, false, FULL, VEC, false, true>(x, [src](uint32_t i) { return src[i]; }, nullptr, idx, len, lane, sk, si);
             row_sync<1>();   // the scratch image is free again
             if (!done) { states |= 2 << (2 * which); continue; }
             states |= 1 << (2 * which);
@@ -2068,11 +2075,11 @@ int launch_rowpos_sort(const float* xpos, const float* ypos, int64_t B, int n, i
                          (reinterpret_cast<uintptr_t>(dest) & 7) == 0 && (n & 3) == 0 && (m & 3) == 0;
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     auto go = [&](auto kern, int kpl) {
-        const size_t lds = (size_t)align4(wave_sort_scratch(kpl)) * 4 * 4;   // 4 waves x the transposition image
+        const size_t lds = (size_t)align4(wave_sort_scratch(kpl, true)) * 4 * 4;   // 4 waves x (the skewed image + the bucket counters)
         static GridCache cache;   // (one per lambda instantiation, i.e. per kernel)
         allow_full_lds_once(cache, reinterpret_cast<const void*>(kern));
         int per_cu = (int)(kLdsLimit / lds);
-        if (per_cu > SOT_ROWPOS_SORT_WAVES) per_cu = SOT_ROWPOS_SORT_WAVES;   // four-wave workgroups: one wave of each per SIMD
+        if (per_cu > SOT_ROWPOS_SORT_MAX_WG) per_cu = SOT_ROWPOS_SORT_MAX_WG;   // four-wave workgroups: one wave of each per SIMD, at most 16 waves per CU
         const int64_t groups = (B + 3) / 4, cap = (int64_t)device_cu_count() * per_cu;
         hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, s, xpos, ypos, B, n, m, xps, yps, dest);
     };

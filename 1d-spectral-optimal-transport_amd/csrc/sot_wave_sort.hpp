@@ -38,6 +38,9 @@
 #ifndef SOT_WSORT_TRANSPOSE_MIN
 #define SOT_WSORT_TRANSPOSE_MIN 4   /* merges whose largest lane distance S / 4 is at least this run their lane stages on the transposed layout (64: never) */
 #endif
+#ifndef SOT_WSORT_BUCKETS
+#define SOT_WSORT_BUCKETS 1   /* 32 keys per lane: the distribution form first, the network when a bucket overflows (0: the network always) */
+#endif
 #ifndef SOT_WSORT_FENCED
 #define SOT_WSORT_FENCED 1
 #endif
@@ -53,7 +56,15 @@ constexpr int kWaveSortRunLimit = 8;
 
 __host__ __device__ constexpr int wsort_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // LDS dwords the index / scratch array of a wave sort needs (the key array needs 64 KPL)
-__host__ __device__ constexpr int wave_sort_scratch(int kpl) { return 64 * kpl + 2 * kpl + 2; }
+// (64 KPL keys: the skewed image of 66 KPL dwords; with `buckets` KPL = 32 also holds the 2048 bucket counters of the distribution form behind it, skewed alike)
+__host__ __device__ constexpr int wave_sort_scratch(int kpl, bool buckets = false) { return ((kpl == 32 && buckets) ? 2 : 1) * (64 * kpl + 2 * kpl) + 2; }
+
+// ---------------------------------------------------------------------------------------------
+// Register <-> element maps.  VEC = false: register r of lane l is element (position) r 64 + l.  VEC = true (KPL % 4 == 0): element
+// (r / 4) 256 + 4 l + r % 4 -- four consecutive elements per lane, i.e. 16-byte loads / stores in global memory and LDS.
+// ---------------------------------------------------------------------------------------------
+template <bool VEC>
+__device__ __forceinline__ int wsort_elem(int r, int lane) { return VEC ? ((r >> 2) << 8) + 4 * lane + (r & 3) : r * 64 + lane; }
 
 // value of lane ^ M
 template <int M>
@@ -203,6 +214,97 @@ __device__ __forceinline__ void wsort_network(uint32_t (&w)[KPL], int lane, uint
     wsort_lane_merges<KPL, 2>(w, lane, addr63, scratch);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The DISTRIBUTION form for 32 keys per lane (round 6, second form): the network above is 72 VALU instructions per key whatever the keys
+// are; packed words of generic positions are almost uniform in their top bits (that is what the row-adaptive quantisation is for), so ONE
+// counting pass puts every word within a few positions of its place:
+//   bucket = word >> 21 (2048 equal bins over the row's range) -> histogram by LDS atomics (the value an atomic returns is the word's rank
+//   inside its bucket, in arrival order) -> exclusive scan (lane l owns buckets 32 l ... 32 l + 31: one read, 32 adds, one DPP wave scan)
+//   -> scatter to base + rank in the skewed image.
+// Then two passes of the 32-register Batcher network on windows of the image -- [32 l, 32 l + 32) and [32 l + 16, 32 l + 48) -- order every
+// bucket of at most kWaveSortBucketLimit = 16 words completely (such a bucket lies inside a window of one of the passes, and a window sort
+// keeps the buckets it holds only partly in their places), whatever order the atomics arrived in: the result does not depend on it.
+// ~45 VALU + 13 LDS operations per key.  A bucket over the limit (clustered positions): returns false with w[] untouched -- the caller runs
+// the network.  image / counters: LDS byte addresses of 2112 dwords each, owned by this wavefront.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWaveSortBucketLimit = 16;
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t wsort_dpp_zero(uint32_t v)   // the DPP source lane's value; 0 where there is none
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+typedef __attribute__((address_space(3))) uint32_t wsort_lds_u32;
+
+template <bool FULL, bool VEC>
+__device__ __forceinline__ bool wsort_bucket_sort32(uint32_t (&w)[32], int lane, int n, uint32_t image, uint32_t counters)
+{
+    // (Measured, 4096 x 2 x 2048 keys: this form 45.6 us at two waves per SIMD = 8 waves per CU, 60.4 us at 4 per CU -- the pass lives on
+    //  occupancy; 16-bit counters packed in pairs (12.7 instead of 16.9 KB per wave) cost 3.5 us of unpacking at the same occupancy, 48.8-49.1 us,
+    //  and their twelve waves per CU need <= 168 registers, which this function does not fit: 65.7 us with 76 dwords spilled.)
+    const uint32_t own = counters + 4u * 33u * (uint32_t)lane;          // this lane's 32 buckets (bucket b at dword b + b / 32)
+#pragma unroll
+    for (int j = 0; j < 32; ++j) lds_st_u32(own + 4u * (uint32_t)j, 0u);
+    row_sync<1>();
+    uint32_t slot[32], rank[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const uint32_t b = w[r] >> 21;
+        slot[r] = counters + 4u * (b + (b >> 5));
+        rank[r] = 0u;
+        if (FULL || w[r] != 0xFFFFFFFFu)        // (pads are not counted: they keep the positions behind the data)
+            rank[r] = __hip_atomic_fetch_add(reinterpret_cast<wsort_lds_u32*>((uintptr_t)slot[r]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    row_sync<1>();
+    uint32_t c[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) c[j] = lds_ld_u32(own + 4u * (uint32_t)j);
+    uint32_t most = 0u, run = 0u;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { most = max(most, c[j]); const uint32_t t = c[j]; c[j] = run; run += t; }
+    if (__builtin_amdgcn_ballot_w64(most > (uint32_t)kWaveSortBucketLimit) != 0ull) return false;   // wave-uniform; w[] untouched
+    uint32_t incl = run;                                                  // inclusive scan of the lanes' totals
+    incl += wsort_dpp_zero<kRowShr1>(incl); incl += wsort_dpp_zero<kRowShr2>(incl);
+    incl += wsort_dpp_zero<kRowShr4>(incl); incl += wsort_dpp_zero<kRowShr8>(incl);
+    incl += wsort_dpp_zero<kRowBcast15, 0xA>(incl); incl += wsort_dpp_zero<kRowBcast31, 0xC>(incl);
+    const uint32_t before = incl - run;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) lds_st_u32(own + 4u * (uint32_t)j, c[j] + before);
+    row_sync<1>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const uint32_t base = lds_ld_u32(slot[r]);
+        const uint32_t pos = (FULL || w[r] != 0xFFFFFFFFu) ? base + rank[r] : (uint32_t)wsort_elem<VEC>(r, lane);   // a pad: its own element number (>= n)
+        lds_st_u32(image + 4u * (pos + (pos >> 5)), w[r]);
+    }
+    row_sync<1>();
+    (void)n;
+    // two window passes: [32 l, 32 l + 32), then [32 l + 16, 32 l + 48) (lane 63 has no second window)
+    const uint32_t blocked = image + 4u * 33u * (uint32_t)lane;
+    uint32_t v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = lds_ld_u32(blocked + 4u * (uint32_t)j);
+    wsort_reg_sort<32>(v);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) lds_st_u32(blocked + 4u * (uint32_t)j, v[j]);
+    row_sync<1>();
+    const uint32_t shifted = blocked + 4u * 16u;                        // position 32 l + 16 + j at 33 l + 16 + j (+ 1 from j = 16 on: the next block's skew)
+    if (lane < 63) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = lds_ld_u32(shifted + 4u * (uint32_t)(j + (j >= 16 ? 1 : 0)));
+    }
+    wsort_reg_sort<32>(v);
+    if (lane < 63) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) lds_st_u32(shifted + 4u * (uint32_t)(j + (j >= 16 ? 1 : 0)), v[j]);
+    }
+    row_sync<1>();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) w[j] = lds_ld_u32(blocked + 4u * (uint32_t)j);
+    return true;
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float wsort_dpp_keep(float v)   // the DPP source lane's value; a lane without one reads its own
 {
@@ -224,13 +326,6 @@ __device__ __forceinline__ float wsort_wave_max(float v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Register <-> element maps.  VEC = false: register r of lane l is element (position) r 64 + l.  VEC = true (KPL % 4 == 0): element
-// (r / 4) 256 + 4 l + r % 4 -- four consecutive elements per lane, i.e. 16-byte loads / stores in global memory and LDS.
-// ---------------------------------------------------------------------------------------------
-template <bool VEC>
-__device__ __forceinline__ int wsort_elem(int r, int lane) { return VEC ? ((r >> 2) << 8) + 4 * lane + (r & 3) : r * 64 + lane; }
-
-// ---------------------------------------------------------------------------------------------
 // x[r]: the key of element wsort_elem<VEC>(r, lane) (any value for e >= n); key[0 .. 64 KPL): the same keys in LDS in natural order
 // with +inf behind the n real ones; idx: LDS scratch of wave_sort_scratch(KPL) dwords.  All 64 lanes of ONE wavefront call it; nobody
 // else touches key / idx meanwhile.  FULL: n == 64 KPL is known at compile time (no validity tests).  Returns (wave-uniform) true:
@@ -239,7 +334,7 @@ __device__ __forceinline__ int wsort_elem(int r, int lane) { return VEC ? ((r >>
 // ---------------------------------------------------------------------------------------------
 // wave_sort_core: the same with the full keys behind a functor (keyof(i): the key of original element i -- LDS, or global memory when no
 // natural copy is kept) and WANT_KEYS = false for callers that only want the permutation (ok[] is then not written).
-template <int KPL, bool STORE_LDS, bool FULL, bool VEC, bool WANT_KEYS, typename KeyOf>
+template <int KPL, bool STORE_LDS, bool FULL, bool VEC, bool WANT_KEYS, bool BUCKETS = false, typename KeyOf>
 __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyof, float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
 {
     static_assert(!STORE_LDS || WANT_KEYS, "the natural-order stores need the sorted keys");
@@ -284,8 +379,10 @@ __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyo
                                   : (((q << (IDXBITS - 6)) + (uint32_t)r) << 6) + low[0];
         w[r] = full ? word : (word | pad_mask(r));   // every pad is the same word 0xFFFFFFFF: behind the data, never a run
     }
+    bool placed = false;
 #if !defined(SOT_WSORT_DIAG_SKIP_NETWORK)   /* diagnostic (timing only, results are wrong): everything but the network */
-    wsort_network<KPL>(w, lane, lds_addr(idx));
+    if constexpr (KPL == 32 && BUCKETS && SOT_WSORT_BUCKETS) placed = wsort_bucket_sort32<FULL, VEC>(w, lane, n, lds_addr(idx), lds_addr(idx) + 4u * 2112u);
+    if (!placed) wsort_network<KPL>(w, lane, lds_addr(idx));
 #endif
     // ---- neighbours that share q: (a ^ b) - 1 < MASK (a == b: two pads)
     uint32_t cmin = 0xFFFFFFFFu;
@@ -303,7 +400,7 @@ __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyo
     }
     // ---- blocked -> striped through the skewed image: position p lives at p + p / 32
     const uint32_t sbase = lds_addr(idx);
-    {
+    if (!placed) {   // (the distribution form has left exactly this image behind)
         const uint32_t p0 = (uint32_t)(lane * KPL);
         const uint32_t wa = sbase + 4u * (p0 + (p0 >> 5));          // KPL <= 32: p0 + r never crosses a multiple of 32 inside one lane's block
 #pragma unroll
@@ -369,7 +466,7 @@ __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyo
 template <int KPL, bool STORE_LDS = true, bool FULL = false, bool VEC = false>
 __device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
 {
-    return wave_sort_core<KPL, STORE_LDS, FULL, VEC, true>(x, [key](uint32_t i) { return key[i]; }, key, idx, n, lane, ok, oi);
+    return wave_sort_core<KPL, STORE_LDS, FULL, VEC, true, false>(x, [key](uint32_t i) { return key[i]; }, key, idx, n, lane, ok, oi);
 }
 
 }  // namespace sot

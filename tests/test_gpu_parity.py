@@ -535,6 +535,8 @@ def test_segmented_sort_adversarial_keys(n):
     same(0.5 + u * 2.0 ** -14)                                             # one bin of the float's own top bits; separated by the row's range
     near = u.clone(); near[:, 1::2] = torch.nextafter(near[:, 0::2][:, :near[:, 1::2].shape[1]], torch.tensor(2.0)); same(near)   # pairs one ulp apart
     same(torch.cat([u[:, :-1] * 1e-9, torch.ones(B, 1)], 1))               # everything but one key in ONE bin: the fallback
+    if n > 100:
+        mod = u.clone(); mod[:, : n - n // 40] *= 0.01; same(mod)           # moderately clustered: the distribution form's buckets overflow, the network takes the row
     same(torch.full((B, n), 0.25))
     z = u.clone(); z[:, ::3] = 0.0; z[:, 1::5] = -0.0; same(z)
     for bad in (float("inf"), float("-inf")):

@@ -5,7 +5,7 @@ the GPU against torch.sort (tests/test_gpu_parity.py: test_segmented_sort_*, tes
 import numpy as np
 import pytest
 
-from wave_sort_model import RUN_LIMIT, collide, network, order_bits, pack_words, wave_sort_model
+from wave_sort_model import BUCKET_LIMIT, RUN_LIMIT, bucket_sort32, collide, network, order_bits, pack_words, wave_sort_model
 
 
 def _check(keys, kpl, expect_decline=False):
@@ -102,3 +102,34 @@ def test_network_sorts_any_words_and_pads_stay_behind():
         out = network(w, kpl).reshape(-1)
         assert np.array_equal(out, np.sort(w.reshape(-1)))
     assert not collide(0xFFFFFFFF, 0xFFFFFFFF, 11) and collide(0x12345000, 0x12345001, 12) and not collide(0x12345000, 0x12346000, 12)
+
+
+def test_distribution_form_does_not_depend_on_the_order_the_atomics_arrive_in():
+    """32 keys per lane (round 6, second form): histogram -> scan -> scatter by the top 11 bits of the packed word, then two passes of 32-register sorts on
+    windows offset by 16.  The rank an LDS atomic returns is an arrival order the hardware owns; the result must not depend on it."""
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = 2048 if trial < 2 else int(rng.integers(1100, 2048))
+        keys = rng.random(n).astype(np.float32) if trial % 2 == 0 else (rng.standard_normal(n) * 1.5).astype(np.float32)
+        want = np.argsort(keys, kind="stable")
+        stats = {}
+        for arrival in (None, rng.permutation(2048), np.arange(2048)[::-1]):
+            out = wave_sort_model(keys, 32, stats, arrival=arrival)
+            assert out is not None and np.array_equal(out[1], want)
+        assert "move" not in stats                                        # the network never ran: the distribution form took these rows
+
+
+def test_distribution_form_declines_an_overfull_bucket_and_the_network_takes_the_row():
+    """moderately clustered positions: most keys inside 1 % of the row's range -- buckets of ~100 words (limit 16), but still one word per quantisation bin:
+    the distribution form declines, the network sorts the same words, the result is the same stable order"""
+    rng = np.random.default_rng(6)
+    keys = np.concatenate([rng.random(2000) * 0.01, rng.random(48)]).astype(np.float32)
+    keys = keys[rng.permutation(2048)]
+    words, ok = pack_words(keys, 2048, 32)
+    assert ok and np.bincount((words >> 21).astype(np.int64), minlength=2048).max() > BUCKET_LIMIT
+    assert bucket_sort32(words.reshape(32, 64).T.copy(), 2048) is None
+    stats = {}
+    out = wave_sort_model(keys, 32, stats)
+    assert out is not None and np.array_equal(out[1], np.argsort(keys, kind="stable")) and stats.get("move", 0) > 0   # the network ran
+    same = wave_sort_model(keys, 32, buckets=False)
+    assert np.array_equal(out[1], same[1])

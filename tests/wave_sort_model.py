@@ -147,6 +147,47 @@ def network(w, kpl, stats=None):
     return w
 
 
+BUCKET_LIMIT = 16        # sot_wave_sort.hpp: kWaveSortBucketLimit
+
+
+def bucket_sort32(w, n, stats=None, arrival=None):
+    """The DISTRIBUTION form of the sort for 32 keys per lane (round 6, second form; sot_wave_sort.hpp: wsort_bucket_sort32): the packed words' top
+    11 bits -- 2048 equal bins over the row's range -- are a bucket number; a histogram (LDS atomics), an exclusive scan (lane l owns buckets
+    32 l ... 32 l + 31) and a scatter put every word into its bucket's position range, in whatever order the atomics arrived (`arrival`: a
+    permutation the test varies); two passes of 32-register sorts on windows [32 l, 32 l + 32) and [32 l + 16, 32 l + 48) then order every
+    bucket of at most BUCKET_LIMIT words completely (a bucket lies inside a window of one of the two passes).  Returns the sorted image in the
+    blocked layout [lane, r], or None when a bucket is over the limit (the caller runs the network on the untouched words)."""
+    words = w.reshape(-1).copy()                    # register order is irrelevant to the result: every word carries its own index
+    real = words != 0xFFFFFFFF
+    assert int(real.sum()) == n
+    buckets = (words >> 21).astype(np.int64)
+    counts = np.bincount(buckets[real], minlength=2048)
+    if counts.max() > BUCKET_LIMIT:
+        return None
+    base = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    image = np.full(2048, 0xFFFFFFFF, np.uint32)    # pads keep positions n ... 2047
+    order = np.arange(len(words)) if arrival is None else arrival
+    fill = np.zeros(2048, np.int64)
+    for i in order:                                 # the atomics' return values: arrival order inside a bucket
+        if real[i]:
+            b = buckets[i]
+            image[base[b] + fill[b]] = words[i]
+            fill[b] += 1
+    lane = np.arange(64)
+    for j in range(32):                             # the two window reads / writes touch 32 banks per half wave on the skewed image
+        for addr in (33 * lane + j, 33 * lane[:63] + 16 + j + (1 if j >= 16 else 0)):
+            half = addr[:32] % 32
+            assert len(set(half.tolist())) == len(half)
+    for start in (0, 16):                           # pass 1: windows [32 l, 32 l + 32); pass 2: [32 l + 16, 32 l + 48), lane 63 idle
+        for l in range(64 if start == 0 else 63):
+            lo = 32 * l + start
+            image[lo:lo + 32] = np.sort(image[lo:lo + 32])
+        if stats is not None:
+            stats["valu_inreg"] = stats.get("valu_inreg", 0) + 2 * 191
+    assert np.all(image[:-1] <= image[1:]), "two window passes did not finish the buckets"
+    return image.reshape(64, 32)
+
+
 def collide(a, b, idxbits):
     """two neighbouring sorted words share q (identical words = two pads: not a collision): the kernel's (a ^ b) - 1 < 2^idxbits - 1"""
     return ((int(a) ^ int(b)) - 1) & 0xFFFFFFFF < (1 << idxbits) - 1
@@ -187,7 +228,7 @@ def skew(p):
     return p + (p >> 5)
 
 
-def wave_sort_model(keys, kpl, stats=None):
+def wave_sort_model(keys, kpl, stats=None, buckets=True, arrival=None):
     """(sorted_keys[n], indices[n]) or None when the fast path declines (caller falls back to the merge sort)."""
     n = len(keys)
     npad = 64 * kpl
@@ -200,7 +241,8 @@ def wave_sort_model(keys, kpl, stats=None):
         return None
     # load order e = r 64 + lane -> register image [lane, r]
     w = words.reshape(kpl, 64).T.copy()
-    w = network(w, kpl, stats)
+    sorted_image = bucket_sort32(w, n, stats, arrival) if (kpl == 32 and buckets) else None
+    w = sorted_image if sorted_image is not None else network(w, kpl, stats)
     # blocked -> striped through the skewed scratch image: write position p = lane kpl + r at skew(p), read p' = r 64 + lane at skew(p')
     scratch = np.zeros(npad + (npad >> 5) + 2, np.uint32)
     lane = np.arange(64)
