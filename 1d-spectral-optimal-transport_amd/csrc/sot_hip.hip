@@ -290,11 +290,11 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
                                                int (&ix)[CPT], int (&iy)[CPT], const uint16_t* perm_in = nullptr, uint16_t* perm_out = nullptr)
 {
     const int n = c.n, m = c.m, t = c.t;
-    // A handed-over row whose first two entries are equal carries the pre-sort's SENTINEL (sot_rowpos_sort_kernel: both arrays arrived sorted,
-    // or the wave sort declined one): the row is then processed as if nothing had been handed over.  Row groups that share workgroup
+    // A handed-over row one of whose two permutations starts with two equal entries carries the pre-sort's SENTINEL (sot_rowpos_sort_kernel: the
+    // wave sort declined that array): the row is then processed as if nothing had been handed over.  Row groups that share workgroup
     // barriers decide together (any sentinel in the workgroup: all of its rows take the self-contained path, which is always correct).
     bool gather = perm_in != nullptr && c.do_sort;
-    if (gather && nmax >= 2) gather = !row_any<G / kWave>(perm_in[0] == perm_in[1]);
+    if (gather && nmax >= 2 && mmax >= 2) gather = !row_any<G / kWave>(perm_in[0] == perm_in[1] || perm_in[n] == perm_in[n + 1]);
     if (gather) {            // uniform over the threads that share barriers
         // The row's positions arrive COALESCED (element t + k G per thread), are staged in natural order in the U / V regions (free until the
         // weights arrive) and gathered from LDS through the permutation: 16 scattered 4-byte loads per thread from global memory -- up to 64
@@ -1971,9 +1971,10 @@ int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stri
 // sorted rows 71 -> 90 us, backward 276 -> 348 us at 4096 x 2048, measured inlined and as a call); a kernel of its own has its own
 // allocation, every wavefront of it sorts, and it needs 8.5 KB of LDS per wavefront (the transposition image; the run repair reads the
 // full keys from global memory).
-// A row whose arrays are BOTH already sorted, or one of whose arrays the wave sort declines (clustered / non-finite positions), gets the
-// SENTINEL perm[row][0] == perm[row][1] == 0xFFFF: the row kernel then treats the row as if no permutation had been handed over
-// (sortedness test, in-LDS merge sort) -- and, when the image is the caller's row_perm_out, stores the real permutations over it.
+// An array that arrives sorted gets the identity; an array the wave sort declines (clustered / non-finite positions) gets the SENTINEL in its
+// part of the image -- its first two entries 0xFFFF (perm[row][0..1] for x, perm[row][n..n+1] for y): the row kernel then treats the ROW as if no
+// permutation had been handed over (sortedness test, in-LDS merge sort) -- and, when the image is the caller's row_perm_out, stores the real
+// permutations over it.
 // ---------------------------------------------------------------------------------------------
 constexpr uint16_t kRowPermSentinel = 0xFFFFu;
 #ifndef SOT_ROWPOS_SORT_MAX_WG
@@ -1992,14 +1993,15 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
     constexpr int SCR = align4(wave_sort_scratch(KPL, true));
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* const idx = reinterpret_cast<uint32_t*>(smem) + wv * SCR;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < B; row += (int64_t)gridDim.x * 4) {
-        uint16_t* const prow = perm + row * ((int64_t)n + m);
-        int states = 0;   // two bits per array -- 0: it arrived sorted (nothing written yet), 1: its permutation is stored, 2: declined
-#pragma unroll 1
-        for (int which = 0; which < 2; ++which) {
+    // one task = ONE array (task 2 r: the x positions of row r, 2 r + 1: its y positions): 2 B tasks spread evenly over whatever number of waves is
+    // resident; an array's outcome is its own business -- sorted on arrival: the identity, sorted here: its permutation, declined: the sentinel in ITS part
+    for (int64_t task = (int64_t)blockIdx.x * 4 + wv; task < 2 * B; task += (int64_t)gridDim.x * 4) {
+        const int64_t row = task >> 1;
+        const int which = (int)(task & 1);
+        {
             const float* src = which ? ypos + row * yps : xpos + row * xps;
             const int len = which ? m : n;
-            uint16_t* const dst = prow + (which ? n : 0);
+            uint16_t* const dst = perm + row * ((int64_t)n + m) + (which ? n : 0);
             float x[KPL];
             if constexpr (VEC) {
 #pragma unroll
@@ -2033,12 +2035,18 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
                     unsorted |= (r * 64 + lane + 1 < len) && (x[r] > nxt);
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(unsorted) == 0ull) continue;
             float sk[KPL]; uint32_t si[KPL];
-            const bool done = wave_sort_core<KPL, false, FULL, VEC, false, true>(x, [src](uint32_t i) { return src[i]; }, nullptr, idx, len, lane, sk, si);
-            row_sync<1>();   // the scratch image is free again
-            if (!done) { states |= 2 << (2 * which); continue; }
-            states |= 1 << (2 * which);
+            if (__builtin_amdgcn_ballot_w64(unsorted) == 0ull) {      // sorted on arrival: the identity
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) si[r] = (uint32_t)wsort_elem<VEC>(r, lane);
+            } else {
+                const bool done = wave_sort_core<KPL, false, FULL, VEC, false, true>(x, [src](uint32_t i) { return src[i]; }, nullptr, idx, len, lane, sk, si);
+                row_sync<1>();   // the scratch image is free again
+                if (!done) {     // declined: the sentinel (wave-uniform), and the row kernel sorts this ROW itself
+                    if (lane < 2) dst[lane] = kRowPermSentinel;
+                    continue;
+                }
+            }
             if constexpr (VEC) {
 #pragma unroll
                 for (int r = 0; r < KPL; r += 4) {
@@ -2050,18 +2058,6 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
             } else {
 #pragma unroll
                 for (int r = 0; r < KPL; ++r) { const int e = r * 64 + lane; if (e < len) dst[e] = (uint16_t)min((int)si[r], len - 1); }
-            }
-        }
-        // (wave-uniform decisions; the stores of one wavefront to one address keep their program order)
-        if ((states & 0xA) != 0 || states == 0) {
-            if (lane < 2) prow[lane] = kRowPermSentinel;
-        } else {
-#pragma unroll 1
-            for (int which = 0; which < 2; ++which) {
-                if (((states >> (2 * which)) & 3) != 0) continue;   // sorted beside an unsorted one: the identity
-                const int len = which ? m : n;
-                uint16_t* const dst = prow + (which ? n : 0);
-                for (int e = lane; e < len; e += 64) dst[e] = (uint16_t)e;
             }
         }
     }
@@ -2080,7 +2076,7 @@ int launch_rowpos_sort(const float* xpos, const float* ypos, int64_t B, int n, i
         allow_full_lds_once(cache, reinterpret_cast<const void*>(kern));
         int per_cu = (int)(kLdsLimit / lds);
         if (per_cu > SOT_ROWPOS_SORT_MAX_WG) per_cu = SOT_ROWPOS_SORT_MAX_WG;   // four-wave workgroups: one wave of each per SIMD, at most 16 waves per CU
-        const int64_t groups = (B + 3) / 4, cap = (int64_t)device_cu_count() * per_cu;
+        const int64_t groups = (2 * B + 3) / 4, cap = (int64_t)device_cu_count() * per_cu;   // one wave per array
         hipLaunchKernelGGL(kern, dim3((unsigned)(groups < cap ? groups : cap)), dim3(256), lds, s, xpos, ypos, B, n, m, xps, yps, dest);
     };
     auto pick = [&](auto kpl_tag) {

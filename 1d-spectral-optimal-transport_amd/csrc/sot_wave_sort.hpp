@@ -41,6 +41,9 @@
 #ifndef SOT_WSORT_BUCKETS
 #define SOT_WSORT_BUCKETS 1   /* 32 keys per lane: the distribution form first, the network when a bucket overflows (0: the network always) */
 #endif
+#ifndef SOT_WSORT_ONE_REGION
+#define SOT_WSORT_ONE_REGION 1   /* the distribution form's counters and its image share their 8.25 KB of LDS (every base is read before a word is stored) */
+#endif
 #ifndef SOT_WSORT_FENCED
 #define SOT_WSORT_FENCED 1
 #endif
@@ -57,7 +60,7 @@ constexpr int kWaveSortRunLimit = 8;
 __host__ __device__ constexpr int wsort_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // LDS dwords the index / scratch array of a wave sort needs (the key array needs 64 KPL)
 // (64 KPL keys: the skewed image of 66 KPL dwords; with `buckets` KPL = 32 also holds the 2048 bucket counters of the distribution form behind it, skewed alike)
-__host__ __device__ constexpr int wave_sort_scratch(int kpl, bool buckets = false) { return ((kpl == 32 && buckets) ? 2 : 1) * (64 * kpl + 2 * kpl) + 2; }
+__host__ __device__ constexpr int wave_sort_scratch(int kpl, bool buckets = false) { return ((kpl == 32 && buckets && !SOT_WSORT_ONE_REGION) ? 2 : 1) * (64 * kpl + 2 * kpl) + 2; }
 
 // ---------------------------------------------------------------------------------------------
 // Register <-> element maps.  VEC = false: register r of lane l is element (position) r 64 + l.  VEC = true (KPL % 4 == 0): element
@@ -272,12 +275,15 @@ __device__ __forceinline__ bool wsort_bucket_sort32(uint32_t (&w)[32], int lane,
 #pragma unroll
     for (int j = 0; j < 32; ++j) lds_st_u32(own + 4u * (uint32_t)j, c[j] + before);
     row_sync<1>();
+    // every word's position first (the bases are read before anything is stored): image and counters may then be ONE region (SOT_WSORT_ONE_REGION)
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         const uint32_t base = lds_ld_u32(slot[r]);
-        const uint32_t pos = (FULL || w[r] != 0xFFFFFFFFu) ? base + rank[r] : (uint32_t)wsort_elem<VEC>(r, lane);   // a pad: its own element number (>= n)
-        lds_st_u32(image + 4u * (pos + (pos >> 5)), w[r]);
+        rank[r] = (FULL || w[r] != 0xFFFFFFFFu) ? base + rank[r] : (uint32_t)wsort_elem<VEC>(r, lane);   // a pad: its own element number (>= n)
     }
+    row_sync<1>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) lds_st_u32(image + 4u * (rank[r] + (rank[r] >> 5)), w[r]);
     row_sync<1>();
     (void)n;
     // two window passes: [32 l, 32 l + 32), then [32 l + 16, 32 l + 48) (lane 63 has no second window)
@@ -381,7 +387,7 @@ __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyo
     }
     bool placed = false;
 #if !defined(SOT_WSORT_DIAG_SKIP_NETWORK)   /* diagnostic (timing only, results are wrong): everything but the network */
-    if constexpr (KPL == 32 && BUCKETS && SOT_WSORT_BUCKETS) placed = wsort_bucket_sort32<FULL, VEC>(w, lane, n, lds_addr(idx), lds_addr(idx) + 4u * 2112u);
+    if constexpr (KPL == 32 && BUCKETS && SOT_WSORT_BUCKETS) placed = wsort_bucket_sort32<FULL, VEC>(w, lane, n, lds_addr(idx), lds_addr(idx) + (SOT_WSORT_ONE_REGION ? 0u : 4u * 2112u));
     if (!placed) wsort_network<KPL>(w, lane, lds_addr(idx));
 #endif
     // ---- neighbours that share q: (a ^ b) - 1 < MASK (a == b: two pads)

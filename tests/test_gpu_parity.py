@@ -560,9 +560,9 @@ def test_segmented_sort_adversarial_keys(n):
 @pytest.mark.parametrize("mode", ["p1", "cutoff"])
 def test_rowpos_presort_kernel_and_its_sentinel(shape, mode):
     """Round 6: per-row positions that nobody has sorted are sorted AHEAD of the row kernel by sot_rowpos_sort_kernel (one wavefront per row,
-    permutations into the caller's row_perm_out or the workspace); the row kernels gather through them.  Rows whose arrays both arrive
-    sorted, and rows the wave sort declines (clustered / tied / non-finite positions), carry a sentinel and are handled by the row kernel
-    itself.  Every route must give the same bits: default (pre-sort) == SOT_FLAG_NO_SPECIALIZE (the row kernel's own merge sort) == the
+    permutations into the caller's row_perm_out or the workspace); the row kernels gather through them.  Arrays that arrive sorted get the
+    identity; rows one of whose arrays the wave sort declines (clustered / tied / non-finite positions) carry a sentinel and are handled by the
+    row kernel itself.  Every route must give the same bits: default (pre-sort) == SOT_FLAG_NO_SPECIALIZE (the row kernel's own merge sort) == the
     oracle within the forward tolerance; the permutations left in row_perm_out are the stable argsort on EVERY row, sentinel rows included."""
     from oracle import sot_oracle as so
     from oracle.inputs import gen_inputs
@@ -573,7 +573,7 @@ def test_rowpos_presort_kernel_and_its_sentinel(shape, mode):
     x, y = gen_inputs("peaky", B, n, m, 300 + n + m)
     g = torch.Generator().manual_seed(n * 3 + m)
     xp, yp = torch.rand(B, n, generator=g), torch.rand(B, m, generator=g)
-    xp[0], yp[0] = torch.sort(xp[0]).values, torch.sort(yp[0]).values          # both sorted: sentinel
+    xp[0], yp[0] = torch.sort(xp[0]).values, torch.sort(yp[0]).values          # both sorted: identities
     xp[1] = torch.sort(xp[1]).values                                            # one sorted, one not: identity + permutation
     if n > 12:
         xp[2, : n - 1] *= 1e-9; xp[2, n - 1] = 1.0                              # clustered: the wave sort declines (sentinel; merge sort in the row kernel)
