@@ -472,7 +472,7 @@ __device__ __forceinline__ bool wave_sort_core(const float (&x)[KPL], KeyOf keyo
 template <int KPL, bool STORE_LDS = true, bool FULL = false, bool VEC = false>
 __device__ __forceinline__ bool wave_sort_kv(const float (&x)[KPL], float* key, uint32_t* idx, int n, int lane, float (&ok)[KPL], uint32_t (&oi)[KPL])
 {
-    return wave_sort_core<KPL, STORE_LDS, FULL, VEC, true, false>(x, [key](uint32_t i) { return key[i]; }, key, idx, n, lane, ok, oi);
+    return wave_sort_core<KPL, STORE_LDS, FULL, VEC, true, SOT_WSORT_ONE_REGION != 0>(x, [key](uint32_t i) { return key[i]; }, key, idx, n, lane, ok, oi);   // (one region: the scratch is no larger with the distribution form)
 }
 
 }  // namespace sot
