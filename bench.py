@@ -1031,8 +1031,8 @@ def main():
     def attached_ms(call, count=32):
         """Average duration of the FIRST kernel `call(i)` launches (a compile-time-length row kernel), from HIP events attached to
         the dispatch: the figure rocprofv3's kernel trace reports for it."""
-        for i in range(60):   # the first launches of a kernel run slower (code load, clock ramp): the headline gets 400 untimed steps, these get 60
-            call(i)
+        for i in range(400):   # the first launches of a kernel run slower (code load, clock ramp): like the headline's 400 untimed steps (60 until round 6:
+            call(i)            # the same kernels then read 5-30 % above their steady state on some boxes -- profiles/r6_same_box_ab.txt)
         slots = list(range(min(count, PROFILE_SLOTS)))
         for i in slots:
             nat.profile_next_launch(i)
