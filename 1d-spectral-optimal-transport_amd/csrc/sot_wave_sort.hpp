@@ -250,14 +250,13 @@ __device__ __forceinline__ bool wsort_bucket_sort32(uint32_t (&w)[32], int lane,
 #pragma unroll
     for (int j = 0; j < 32; ++j) lds_st_u32(own + 4u * (uint32_t)j, 0u);
     row_sync<1>();
-    uint32_t slot[32], rank[32];
+    auto slot_of = [counters](uint32_t word) { const uint32_t b = word >> 21; return counters + 4u * (b + (b >> 5)); };   // (computed twice per word rather than kept)
+    uint32_t rank[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
-        const uint32_t b = w[r] >> 21;
-        slot[r] = counters + 4u * (b + (b >> 5));
         rank[r] = 0u;
         if (FULL || w[r] != 0xFFFFFFFFu)        // (pads are not counted: they keep the positions behind the data)
-            rank[r] = __hip_atomic_fetch_add(reinterpret_cast<wsort_lds_u32*>((uintptr_t)slot[r]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            rank[r] = __hip_atomic_fetch_add(reinterpret_cast<wsort_lds_u32*>((uintptr_t)slot_of(w[r])), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     row_sync<1>();
     uint32_t c[32];
@@ -278,7 +277,7 @@ __device__ __forceinline__ bool wsort_bucket_sort32(uint32_t (&w)[32], int lane,
     // every word's position first (the bases are read before anything is stored): image and counters may then be ONE region (SOT_WSORT_ONE_REGION)
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
-        const uint32_t base = lds_ld_u32(slot[r]);
+        const uint32_t base = lds_ld_u32(slot_of(w[r]));
         rank[r] = (FULL || w[r] != 0xFFFFFFFFu) ? base + rank[r] : (uint32_t)wsort_elem<VEC>(r, lane);   // a pad: its own element number (>= n)
     }
     row_sync<1>();
