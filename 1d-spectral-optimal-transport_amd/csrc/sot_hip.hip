@@ -290,11 +290,7 @@ __device__ __forceinline__ void rowpos_prepare(const RowCtx<G>& c, const float* 
                                                int (&ix)[CPT], int (&iy)[CPT], const uint16_t* perm_in = nullptr, uint16_t* perm_out = nullptr)
 {
     const int n = c.n, m = c.m, t = c.t;
-    // A handed-over row one of whose two permutations starts with two equal entries carries the pre-sort's SENTINEL (sot_rowpos_sort_kernel: the
-    // wave sort declined that array): the row is then processed as if nothing had been handed over.  Row groups that share workgroup
-    // barriers decide together (any sentinel in the workgroup: all of its rows take the self-contained path, which is always correct).
-    bool gather = perm_in != nullptr && c.do_sort;
-    if (gather && nmax >= 2 && mmax >= 2) gather = !row_any<G / kWave>(perm_in[0] == perm_in[1] || perm_in[n] == perm_in[n + 1]);
+    const bool gather = perm_in != nullptr && c.do_sort;   // (an image is always complete: the pre-sort kernel and the sorting row kernels both write every row)
     if (gather) {            // uniform over the threads that share barriers
         // The row's positions arrive COALESCED (element t + k G per thread), are staged in natural order in the U / V regions (free until the
         // weights arrive) and gathered from LDS through the permutation: 16 scattered 4-byte loads per thread from global memory -- up to 64
@@ -1971,12 +1967,20 @@ int launch_segmented_sort_wave(const float* keys, int64_t B, int n, int64_t stri
 // sorted rows 71 -> 90 us, backward 276 -> 348 us at 4096 x 2048, measured inlined and as a call); a kernel of its own has its own
 // allocation, every wavefront of it sorts, and it needs 8.5 KB of LDS per wavefront (the transposition image; the run repair reads the
 // full keys from global memory).
-// An array that arrives sorted gets the identity; an array the wave sort declines (clustered / non-finite positions) gets the SENTINEL in its
-// part of the image -- its first two entries 0xFFFF (perm[row][0..1] for x, perm[row][n..n+1] for y): the row kernel then treats the ROW as if no
-// permutation had been handed over (sortedness test, in-LDS merge sort) -- and, when the image is the caller's row_perm_out, stores the real
-// permutations over it.
+// An array that arrives sorted gets the identity; an array the wave sort declines (clustered / non-finite positions) is sorted by the same wavefront with
+// the stable merge sort of round 4 (17.4 KB of LDS per wave are provisioned for it: the kernel's 8 waves per CU leave the room): the image is always complete.
 // ---------------------------------------------------------------------------------------------
-constexpr uint16_t kRowPermSentinel = 0xFFFFu;
+
+// The stable merge sort of ONE array by ONE wavefront (what a declined wave sort falls back to): a call, not inlined -- its 64 result registers stay
+// out of the pre-sort kernel's hot path.  key: natural keys in LDS with +inf behind the len real ones up to sort16_npad(len); idx: scratch in, indices out.
+template <int MAXB>
+static __device__ __attribute__((noinline)) void wave_merge_sort_array(float* key, int* idx, int len, int lane)
+{
+    const SortJob job{key, idx, len, sort16_npad(len)}, none{nullptr, nullptr, 0, 0};
+    row_sync<1>();
+    merge_sort16_kv2<MAXB>(job, none, lane, kWave, [] { row_sync<1>(); });
+    row_sync<1>();
+}
 #ifndef SOT_ROWPOS_SORT_MAX_WG
 #define SOT_ROWPOS_SORT_MAX_WG 4
 #endif
@@ -1990,11 +1994,14 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
                                                                  int64_t xps, int64_t yps, uint16_t* __restrict__ perm)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SCR = align4(wave_sort_scratch(KPL, true));
+    // per wave: [idx / scratch | key]: the wave sort needs the first only (8.25 KB at 32 keys per lane); the merge-sort fallback both (17.4 KB) -- at the 8 waves
+    // per CU the kernel's registers allow anyway, the CU holds that
+    constexpr int ICAP = wave_sort_idx_cap<KPL>(), KCAP = wave_sort_key_cap<KPL>();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* const idx = reinterpret_cast<uint32_t*>(smem) + wv * SCR;
+    uint32_t* const idx = reinterpret_cast<uint32_t*>(smem) + wv * (ICAP + KCAP);
+    float* const keyl = reinterpret_cast<float*>(idx + ICAP);
     // one task = ONE array (task 2 r: the x positions of row r, 2 r + 1: its y positions): 2 B tasks spread evenly over whatever number of waves is
-    // resident; an array's outcome is its own business -- sorted on arrival: the identity, sorted here: its permutation, declined: the sentinel in ITS part
+    // resident; an array's outcome is its own business -- sorted on arrival: the identity, sorted here (wave sort, or the merge sort when that declines): its permutation
     for (int64_t task = (int64_t)blockIdx.x * 4 + wv; task < 2 * B; task += (int64_t)gridDim.x * 4) {
         const int64_t row = task >> 1;
         const int which = (int)(task & 1);
@@ -2042,9 +2049,15 @@ __global__ __launch_bounds__(256, SOT_ROWPOS_SORT_WAVES) void sot_rowpos_sort_ke
             } else {
                 const bool done = wave_sort_core<KPL, false, FULL, VEC, false, true>(x, [src](uint32_t i) { return src[i]; }, nullptr, idx, len, lane, sk, si);
                 row_sync<1>();   // the scratch image is free again
-                if (!done) {     // declined: the sentinel (wave-uniform), and the row kernel sorts this ROW itself
-                    if (lane < 2) dst[lane] = kRowPermSentinel;
-                    continue;
+                if (!done) {     // declined (clustered / non-finite positions; wave-uniform): the stable merge sort of round 4, by this wavefront alone
+                    constexpr int NP = 64 * KPL;
+#pragma unroll
+                    for (int r = 0; r < KPL; ++r) keyl[wsort_elem<VEC>(r, lane)] = x[r];          // natural order; +inf behind the row (x[] holds the pads)
+                    for (int e = NP + lane; e < sort16_npad(len); e += 64) keyl[e] = INFINITY;    // (never: sort16_npad(len) <= 64 KPL)
+                    wave_merge_sort_array<(NP / 16 + 63) / 64>(keyl, reinterpret_cast<int*>(idx), len, lane);
+#pragma unroll
+                    for (int r = 0; r < KPL; ++r) si[r] = (uint32_t)min(reinterpret_cast<int*>(idx)[wsort_elem<VEC>(r, lane)], len - 1);   // (a pad's INT_MAX / NaN rows: never outside the row)
+                    row_sync<1>();
                 }
             }
             if constexpr (VEC) {
@@ -2071,7 +2084,7 @@ int launch_rowpos_sort(const float* xpos, const float* ypos, int64_t B, int n, i
                          (reinterpret_cast<uintptr_t>(dest) & 7) == 0 && (n & 3) == 0 && (m & 3) == 0;
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
     auto go = [&](auto kern, int kpl) {
-        const size_t lds = (size_t)align4(wave_sort_scratch(kpl, true)) * 4 * 4;   // 4 waves x (the skewed image + the bucket counters)
+        const size_t lds = (size_t)(sot::align4(sot::imax(sot::sort16_capacity(sot::sort16_npad(64 * kpl)), wave_sort_scratch(kpl, true))) + sot::align4(sot::sort16_capacity(sot::sort16_npad(64 * kpl)))) * 4 * 4;   // 4 waves x (idx / scratch | key)
         static GridCache cache;   // (one per lambda instantiation, i.e. per kernel)
         allow_full_lds_once(cache, reinterpret_cast<const void*>(kern));
         int per_cu = (int)(kLdsLimit / lds);
@@ -2134,7 +2147,7 @@ int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t 
         if (dest != nullptr) {
             rc = launch_rowpos_sort(pr->xpos, pr->ypos, pr->B, n, m, pr->xpos_row_stride, pr->ypos_row_stride, dest, l.s);
             if (rc != SOT_OK) return rc;
-            a.perm_in = dest;   // (a.perm_out stays the caller's image: rows that carry the sentinel store their permutations over it)
+            a.perm_in = dest; a.perm_out = nullptr;   // the image is complete: the row kernel only reads it
         }
     }
 

@@ -96,10 +96,8 @@ typedef struct sot_problem {
      * through them instead of sorting again.  Ignored for shared positions.
      * Round 6: rows of 2 ... 2048 positions are sorted AHEAD of the row kernel by a kernel of their own (one wavefront per row, a packed-word
      * network in registers: csrc/sot_wave_sort.hpp) whenever there is a place for the permutations -- row_perm_out, else the call's workspace
-     * when it holds sot_workspace_bytes() bytes, else the row kernel sorts in LDS as before.  An array that arrives sorted gets the identity; an
-     * array the wave sort declines (clustered / non-finite positions) gets a SENTINEL -- the first two entries of ITS permutation are 0xFFFF: a
-     * row kernel handed such an image treats that row as unsorted input, and a forward whose row_perm_out it is stores the real permutations
-     * over the sentinel. */
+     * when it holds sot_workspace_bytes() bytes, else the row kernel sorts in LDS as before.  Either way an image that a call has written holds
+     * the stable sort permutations of every row. */
     uint16_t *row_perm_out;
     const uint16_t *row_perm_in;
 } sot_problem;

@@ -558,12 +558,12 @@ def test_segmented_sort_adversarial_keys(n):
 
 @pytest.mark.parametrize("shape", [(9, 2, 2), (5, 50, 70), (7, 300, 411), (6, 512, 512), (5, 1000, 1024), (4, 1025, 1025), (4, 1536, 1400), (6, 2048, 2048), (5, 2048, 2000)])
 @pytest.mark.parametrize("mode", ["p1", "cutoff"])
-def test_rowpos_presort_kernel_and_its_sentinel(shape, mode):
+def test_rowpos_presort_kernel_on_every_route(shape, mode):
     """Round 6: per-row positions that nobody has sorted are sorted AHEAD of the row kernel by sot_rowpos_sort_kernel (one wavefront per row,
     permutations into the caller's row_perm_out or the workspace); the row kernels gather through them.  Arrays that arrive sorted get the
-    identity; rows one of whose arrays the wave sort declines (clustered / tied / non-finite positions) carry a sentinel and are handled by the
-    row kernel itself.  Every route must give the same bits: default (pre-sort) == SOT_FLAG_NO_SPECIALIZE (the row kernel's own merge sort) == the
-    oracle within the forward tolerance; the permutations left in row_perm_out are the stable argsort on EVERY row, sentinel rows included."""
+    identity; arrays the wave sort declines (clustered / tied / non-finite positions) are merge-sorted by the same wavefront: the image is always
+    complete.  Every route must give the same bits: default (pre-sort) == SOT_FLAG_NO_SPECIALIZE (the row kernel's own merge sort) == the
+    oracle within the forward tolerance; the permutations left in row_perm_out are the stable argsort on EVERY row."""
     from oracle import sot_oracle as so
     from oracle.inputs import gen_inputs
     from oracle.make_golden import MODES
@@ -576,7 +576,7 @@ def test_rowpos_presort_kernel_and_its_sentinel(shape, mode):
     xp[0], yp[0] = torch.sort(xp[0]).values, torch.sort(yp[0]).values          # both sorted: identities
     xp[1] = torch.sort(xp[1]).values                                            # one sorted, one not: identity + permutation
     if n > 12:
-        xp[2, : n - 1] *= 1e-9; xp[2, n - 1] = 1.0                              # clustered: the wave sort declines (sentinel; merge sort in the row kernel)
+        xp[2, : n - 1] *= 1e-9; xp[2, n - 1] = 1.0                              # clustered: the wave sort declines (merge sort by the same wavefront)
         yp[3] = torch.round(yp[3] * 3) / 3                                      # long runs of ties: declined
     p, flags = ctor_to_flags(MODES[mode])
     xd, yd, xpd, ypd = x.to(dev), y.to(dev), xp.to(dev), yp.to(dev)
