@@ -1244,6 +1244,7 @@ template <bool ROWPOS>
 hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs& b, size_t lds, int64_t want, int block,
                              hipStream_t s);
 hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
+hipError_t dispatch_forward_full_rowpos(int pm, const FwdArgs& a, hipStream_t s);   // per-row positions through handed-over permutations, 2048-point rows (round 6)
 hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, hipStream_t s);
 hipError_t dispatch_area_full(const FwdArgs& a, hipStream_t s);
 hipError_t dispatch_area_train(const BwdArgs& b, hipStream_t s);
@@ -1285,6 +1286,7 @@ template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, cons
 #endif
 #if !(SOT_PART & 128)
 hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+hipError_t dispatch_forward_full_rowpos(int, const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_area_full(const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_area_train(const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
@@ -2199,6 +2201,14 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 512)
     full_rt = false;
 #endif
+    // per-row positions with their permutations at hand (handed in, or just written by the pre-sort kernel), 2048-point rows: the compile-time-length
+    // kernel with a position copy of its own per row (sot_forward_full.inc: RP)
+    bool full_rp = l.rowpos && l.a.perm_in != nullptr && !quant && pr->n == 2048 && pr->m == 2048 && l.vec && (pr->flags & SOT_FLAG_REQUIRE_SORT) &&
+                   (reinterpret_cast<uintptr_t>(l.a.perm_in) & 15) == 0 && !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
+#if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
+    full_rp = false;
+#endif
+    if (full_rp) return dispatch_forward_full_rowpos(l.pm, l.a, l.s) == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
     // p = 1 on one grid shared by both measures, no cutoff: the merge-free kernel (sot_forward_full.inc: sot_area_full_kernel)
     const bool area = (full || full_rt) && l.pm == 1 && (pr->flags & SOT_FLAG_SAME_GRID) && !(pr->flags & (SOT_FLAG_LIMIT_Q | SOT_FLAG_NO_AREA));
     const hipError_t e = area       ? (full ? dispatch_area_full(l.a, l.s) : dispatch_area_full_rt(l.a, l.s))
