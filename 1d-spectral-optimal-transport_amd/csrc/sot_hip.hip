@@ -1246,6 +1246,7 @@ hipError_t dispatch_backward(const LaunchCfg& c, int pm, bool vec, const BwdArgs
 hipError_t dispatch_forward_full(const LaunchCfg& c, int pm, const FwdArgs& a, size_t lds, int64_t want, int block, hipStream_t s);
 hipError_t dispatch_forward_full_rowpos(int pm, const FwdArgs& a, hipStream_t s);   // per-row positions through handed-over permutations, 2048-point rows (round 6)
 hipError_t dispatch_backward_full(const LaunchCfg& c, int pm, const BwdArgs& b, hipStream_t s);
+hipError_t dispatch_backward_full_rowpos(int pm, const BwdArgs& b, hipStream_t s);   // per-row positions through handed-over permutations, 2048-point rows (round 6)
 hipError_t dispatch_area_full(const FwdArgs& a, hipStream_t s);
 hipError_t dispatch_area_train(const BwdArgs& b, hipStream_t s);
 bool area_train_supports(int n);
@@ -1288,6 +1289,7 @@ template <> hipError_t dispatch_backward<true>(const LaunchCfg&, int, bool, cons
 hipError_t dispatch_forward_full(const LaunchCfg&, int, const FwdArgs&, size_t, int64_t, int, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_forward_full_rowpos(int, const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_backward_full(const LaunchCfg&, int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
+hipError_t dispatch_backward_full_rowpos(int, const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_area_full(const FwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 hipError_t dispatch_area_train(const BwdArgs&, hipStream_t) { return hipErrorInvalidDeviceFunction; }
 bool area_train_supports(int) { return false; }
@@ -2245,7 +2247,13 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 1024)
     full_rt = false;
 #endif
-    if ((full || full_rt) && gx == nullptr && row_loss_out != nullptr) {   // the y-only full-row kernel accumulates the loss on its walk
+    // per-row positions with their permutations at hand, 2048-point rows: the compile-time-length kernel with a position copy of its own per row
+    bool full_rp = l.rowpos && b.f.perm_in != nullptr && pr->n == 2048 && pr->m == 2048 && l.vec && (pr->flags & SOT_FLAG_REQUIRE_SORT) &&
+                   (reinterpret_cast<uintptr_t>(b.f.perm_in) & 15) == 0 && !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
+#if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
+    full_rp = false;
+#endif
+    if ((full || full_rt || full_rp) && gx == nullptr && row_loss_out != nullptr) {   // the y-only full-row kernel accumulates the loss on its walk
         b.f.row_loss = row_loss_out;
         if (mean_tail != nullptr) b.f.mt = *mean_tail;
         if (fused) *fused = true;
@@ -2256,6 +2264,7 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
     const bool area = full && gx == nullptr && l.pm == 1 && area_train_supports(pr->n) && (pr->flags & SOT_FLAG_SAME_GRID) && (pr->flags & SOT_FLAG_TIE_FREE_GRADIENT) &&
                       !(pr->flags & (SOT_FLAG_LIMIT_Q | SOT_FLAG_NO_AREA));
     const hipError_t e = area       ? dispatch_area_train(b, l.s)
+                         : full_rp  ? dispatch_backward_full_rowpos(l.pm, b, l.s)
                          : full     ? dispatch_backward_full(l.cfg, l.pm, b, l.s)
                          : full_rt  ? dispatch_backward_full_rt(l.pm, b, l.s)
                          : l.rowpos ? dispatch_backward<true>(l.cfg, l.pm, l.vec, b, l.lds, l.want, l.block, l.s)
