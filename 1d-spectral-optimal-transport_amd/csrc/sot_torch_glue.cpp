@@ -433,6 +433,108 @@ at::Tensor mss_loss(const at::Tensor& target, const at::Tensor& estimate, const 
     return MssLoss::apply(target, estimate, windows, fft_sizes, mag_weight, logmag_weight, l2, per_clip, grad);
 }
 
+// ---- round 6: the WHOLE loss block of the paper's training step (trainer.py:183-245 with train_config.yaml:73-102: `MixOfLosses([MSSLoss,
+// Wasserstein1D], weights)` on the audio pair and on its STFT magnitudes, the sum of the two means, gradient into the estimate's audio) as ONE
+// host call and ONE autograd node.  Module by module the step is ~25 launches, fifteen of them the trainer's own arithmetic (`* weight`,
+// `.mean()` of a scalar, `0 + value`, the autograd engine's gradient accumulation): ~44 of its 127 us at the paper's 64 clips.  Here the
+// forward runs plan -> STFT pair -> SOT loss + d mean / d spectrum -> STFT backward from the stored spectrum, accumulated INTO the gradient
+// the MSS kernels wrote (their weights carry the mix weight; the SOT's goes into its gradient scale), and one addition of the two scalars.  The
+// backward multiplies the stored gradient by the upstream scalar.  (The MSS kernels on a second stream beside the STFT -> SOT chain -- the
+// two are independent until the accumulation -- measured no gain: 96.0 against 97.1 us replayed at 64 clips, and 50 us more host time eager.)
+class MixLossStep : public torch::autograd::Function<MixLossStep> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window,
+                              const at::Tensor& xpos, const at::Tensor& ypos, int64_t n_fft, int64_t hop, double p, int64_t flags,
+                              const std::vector<at::Tensor>& mss_windows, const std::vector<int64_t>& mss_sizes, double mag_weight,
+                              double logmag_weight, bool l2, double w_mss, double w_sot, bool grad)
+    {
+        TORCH_CHECK(target.is_cuda() && target.scalar_type() == at::kFloat && target.dim() == 2 && target.is_contiguous() &&
+                    estimate.is_cuda() && estimate.scalar_type() == at::kFloat && estimate.is_contiguous() && estimate.sizes() == target.sizes() &&
+                    target.size(0) > 0, "sot glue: target and estimate must be contiguous float32 GPU tensors [clips, samples] of one shape");
+        TORCH_CHECK(window.is_cuda() && window.scalar_type() == at::kFloat && window.is_contiguous() && window.numel() == n_fft &&
+                    reinterpret_cast<uintptr_t>(window.data_ptr<float>()) % 8 == 0, "sot glue: window must hold n_fft float32 taps, 8-byte aligned");
+        const int n = (int)mss_sizes.size();
+        TORCH_CHECK(n >= 1 && n <= 8 && (int)mss_windows.size() == n, "sot glue: one window per FFT size, at most 8");
+        int sizes[8];
+        const float* wins[8];
+        for (int i = 0; i < n; ++i) {
+            sizes[i] = (int)mss_sizes[i];
+            TORCH_CHECK(mss_windows[i].is_cuda() && mss_windows[i].scalar_type() == at::kFloat && mss_windows[i].is_contiguous() &&
+                        mss_windows[i].numel() == mss_sizes[i] && reinterpret_cast<uintptr_t>(mss_windows[i].data_ptr<float>()) % 8 == 0,
+                        "sot glue: window ", i, " must hold n_fft float32 taps, 8-byte aligned");
+            wins[i] = mss_windows[i].data_ptr<float>();
+        }
+        const int64_t clips = target.size(0), samples = target.size(1);
+        const int64_t frames = g_api.stft_frames(samples, (int)hop), bins = n_fft / 2 + 1;
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(target.device());
+        void* st = current_stream(target);
+        const size_t mss_bytes = g_api.mss_ws(clips, samples, sizes, n);
+        TORCH_CHECK(mss_bytes > 0, "libsot_hip: unsupported size (status ", (int)SOT_ERR_UNSUPPORTED_SIZE, ")");
+        at::Tensor mss_ws = at::empty({(int64_t)mss_bytes}, target.options().dtype(at::kByte));
+        at::Tensor mss_loss = at::empty({}, target.options());
+        at::Tensor grad_audio = grad ? at::empty({clips, samples}, target.options()) : at::Tensor();
+        at::Tensor mag = at::empty({2 * clips, frames, bins}, target.options());
+        at::Tensor cplx = grad ? at::empty({clips, frames, bins, 2}, target.options()) : at::Tensor();
+
+        // fresh plan, both magnitude spectrograms in one launch, SOT loss (+ d (w_sot * mean) / d spectrum)
+        if (!(xpos.is_same(ypos) || (xpos.data_ptr() == ypos.data_ptr() && xpos.numel() == ypos.numel()))) flags &= ~(int64_t)SOT_FLAG_SAME_GRID;
+        const std::vector<at::Tensor> pl = make_plan(xpos, ypos);
+        check_status(g_api.stft_pair(target.data_ptr<float>(), samples, estimate.data_ptr<float>(), samples, clips, samples,
+                                     window.data_ptr<float>(), (int)n_fft, (int)hop, mag.data_ptr<float>(),
+                                     grad ? cplx.data_ptr<float>() : nullptr, st), p);
+        const at::Tensor rows_x = mag.narrow(0, 0, clips).view({clips * frames, bins});
+        const at::Tensor rows_y = mag.narrow(0, clips, clips).view({clips * frames, bins});
+        const Plan plan{pl[0], pl[1], pl[2], pl[3], pl[4]};
+        sot_problem pr = make_problem(rows_x, rows_y, plan, p, flags);
+        at::Tensor rows = at::empty({pr.B}, target.options());
+        at::Tensor sot_mean = at::empty({}, target.options());
+        at::Tensor gy;
+        if (grad) {
+            gy = at::empty({clips, frames, bins}, target.options());
+            check_status(g_api.loss_and_grad(&pr, rows.data_ptr<float>(), (double)pr.B, sot_mean.data_ptr<float>(), nullptr,
+                                             (float)(w_sot / (double)pr.B), gy.data_ptr<float>(), nullptr, nullptr, 0, st), p);
+        } else {
+            check_status(g_api.loss(&pr, rows.data_ptr<float>(), (double)pr.B, 0, 0.0f, sot_mean.data_ptr<float>(), nullptr, nullptr, nullptr, 0, st), p);
+        }
+
+        // MSSLoss * w_mss and its gradient: the mix weight rides on the two distance weights
+        check_status(g_api.mss(target.data_ptr<float>(), samples, estimate.data_ptr<float>(), samples, clips, samples, sizes, wins, n,
+                               (float)(mag_weight * w_mss), (float)(logmag_weight * w_mss), 1e-5f, l2 ? 1 : 0, 0, mss_loss.data_ptr<float>(),
+                               grad ? grad_audio.data_ptr<float>() : nullptr, mss_ws.data_ptr(), mss_bytes, st), 1.0);
+        if (grad) {   // d (w_sot * SOT mean) / d estimate, added to the MSS gradient inside the kernel
+            const size_t ws_bytes = g_api.stft_backward_ws(clips, samples, (int)n_fft, (int)hop);
+            at::Tensor ws = at::empty({(int64_t)(ws_bytes > 0 ? ws_bytes : 1)}, target.options().dtype(at::kByte));
+            check_status(g_api.stft_backward(nullptr, cplx.data_ptr<float>(), clips, samples, samples, window.data_ptr<float>(), (int)n_fft, (int)hop,
+                                             gy.data_ptr<float>(), nullptr, grad_audio.data_ptr<float>(), 1, ws.data_ptr(), ws_bytes, st), 1.0);
+            ctx->saved_data["grad_audio"] = grad_audio;
+        }
+        return w_sot == 1.0 ? at::add(mss_loss, sot_mean) : at::add(mss_loss, sot_mean, w_sot);
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs)
+    {
+        at::Tensor g = grad_outputs[0];
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        const at::Tensor grad_audio = ctx->saved_data["grad_audio"].toTensor();
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(grad_audio.device());
+        at::Tensor out = grad_audio * g;   // the stored gradient is never modified: a retained graph can be walked again
+        return {at::Tensor(), out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor mix_loss_step(const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos,
+                         int64_t n_fft, int64_t hop, double p, int64_t flags, const std::vector<at::Tensor>& mss_windows,
+                         const std::vector<int64_t>& mss_sizes, double mag_weight, double logmag_weight, bool l2, double w_mss, double w_sot)
+{
+    TORCH_CHECK(g_api.mss != nullptr && g_api.stft_pair != nullptr, "sot glue: bind() has not been called");
+    TORCH_CHECK(!(at::GradMode::is_enabled() && (target.requires_grad() || xpos.requires_grad() || ypos.requires_grad())),
+                "sot glue: gradients w.r.t. the target or the positions are not this path's case");
+    const bool grad = at::GradMode::is_enabled() && estimate.requires_grad();
+    return MixLossStep::apply(target, estimate, window, xpos, ypos, n_fft, hop, p, flags, mss_windows, mss_sizes, mag_weight, logmag_weight, l2, w_mss,
+                              w_sot, grad);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -444,5 +546,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("make_plan", &make_plan, "sot_prepare_positions into one allocation: (sorted x, sorted y, x permutation, y permutation, identity flags)");
     m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
     m.def("stft_magnitude", &stft_magnitude, "[clips, samples] -> [clips, frames, n_fft / 2 + 1] magnitudes (features.TorchSTFT); differentiable w.r.t. the audio");
+    m.def("mix_loss_step", &mix_loss_step, "MixOfLosses([MSSLoss, Wasserstein1D]) of the paper's training step on an audio pair: one call, one node; differentiable w.r.t. the estimate's audio");
     m.def("mss_loss", &mss_loss, "MSSLoss in two launches (sot_mss_loss_and_grad); differentiable w.r.t. the estimate's audio");
 }

@@ -448,18 +448,69 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
     return loss_module(spec_x, spec_y, x_pos=pos[0], y_pos=pos[1])
 
 
+FUSED_TRAINER_STEP = True    # module switch: trainer_loss_step may take the one-node form below (tests and the bench compare both)
+
+
+def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window):
+    """`MixOfLosses([MSSLoss, Wasserstein1D], weights)` of the paper's step (train_config.yaml:73-102) on a float32 GPU audio pair as ONE
+    C++ call and ONE autograd node (csrc/sot_torch_glue.cpp: MixLossStep) -> the 0-d total, or None when the configuration is not that
+    node's case (any other mix, a target that asks for a gradient, `hinge`, per-row positions, transform sizes outside the fused MSS
+    kernels): the caller then composes the modules one by one.  Same kernels as the module-by-module route; what goes away is the trainer's
+    own arithmetic around them (`* weight`, `.mean()` of a scalar, `0 + value`, gradient accumulation: ~15 launches)."""
+    from . import losses as L
+    from . import _native as nat
+    fns, weights = list(loss_fn.losses), list(loss_fn.weights)
+    if len(fns) != 2 or not all(isinstance(w, (int, float)) for w in weights):
+        return None
+    mss = next((f for f in fns if type(f) is L.MSSLoss), None)
+    sot = next((f for f in fns if type(f) is L.Wasserstein1D), None)
+    if mss is None or sot is None:
+        return None
+    w_mss, w_sot = float(weights[fns.index(mss)]), float(weights[fns.index(sot)])
+    grad_on = torch.is_grad_enabled()
+    if not (x.is_cuda and x_hat.is_cuda and x.dtype is torch.float32 and x_hat.dtype is torch.float32 and x.ndim == 2 and x.shape == x_hat.shape
+            and x.shape[0] > 0 and x.is_contiguous() and x_hat.is_contiguous() and x.device == x_hat.device
+            and not (grad_on and (x.requires_grad or x_pos.requires_grad or y_pos.requires_grad))):
+        return None
+    samples, bins = x.shape[1], n_fft // 2 + 1
+    sizes = tuple(int(s) for s in mss.fft_sizes)
+    kind = str(mss.loss_type).upper()
+    if not (L.MSS_FUSED and kind in ("L1", "L2") and (mss.mag_weight > 0 or mss.logmag_weight > 0) and 1 <= len(sizes) <= 8
+            and all(s in nat.MSS_FUSED_SIZES and hip_stft_supported(s, int(s * 0.25), samples) for s in sizes)):
+        return None
+    if not (L.EARLY_GRADIENT and SAVE_SPECTRUM and not sot.hinge and sot.require_sort and sot.p >= 1 and hip_stft_supported(n_fft, hop, samples)
+            and 2 * bins <= 12000 and L._fresh_grid_ok(x_pos, x, bins) and L._fresh_grid_ok(y_pos, x, bins)):
+        return None
+    glue = nat.glue()
+    if glue is None or not hasattr(glue, "mix_loss_step"):
+        return None
+    flags = L._flags(sot.square_dist, sot.dont_normalize, sot.limit_quantile_range, sot.require_sort)
+    if getattr(sot, "tie_free_gradient", False):
+        flags |= nat.FLAG_TIE_FREE_GRADIENT
+    return glue.mix_loss_step(x, x_hat, _cached_window(window, n_fft, x.device), x_pos, y_pos, int(n_fft), int(hop), float(sot.p), int(flags),
+                              _cached_windows(None, sizes, x.device), list(sizes), float(mss.mag_weight), float(mss.logmag_weight), kind == "L2",
+                              w_mss, w_sot)
+
+
 def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop",
-                      sample_rate: float = 16000.0, positions=None) -> torch.Tensor:
+                      sample_rate: float = 16000.0, positions=None, fused=None) -> torch.Tensor:
     """The loss block of the reference's `trainer.shared_step` (trainer.py:183-245) for a `MixOfLosses` (or a single loss module):
     unit-scaled bin frequencies built AFRESH (`x_pos = torch.tensor(transform.get_frequencies()).to(device); x_pos = x_pos / x_pos.max();
     y_pos = x_pos.clone()`, :192-197), both signals through the transform (`TorchSTFT`, :199-200), `MSSLoss` fed the audio and every
     other loss the spectra, each `loss_fn(a, b, x_pos=, y_pos=) * weight` (:206-221), the total = sum of `value.mean()` (:231-236).
     `positions`: a device tensor of bin frequencies to start from instead of the host tensor (a captured step cannot copy from pageable
-    host memory); the division and the clone still run per step.  The caller backpropagates into `x_hat`."""
+    host memory); the division and the clone still run per step.  The caller backpropagates into `x_hat`.
+    `fused` (None = the module switch FUSED_TRAINER_STEP): the paper's own mix -- `MixOfLosses([MSSLoss, Wasserstein1D])` on float32 GPU
+    audio -- runs as one host call and one autograd node (_fused_mix_step: the same kernels, none of the per-module arithmetic between
+    them); every other configuration, and `fused=False`, composes the modules one by one exactly as the reference's trainer does."""
     if positions is None:
         positions = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device)   # torch.tensor(get_frequencies()).to(device)
     x_pos = positions / positions.max()
     y_pos = x_pos.clone()
+    if (FUSED_TRAINER_STEP if fused is None else fused) and hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):
+        total = _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window)
+        if total is not None:
+            return total
     spec_x = stft_magnitude(x, n_fft, hop, window)
     spec_x_hat = stft_magnitude(x_hat, n_fft, hop, window)
     if hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):   # isinstance(self.loss_fn, losses.MixOfLosses)

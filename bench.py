@@ -666,10 +666,11 @@ def paper_loss_workloads(dev, nat, timed, n):
         hats = [spectra.harmonic_batch(clips, generator=gen, device=dev).requires_grad_(True) for _ in range(2)]
         io_bytes = 3 * clips * 4096 * 4   # both clips' audio in, the estimate's gradient out: what the block must move
 
-        def full_step(i, fresh_host_positions=True):
+        def full_step(i, fresh_host_positions=True, fused=None):   # fused=None: what a caller of trainer_loss_step gets (the one-node form)
             e = hats[i % 2]
             e.grad = None
-            spectra.trainer_loss_step(mix, x, e, 2048, 256, "flattop", 16000.0, positions=None if fresh_host_positions else freqs_dev).backward(seed)
+            spectra.trainer_loss_step(mix, x, e, 2048, 256, "flattop", 16000.0, positions=None if fresh_host_positions else freqs_dev,
+                                      fused=fused).backward(seed)
 
         def mss_step(i):
             e = hats[i % 2]
@@ -695,11 +696,13 @@ def paper_loss_workloads(dev, nat, timed, n):
             return {"ms": ms, "what": what, "algorithmic_bytes": io_bytes, "frac": io_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "clips": clips, **kw}
 
         tag = f"{clips}clips"
-        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 verbatim (x_pos from the host every step), eager, launched from Python")
+        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 (x_pos from the host every step) as spectra.trainer_loss_step runs it: the mix of MSSLoss and Wasserstein1D as ONE host call / autograd node (round 6), eager, launched from Python")
         out[f"paper_loss_step_{tag}_device_positions"] = entry(timed(lambda i: full_step(i, False), n), "the same with the bin frequencies already on the device (division + clone per step)")
+        out[f"paper_loss_step_{tag}_module_by_module"] = entry(timed(lambda i: full_step(i, False, False), n), "the same step composed module by module as the reference's trainer does (fused=False: rounds 4-5's form), device positions, eager")
         out[f"mssloss_forward_backward_{tag}"] = entry(timed(mss_step, n), "MSSLoss(6 scales, L1, mag_weight 1) forward + backward into the estimate, eager")
         out[f"sot_slice_forward_backward_{tag}"] = entry(timed(sot_step, n), "STFT pair + Wasserstein1D (paper mode) forward + backward, eager (= config 5's slice)")
-        for key, fn in ((f"paper_loss_step_{tag}", lambda i: full_step(i, False)), (f"mssloss_forward_backward_{tag}", mss_step),
+        for key, fn in ((f"paper_loss_step_{tag}", lambda i: full_step(i, False)), (f"paper_loss_step_{tag}_module_by_module", lambda i: full_step(i, False, False)),
+                        (f"mssloss_forward_backward_{tag}", mss_step),
                         (f"sot_slice_forward_backward_{tag}", sot_step)):
             try:
                 out[key + "_graph_replay"] = entry(replayed(fn), "the same kernels replayed from ONE HIP graph (GPU time of the block)")
@@ -829,6 +832,7 @@ def flatten_for_scalar_readers(rec, B, N):
         "paper_step_64clips_graph_ms": ms_of("paper_loss_step_64clips_graph_replay"),
         "paper_step_64clips_eager_ms": ms_of("paper_loss_step_64clips"),
         "paper_step_256clips_graph_ms": ms_of("paper_loss_step_256clips_graph_replay"),
+        "paper_step_64clips_module_by_module_graph_ms": ms_of("paper_loss_step_64clips_module_by_module_graph_replay"),
         "mss_64clips_graph_ms": ms_of("mssloss_forward_backward_64clips_graph_replay"),
         "mss_256clips_graph_ms": ms_of("mssloss_forward_backward_256clips_graph_replay"),
         "sot_slice_64clips_graph_ms": ms_of("sot_slice_forward_backward_64clips_graph_replay"),

@@ -798,3 +798,95 @@ def test_one_wave_per_frame_kernels_of_large_batches(hop, clips, samples):
     want2 = nat.stft_mag_backward(a, win, n_fft, hop, gm, grad_scale=up, accumulate_into=base.clone())
     got2 = nat.stft_mag_backward(a, win, n_fft, hop, gm, grad_scale=up, accumulate_into=base.clone(), spec=spec)
     assert float((got2 - want2).abs().max()) <= 2e-5 * max(gpeak, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,weights,mss_kw,sot_kw", [
+    ("L1", [0.05, 1], dict(mag_weight=1, logmag_weight=0), dict(p=2, square_dist=True, dont_normalize=True, limit_quantile_range=True)),   # the paper's YAML
+    ("L2", [0.3, 0.7], dict(mag_weight=0.5, logmag_weight=1.0), dict(p=1)),
+    ("L1", [2, 1], dict(mag_weight=0, logmag_weight=1.0), dict(p=2, square_dist=False, dont_normalize=False, limit_quantile_range=False)),
+])
+def test_one_node_loss_step_equals_the_module_by_module_step(kind, weights, mss_kw, sot_kw):
+    """Round 6: spectra.trainer_loss_step runs the paper's mix -- MSSLoss on the audio, Wasserstein1D on the spectra -- as ONE host call and ONE
+    autograd node (csrc/sot_torch_glue.cpp: MixLossStep; same kernels, none of the trainer's arithmetic between them).  Against the
+    module-by-module composition (fused=False, what the fixture tests above pin to the reference): the total to 2e-7 relative (the mix
+    weight rides on the MSS kernel's distance weights instead of multiplying its result: one rounding), the audio gradient to 1e-6 of its
+    peak; in either order of the two losses; with an upstream factor; without a gradient; and the configurations the node does not take
+    (a third loss, a target that asks for a gradient) fall back to the composition."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    from sot_amd.losses import MixOfLosses, MSSLoss, Wasserstein1D
+    native()
+    dev = device()
+    gen = torch.Generator(device=dev).manual_seed(77)
+    x = spectra.harmonic_batch(6, generator=gen, device=dev)
+    e = spectra.harmonic_batch(6, generator=gen, device=dev)
+    mss = MSSLoss(fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type=kind, **mss_kw)
+    sot = Wasserstein1D(require_sort=True, **sot_kw)
+    for fns, ws in (([mss, sot], weights), ([sot, mss], weights[::-1])):
+        mix = MixOfLosses(fns, ws).to(dev)
+        results = {}
+        for fused in (False, True):
+            est = e.clone().requires_grad_(True)
+            loss = spectra.trainer_loss_step(mix, x, est, fused=fused)
+            (loss * 3.0).backward()
+            results[fused] = (loss.detach(), est.grad)
+            if fused:
+                assert "MixLossStep" in loss.grad_fn.name(), loss.grad_fn.name()
+        (l0, g0), (l1, g1) = results[False], results[True]
+        assert abs(float(l1) - float(l0)) <= 2e-7 * abs(float(l0)), (float(l0), float(l1))
+        assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
+        with torch.no_grad():
+            assert abs(float(spectra.trainer_loss_step(mix, x, e, fused=True)) - float(l0)) <= 2e-7 * abs(float(l0))
+    # not the node's case: composed module by module, same values as fused=False
+    est = e.clone().requires_grad_(True)
+    assert "MixLossStep" not in spectra.trainer_loss_step(MixOfLosses([mss, sot, sot], [0.05, 1, 1]).to(dev), x, est).grad_fn.name()
+    tgt = x.clone().requires_grad_(True)
+    mix = MixOfLosses([mss, sot], weights).to(dev)
+    loss = spectra.trainer_loss_step(mix, tgt, est)
+    assert "MixLossStep" not in loss.grad_fn.name()
+    loss.backward()
+    assert tgt.grad is not None and est.grad is not None
+
+
+@pytest.mark.gpu
+def test_one_node_loss_step_in_a_hip_graph():
+    """The one-node step captured into a HIP graph and replayed on new audio: the same loss and gradient as the eager call."""
+    from gpu_util import device, native
+    from sot_amd import spectra
+    native()
+    dev = device()
+    mix = _paper_mix().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(78)
+    x = spectra.harmonic_batch(8, generator=gen, device=dev)
+    est = spectra.harmonic_batch(8, generator=gen, device=dev).requires_grad_(True)
+    freqs = torch.fft.rfftfreq(2048, d=1.0 / 16000.0).to(dev)
+
+    def step():
+        est.grad = None
+        loss = spectra.trainer_loss_step(mix, x, est, positions=freqs)
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    grad_buffer = est.grad
+    new_x, new_e = spectra.harmonic_batch(8, generator=gen, device=dev), spectra.harmonic_batch(8, generator=gen, device=dev)
+    with torch.no_grad():
+        x.copy_(new_x)
+        est.copy_(new_e)
+    graph.replay()
+    torch.cuda.synchronize()
+    got_loss, got_grad = float(captured), grad_buffer.clone()
+    ref = new_e.clone().requires_grad_(True)
+    want = spectra.trainer_loss_step(mix, new_x, ref, positions=freqs)
+    want.backward()
+    assert got_loss == float(want)
+    assert torch.equal(got_grad, ref.grad)
