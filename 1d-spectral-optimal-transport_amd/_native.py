@@ -31,7 +31,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 11                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 12                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -57,6 +57,7 @@ EXPORTS = {
     "sot_profile_next_launch": (ctypes.c_int, [ctypes.c_int]),
     "sot_profile_elapsed_ms": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     "sot_prepare_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sot_prepare_unit_positions": (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sot_w1d_forward": (ctypes.c_int, [ctypes.POINTER(SotProblem), _vp, _vp, ctypes.c_size_t, _vp]),
     "sot_w1d_reduce_mean": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_float,
                                            _vp, _vp, _vp]),
@@ -295,9 +296,10 @@ def make_problem(x, y, xpos, ypos, p, flags, plan=None, perm_out=None, perm_in=N
 
 
 class PositionPlan:
-    """Sorted shared positions + permutation + identity flags (sot_prepare_positions)."""
+    """Sorted shared positions + permutation + identity flags (sot_prepare_positions); unit: of xpos / xpos.max() and ypos / ypos.max()
+    (sot_prepare_unit_positions: the grid the reference's trainer rebuilds every step, trainer.py:196-197, out of one launch)."""
 
-    def __init__(self, xpos: torch.Tensor, ypos: torch.Tensor):
+    def __init__(self, xpos: torch.Tensor, ypos: torch.Tensor, unit: bool = False):
         require_hip(xpos, ypos)
         lib = load()
         n, m = xpos.numel(), ypos.numel()
@@ -309,16 +311,16 @@ class PositionPlan:
             self.stream = stream_ptr(dev)
             if g is not None and xp.ndim == 1 and yp.ndim == 1:
                 # one allocation + one launch (the reference's trainer makes fresh positions, hence a fresh plan, every step)
-                self.xpos_sorted, self.ypos_sorted, self.xperm, self.yperm, self.ident = g.make_plan(xp, yp)
+                self.xpos_sorted, self.ypos_sorted, self.xperm, self.yperm, self.ident = g.make_plan(xp, yp, bool(unit))
             else:
                 self.xpos_sorted = torch.empty(n, dtype=torch.float32, device=dev)
                 self.ypos_sorted = torch.empty(m, dtype=torch.float32, device=dev)
                 self.xperm = torch.empty(n, dtype=torch.int32, device=dev)
                 self.yperm = torch.empty(m, dtype=torch.int32, device=dev)
                 self.ident = torch.empty(2, dtype=torch.int32, device=dev)
-                check(lib.sot_prepare_positions(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(),
-                                                self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
-                                                self.yperm.data_ptr(), self.ident.data_ptr(), self.stream))
+                prepare = lib.sot_prepare_unit_positions if unit else lib.sot_prepare_positions
+                check(prepare(xp.data_ptr(), yp.data_ptr(), n, m, self.xpos_sorted.data_ptr(), self.ypos_sorted.data_ptr(), self.xperm.data_ptr(),
+                              self.yperm.data_ptr(), self.ident.data_ptr(), self.stream))
             # the plan is cached and may be consumed from other streams: they wait on this event (see use_plan)
             self.ready = torch.cuda.Event()
             self.ready.record(torch.cuda.current_stream(dev))

@@ -1257,7 +1257,7 @@ hipError_t dispatch_forward_full_rt(int pm, const FwdArgs& a, hipStream_t s);
 hipError_t dispatch_area_full_rt(const FwdArgs& a, hipStream_t s);
 hipError_t dispatch_backward_full_rt(int pm, const BwdArgs& b, hipStream_t s);
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
-                   hipStream_t s);
+                   hipStream_t s, bool unit = false);
 int setup_launch(const sot_problem* pr, bool with_grad, void* workspace, size_t workspace_bytes, void* stream, Launch* out);
 int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, float* Q, float* U, float* V, bool quant,
                 void* workspace, size_t workspace_bytes, void* stream, const MeanTail* mean_tail = nullptr);
@@ -1732,6 +1732,9 @@ int run_column_sum(const float* rows, int64_t B, int n, int64_t stride, float* o
 // Shared-position preparation (losses.py:287-288 for row-invariant positions): one workgroup per
 // array checks sortedness and, if needed, sorts (position, index) pairs in LDS.
 // ---------------------------------------------------------------------------------------------
+// UNIT: the array is divided by its maximum first (trainer.py:196-197: `x_pos = x_pos / x_pos.max()` -- torch.max's NaN rule, IEEE
+// division: the same floats as the two torch kernels), so that a training step that rebuilds its grid pays one launch, not four.
+template <bool UNIT>
 __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     const float* __restrict__ xpos, const float* __restrict__ ypos, int n, int m,
     float* __restrict__ sx, float* __restrict__ sy, int* __restrict__ px, int* __restrict__ py,
@@ -1749,8 +1752,32 @@ __global__ __launch_bounds__(1024) void sot_prepare_positions_kernel(
     int* const unsorted_flag = reinterpret_cast<int*>(smem + 2 * cap);  // all LDS is dynamic (16-B aligned carve)
     const int t = threadIdx.x, T = blockDim.x;
     if (t == 0) *unsorted_flag = 0;
+    float top = 1.0f;
+    if (UNIT) {   // max over the array: NaN wins (torch.max), otherwise order-free
+        float* const part = reinterpret_cast<float*>(unsorted_flag + 1);   // 16 floats behind the flag
+        float mx = -INFINITY;
+        bool nan = false;
+        for (int i = t; i < len; i += T) {
+            const float v = pos[i];
+            nan |= (v != v);
+            mx = fmaxf(mx, v);
+        }
+        if (nan) mx = NAN;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float o = __shfl_xor(mx, off);
+            mx = (mx != mx || o != o) ? NAN : fmaxf(mx, o);
+        }
+        if ((t & 63) == 0) part[t >> 6] = mx;
+        __syncthreads();
+        top = part[0];
+        for (int w = 1; w < (T >> 6); ++w) {
+            const float o = part[w];
+            top = (top != top || o != o) ? NAN : fmaxf(top, o);
+        }
+    }
     for (int i = t; i < npad; i += T) {
-        key[i] = (i < len) ? pos[i] : INFINITY;
+        key[i] = (i < len) ? (UNIT ? pos[i] / top : pos[i]) : INFINITY;
         idx[i] = (i < len) ? i : INT_MAX;
     }
     __syncthreads();
@@ -2109,16 +2136,21 @@ int launch_rowpos_sort(const float* xpos, const float* ypos, int64_t B, int n, i
 }
 
 int launch_prepare(const float* xpos, const float* ypos, int n, int m, float* sx, float* sy, int* px, int* py, int* ident,
-                          hipStream_t s)
+                          hipStream_t s, bool unit)
 {
     const int npad = sort16_npad(n > m ? n : m);
     if (npad > 16 * 1024) return SOT_ERR_UNSUPPORTED_SIZE;
-    const size_t prep_lds = (size_t)((sort16_capacity(npad) + 3) & ~3) * 8 + 16;
+    const size_t prep_lds = (size_t)((sort16_capacity(npad) + 3) & ~3) * 8 + 16 + 64;   // + the flag's slot + 16 partial maxima
     if (prep_lds > kLdsLimit) return SOT_ERR_UNSUPPORTED_SIZE;
-    static GridCache cache;
-    allow_full_lds_once(cache, reinterpret_cast<const void*>(sot_prepare_positions_kernel));
+    static GridCache cache, cache_unit;
     (void)hipGetLastError();  // do not inherit a stale error from earlier runtime calls
-    hipLaunchKernelGGL(sot_prepare_positions_kernel, dim3(2), dim3(1024), prep_lds, s, xpos, ypos, n, m, sx, sy, px, py, ident);
+    if (unit) {
+        allow_full_lds_once(cache_unit, reinterpret_cast<const void*>(sot_prepare_positions_kernel<true>));
+        hipLaunchKernelGGL(sot_prepare_positions_kernel<true>, dim3(2), dim3(1024), prep_lds, s, xpos, ypos, n, m, sx, sy, px, py, ident);
+    } else {
+        allow_full_lds_once(cache, reinterpret_cast<const void*>(sot_prepare_positions_kernel<false>));
+        hipLaunchKernelGGL(sot_prepare_positions_kernel<false>, dim3(2), dim3(1024), prep_lds, s, xpos, ypos, n, m, sx, sy, px, py, ident);
+    }
     return hipGetLastError() == hipSuccess ? SOT_OK : SOT_ERR_LAUNCH;
 }
 
@@ -2426,7 +2458,16 @@ int sot_prepare_positions(const float* xpos, const float* ypos, int32_t n, int32
     if (n < 1 || m < 1) return SOT_ERR_BAD_SHAPE;
     if (!xpos || !ypos || !xpos_sorted || !ypos_sorted || !xperm || !yperm || !perm_is_identity) return SOT_ERR_NULL_POINTER;
     return sot::launch_prepare(xpos, ypos, n, m, xpos_sorted, ypos_sorted, xperm, yperm, perm_is_identity,
-                               reinterpret_cast<hipStream_t>(stream));
+                               reinterpret_cast<hipStream_t>(stream), false);
+}
+
+int sot_prepare_unit_positions(const float* xpos, const float* ypos, int32_t n, int32_t m, float* xpos_sorted, float* ypos_sorted,
+                               int32_t* xperm, int32_t* yperm, int32_t* perm_is_identity, void* stream)
+{
+    if (n < 1 || m < 1) return SOT_ERR_BAD_SHAPE;
+    if (!xpos || !ypos || !xpos_sorted || !ypos_sorted || !xperm || !yperm || !perm_is_identity) return SOT_ERR_NULL_POINTER;
+    return sot::launch_prepare(xpos, ypos, n, m, xpos_sorted, ypos_sorted, xperm, yperm, perm_is_identity,
+                               reinterpret_cast<hipStream_t>(stream), true);
 }
 
 int sot_w1d_forward(const sot_problem* prob, float* row_loss, void* workspace, size_t workspace_bytes, void* stream)

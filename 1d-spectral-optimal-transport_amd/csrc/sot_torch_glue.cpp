@@ -32,6 +32,7 @@ struct Api {
     decltype(&sot_w1d_backward) backward = nullptr;
     decltype(&sot_scale_inplace) scale_inplace = nullptr;
     decltype(&sot_prepare_positions) prepare_positions = nullptr;
+    decltype(&sot_prepare_unit_positions) prepare_unit_positions = nullptr;
     decltype(&sot_stft_frames) stft_frames = nullptr;
     decltype(&sot_stft_mag_forward_pair_spec) stft_pair = nullptr;
     decltype(&sot_stft_mag_backward_spec) stft_backward = nullptr;
@@ -61,6 +62,7 @@ int64_t bind_library(const std::string& path)
     bind_symbol(handle, "sot_w1d_backward", g_api.backward);
     bind_symbol(handle, "sot_scale_inplace", g_api.scale_inplace);
     bind_symbol(handle, "sot_prepare_positions", g_api.prepare_positions);
+    bind_symbol(handle, "sot_prepare_unit_positions", g_api.prepare_unit_positions);
     bind_symbol(handle, "sot_stft_frames", g_api.stft_frames);
     bind_symbol(handle, "sot_stft_mag_forward_pair_spec", g_api.stft_pair);
     bind_symbol(handle, "sot_stft_mag_backward_spec", g_api.stft_backward);
@@ -205,7 +207,7 @@ at::Tensor mean_loss(const at::Tensor& x, const at::Tensor& y, const at::Tensor&
 // trainer builds x_pos / y_pos afresh every step (trainer.py:187-197), so a plan per step must cost one allocation and one launch,
 // not five allocations.  Returns (sorted x positions, sorted y positions, x permutation, y permutation, identity flags): views of one
 // buffer, each 256-byte aligned.
-std::vector<at::Tensor> make_plan(const at::Tensor& xpos, const at::Tensor& ypos)
+std::vector<at::Tensor> make_plan(const at::Tensor& xpos, const at::Tensor& ypos, bool unit = false)
 {
     TORCH_CHECK(g_api.prepare_positions != nullptr, "sot glue: bind() has not been called");
     TORCH_CHECK(xpos.is_cuda() && ypos.is_cuda() && xpos.scalar_type() == at::kFloat && ypos.scalar_type() == at::kFloat && xpos.dim() == 1 &&
@@ -219,9 +221,10 @@ std::vector<at::Tensor> make_plan(const at::Tensor& xpos, const at::Tensor& ypos
     at::Tensor ints = buf.view(at::kInt);
     at::Tensor xs = buf.narrow(0, 0, n), ys = buf.narrow(0, o_ys, m);
     at::Tensor xperm = ints.narrow(0, o_xp, n), yperm = ints.narrow(0, o_yp, m), ident = ints.narrow(0, o_id, 2);
-    check_status(g_api.prepare_positions(xpos.data_ptr<float>(), ypos.data_ptr<float>(), (int32_t)n, (int32_t)m, xs.data_ptr<float>(),
-                                         ys.data_ptr<float>(), xperm.data_ptr<int32_t>(), yperm.data_ptr<int32_t>(), ident.data_ptr<int32_t>(),
-                                         current_stream(xpos)), 1.0);
+    // unit: both grids divided by their maxima inside the launch (sot_prepare_unit_positions: trainer.py:196-197 without the three torch kernels)
+    check_status((unit ? g_api.prepare_unit_positions : g_api.prepare_positions)(
+                     xpos.data_ptr<float>(), ypos.data_ptr<float>(), (int32_t)n, (int32_t)m, xs.data_ptr<float>(), ys.data_ptr<float>(),
+                     xperm.data_ptr<int32_t>(), yperm.data_ptr<int32_t>(), ident.data_ptr<int32_t>(), current_stream(xpos)), 1.0);
     return {xs, ys, xperm, yperm, ident};
 }
 
@@ -446,7 +449,7 @@ public:
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window,
                               const at::Tensor& xpos, const at::Tensor& ypos, int64_t n_fft, int64_t hop, double p, int64_t flags,
                               const std::vector<at::Tensor>& mss_windows, const std::vector<int64_t>& mss_sizes, double mag_weight,
-                              double logmag_weight, bool l2, double w_mss, double w_sot, bool grad)
+                              double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions, bool grad)
     {
         TORCH_CHECK(target.is_cuda() && target.scalar_type() == at::kFloat && target.dim() == 2 && target.is_contiguous() &&
                     estimate.is_cuda() && estimate.scalar_type() == at::kFloat && estimate.is_contiguous() && estimate.sizes() == target.sizes() &&
@@ -478,7 +481,10 @@ public:
 
         // fresh plan, both magnitude spectrograms in one launch, SOT loss (+ d (w_sot * mean) / d spectrum)
         if (!(xpos.is_same(ypos) || (xpos.data_ptr() == ypos.data_ptr() && xpos.numel() == ypos.numel()))) flags &= ~(int64_t)SOT_FLAG_SAME_GRID;
-        const std::vector<at::Tensor> pl = make_plan(xpos, ypos);
+        // unit_positions: xpos / ypos are the transform's bin frequencies as they are; x_pos = f / f.max() and y_pos = x_pos.clone() happen inside
+        // the plan's launch -- two separate grids to the kernels, as in the trainer (never SOT_FLAG_SAME_GRID)
+        if (unit_positions) flags &= ~(int64_t)SOT_FLAG_SAME_GRID;
+        const std::vector<at::Tensor> pl = make_plan(xpos, ypos, unit_positions);
         check_status(g_api.stft_pair(target.data_ptr<float>(), samples, estimate.data_ptr<float>(), samples, clips, samples,
                                      window.data_ptr<float>(), (int)n_fft, (int)hop, mag.data_ptr<float>(),
                                      grad ? cplx.data_ptr<float>() : nullptr, st), p);
@@ -519,20 +525,20 @@ public:
         const c10::hip::HIPGuardMasqueradingAsCUDA guard(grad_audio.device());
         at::Tensor out = grad_audio * g;   // the stored gradient is never modified: a retained graph can be walked again
         return {at::Tensor(), out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
 
 at::Tensor mix_loss_step(const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos,
                          int64_t n_fft, int64_t hop, double p, int64_t flags, const std::vector<at::Tensor>& mss_windows,
-                         const std::vector<int64_t>& mss_sizes, double mag_weight, double logmag_weight, bool l2, double w_mss, double w_sot)
+                         const std::vector<int64_t>& mss_sizes, double mag_weight, double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions)
 {
     TORCH_CHECK(g_api.mss != nullptr && g_api.stft_pair != nullptr, "sot glue: bind() has not been called");
     TORCH_CHECK(!(at::GradMode::is_enabled() && (target.requires_grad() || xpos.requires_grad() || ypos.requires_grad())),
                 "sot glue: gradients w.r.t. the target or the positions are not this path's case");
     const bool grad = at::GradMode::is_enabled() && estimate.requires_grad();
     return MixLossStep::apply(target, estimate, window, xpos, ypos, n_fft, hop, p, flags, mss_windows, mss_sizes, mag_weight, logmag_weight, l2, w_mss,
-                              w_sot, grad);
+                              w_sot, unit_positions, grad);
 }
 
 }  // namespace
@@ -543,7 +549,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("bind", &bind_library, "dlopen libsot_hip.so at `path` and resolve the entry points; returns its ABI version");
     m.def("mean_loss", &mean_loss, "mean over the rows of W_p^p(x_r, y_r) on planned shared positions; differentiable w.r.t. y");
     m.def("mean_loss_fresh", &mean_loss_fresh, "mean_loss on raw 1-D position tensors: the plan is prepared inside the call (one allocation, one launch)");
-    m.def("make_plan", &make_plan, "sot_prepare_positions into one allocation: (sorted x, sorted y, x permutation, y permutation, identity flags)");
+    m.def("make_plan", &make_plan, "sot_prepare_positions into one allocation: (sorted x, sorted y, x permutation, y permutation, identity flags); unit: of x / max(x), y / max(y)",
+          pybind11::arg("xpos"), pybind11::arg("ypos"), pybind11::arg("unit") = false);
     m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
     m.def("stft_magnitude", &stft_magnitude, "[clips, samples] -> [clips, frames, n_fft / 2 + 1] magnitudes (features.TorchSTFT); differentiable w.r.t. the audio");
     m.def("mix_loss_step", &mix_loss_step, "MixOfLosses([MSSLoss, Wasserstein1D]) of the paper's training step on an audio pair: one call, one node; differentiable w.r.t. the estimate's audio");

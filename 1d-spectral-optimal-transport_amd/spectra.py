@@ -451,12 +451,14 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
 FUSED_TRAINER_STEP = True    # module switch: trainer_loss_step may take the one-node form below (tests and the bench compare both)
 
 
-def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window):
+def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_positions=False):
     """`MixOfLosses([MSSLoss, Wasserstein1D], weights)` of the paper's step (train_config.yaml:73-102) on a float32 GPU audio pair as ONE
     C++ call and ONE autograd node (csrc/sot_torch_glue.cpp: MixLossStep) -> the 0-d total, or None when the configuration is not that
     node's case (any other mix, a target that asks for a gradient, `hinge`, per-row positions, transform sizes outside the fused MSS
     kernels): the caller then composes the modules one by one.  Same kernels as the module-by-module route; what goes away is the trainer's
-    own arithmetic around them (`* weight`, `.mean()` of a scalar, `0 + value`, gradient accumulation: ~15 launches)."""
+    own arithmetic around them (`* weight`, `.mean()` of a scalar, `0 + value`, gradient accumulation: ~15 launches).
+    unit_positions: x_pos / y_pos are the bin frequencies as they are and the node divides them by their maximum inside the plan's launch
+    (sot_prepare_unit_positions: `x_pos / x_pos.max()` and the clone of trainer.py:196-197 without their three torch kernels)."""
     from . import losses as L
     from . import _native as nat
     fns, weights = list(loss_fn.losses), list(loss_fn.weights)
@@ -489,7 +491,7 @@ def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window):
         flags |= nat.FLAG_TIE_FREE_GRADIENT
     return glue.mix_loss_step(x, x_hat, _cached_window(window, n_fft, x.device), x_pos, y_pos, int(n_fft), int(hop), float(sot.p), int(flags),
                               _cached_windows(None, sizes, x.device), list(sizes), float(mss.mag_weight), float(mss.logmag_weight), kind == "L2",
-                              w_mss, w_sot)
+                              w_mss, w_sot, bool(unit_positions))
 
 
 def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop",
@@ -499,18 +501,19 @@ def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int 
     y_pos = x_pos.clone()`, :192-197), both signals through the transform (`TorchSTFT`, :199-200), `MSSLoss` fed the audio and every
     other loss the spectra, each `loss_fn(a, b, x_pos=, y_pos=) * weight` (:206-221), the total = sum of `value.mean()` (:231-236).
     `positions`: a device tensor of bin frequencies to start from instead of the host tensor (a captured step cannot copy from pageable
-    host memory); the division and the clone still run per step.  The caller backpropagates into `x_hat`.
+    host memory); the division and the clone still run per step (in the one-node form: inside the plan's launch).  The caller backpropagates into `x_hat`.
     `fused` (None = the module switch FUSED_TRAINER_STEP): the paper's own mix -- `MixOfLosses([MSSLoss, Wasserstein1D])` on float32 GPU
     audio -- runs as one host call and one autograd node (_fused_mix_step: the same kernels, none of the per-module arithmetic between
     them); every other configuration, and `fused=False`, composes the modules one by one exactly as the reference's trainer does."""
     if positions is None:
         positions = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device)   # torch.tensor(get_frequencies()).to(device)
-    x_pos = positions / positions.max()
-    y_pos = x_pos.clone()
     if (FUSED_TRAINER_STEP if fused is None else fused) and hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):
-        total = _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window)
+        # the frequencies go in as they are: the division by the maximum and the second grid are part of the node's plan launch
+        total = _fused_mix_step(loss_fn, x, x_hat, positions, positions, n_fft, hop, window, unit_positions=True)
         if total is not None:
             return total
+    x_pos = positions / positions.max()
+    y_pos = x_pos.clone()
     spec_x = stft_magnitude(x, n_fft, hop, window)
     spec_x_hat = stft_magnitude(x_hat, n_fft, hop, window)
     if hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):   # isinstance(self.loss_fn, losses.MixOfLosses)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 11   /* bumped on every change of a signature or of a buffer contract below; the binding checks it
+#define SOT_ABI_VERSION 12   /* bumped on every change of a signature or of a buffer contract below; the binding checks it
                               * (11, round 6: sot_workspace_bytes covers the per-row pre-sort; the MSS workspace is 16-byte aligned) */
 
 typedef enum sot_status {
@@ -122,6 +122,14 @@ int sot_prepare_positions(const float *xpos, const float *ypos, int32_t n, int32
                           float *xpos_sorted /* [n] */, float *ypos_sorted /* [m] */,
                           int32_t *xperm /* [n] */, int32_t *yperm /* [m] */,
                           int32_t *perm_is_identity /* [2] */, void *stream);
+/* The same plan for xpos / max(xpos) and ypos / max(ypos) (round 6, ABI 12): the reference's trainer rebuilds its grid on every step --
+ * `x_pos = x_pos / x_pos.max(); y_pos = x_pos.clone()` (trainer.py:196-197) -- and this call takes the bin frequencies as they are, so
+ * that such a step pays one launch instead of a reduction, a division, a copy and the plan.  The sorted positions written are the
+ * floats torch computes: torch.max's NaN rule, IEEE division. */
+int sot_prepare_unit_positions(const float *xpos, const float *ypos, int32_t n, int32_t m,
+                               float *xpos_sorted /* [n] */, float *ypos_sorted /* [m] */,
+                               int32_t *xperm /* [n] */, int32_t *yperm /* [m] */,
+                               int32_t *perm_is_identity /* [2] */, void *stream);
 
 /*
  * Forward: row_loss[r] = W_p^p(x_r, y_r) for r in [0, B).

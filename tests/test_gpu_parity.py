@@ -1686,3 +1686,36 @@ def test_one_wave_rows_with_unsorted_positions_strides_and_the_in_kernel_mean():
         two = nat.loss_fused(xs, ys, pd_, pd2, 2.0, flags, plan)
         one = nat.loss_fused(xs, ys, pd_, pd2, 2.0, flags, plan, fused_mean=True)
         assert torch.equal(two[0] if isinstance(two, tuple) else two, one[0] if isinstance(one, tuple) else one)
+
+
+def test_unit_position_plan_equals_torch_division_and_sort():
+    """sot_prepare_unit_positions (ABI 12): the plan of xpos / xpos.max() and ypos / ypos.max() out of one launch -- the floats of torch's
+    max + true division (bit for bit), then the same sorted positions / permutations / identity flags as the plan of those quotients;
+    sorted and unsorted grids, n != m, the paper's bin frequencies, a NaN (torch.max's rule: everything NaN), through the C++ host path
+    and through ctypes."""
+    nat = native()
+    dev = device()
+    g = torch.Generator().manual_seed(5)
+    grids = [(torch.fft.rfftfreq(2048, d=1.0 / 16000.0), torch.fft.rfftfreq(2048, d=1.0 / 16000.0)),
+             (torch.rand(1025, generator=g) * 8000.0, torch.rand(513, generator=g) * 3.0 + 0.1),
+             (torch.linspace(0.5, 977.0, 300), torch.rand(300, generator=g) + 1e-3),
+             (torch.tensor([3.0, 1.0, 2.0]), torch.tensor([7.0]))]
+    import sot_amd._native as native_mod
+    for use_glue in (True, False):
+        saved = native_mod.glue
+        if not use_glue:
+            native_mod.glue = lambda: None
+        try:
+            for xf, yf in grids:
+                xf, yf = xf.float().to(dev), yf.float().to(dev)
+                unit = nat.PositionPlan(xf, yf, unit=True)
+                want = nat.PositionPlan(xf / xf.max(), yf / yf.max())
+                torch.cuda.synchronize()
+                assert torch.equal(unit.xpos_sorted, want.xpos_sorted) and torch.equal(unit.ypos_sorted, want.ypos_sorted)
+                assert torch.equal(unit.xperm, want.xperm) and torch.equal(unit.yperm, want.yperm) and torch.equal(unit.ident, want.ident)
+                assert torch.equal(unit.xpos_sorted, torch.sort(xf / xf.max(), stable=True).values)
+            bad = torch.tensor([1.0, float("nan"), 4.0, 2.0], device=dev)
+            plan = nat.PositionPlan(bad, bad.clone(), unit=True)
+            assert bool(torch.isnan(plan.xpos_sorted).all()) and bool(torch.isnan(plan.ypos_sorted).all())   # x / NaN
+        finally:
+            native_mod.glue = saved
