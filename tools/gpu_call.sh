@@ -26,7 +26,7 @@ case "$CASE" in
     O="gpurun_out/${1:-r5a}"; shift || true
     mkdir -p "$O"
     for clips in ${@:-64 256}; do
-      for what in full mss sot; do
+      for what in full modules mss sot; do
         echo "== $what, $clips clips (45 steps incl. 5 warm-up)" | tee -a "$O/summary.txt"
         kstats "$O/${what}_${clips}" tools/r5/paper_step_probe.py "$clips" 40 "$what" | tee -a "$O/summary.txt"
         tail -n 1 "$O/${what}_${clips}.log" | tee -a "$O/summary.txt"

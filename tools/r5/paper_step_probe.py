@@ -1,5 +1,6 @@
 """The paper's loss step (trainer.py:183-245 with the SOT-2048 YAML) back to back, for rocprofv3 --kernel-trace --stats:
-python3 tools/r5/paper_step_probe.py [clips=64] [steps=40] [what=full|mss|sot]"""
+python3 tools/r5/paper_step_probe.py [clips=64] [steps=40] [what=full|modules|mss|sot]   (full: the one-node step of round 6; modules: the same step composed
+module by module, fused=False)"""
 import os
 import sys
 
@@ -29,7 +30,7 @@ for i in range(steps + 5):
     elif what == "sot":
         loss = spectra.training_step_slice(sot, x, e)
     else:
-        loss = spectra.trainer_loss_step(mix, x, e, positions=freqs)
+        loss = spectra.trainer_loss_step(mix, x, e, positions=freqs, fused=(what != "modules"))
     loss.backward(seed)
 torch.cuda.synchronize()
 print(f"{what} {clips} clips: loss {float(loss):.9g}, |grad| {float(hats[0].grad.abs().sum()):.6g}")
