@@ -105,10 +105,10 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
             return f"sot_area_full_kernel<{g}, {cpt}, {rows}, {b(sq)}, -1>"
         if backward:   # y-only (training) kernel; the 1024-point geometry in the layout without U gradient slots, capped at 128 VGPRs
             tail = "false, true, 4" if cap == 1024 else "false, false, 1"
-            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1, {tail}>"
+            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1, {tail}, false>"
         if cap == 1024 and batch >= 8192:
             g, cpt, rows = 64, 16, 4
-        return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1>"
+        return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pmt}, {b(lim)}, {b(sq)}, -1, false>"
     if pm not in (1, 2):
         pm = 0
     g, cpt, rows, nx = geo
@@ -121,17 +121,17 @@ def forward_kernel_name(n, mode, backward=False, same_grid=True, batch=0):
     if backward:   # the y-only (training) kernels <..., WANT_X, SLIM, MINB>: 2048-bin rows run two per workgroup in the layout without
         # U gradient slots, 1025- and 513-bin rows in that layout compiled for four workgroups per CU
         if n == 2048:
-            return f"sot_backward_full_kernel<{g}, {cpt}, 2, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
+            return f"sot_backward_full_kernel<{g}, {cpt}, 2, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1, false>"
         if n in (1025, 513):
-            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 4>"
+            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 4, false>"
         if n in (1024, 2049):
-            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1>"
-        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false, 1>"
+            return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, true, 1, false>"
+        return f"sot_backward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false, false, 1, false>"
     if (n == 257 and batch >= 40960) or (n == 129 and batch >= 8192):   # two rows per wave
         return f"sot_forward_half_kernel<{9 if n == 257 else 5}, 8, {pm}, {b(lim)}, {b(sq)}, {n}>"
     if n == 1025 and batch >= 6144:
         g, cpt, rows = 64, 17, 4
-    return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}>"
+    return f"sot_forward_full_kernel<{g}, {cpt}, {rows}, {pm}, {b(lim)}, {b(sq)}, {nx}, false>"
 
 
 def global_batch_rows(first, count, n, block=8192):

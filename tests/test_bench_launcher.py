@@ -51,23 +51,23 @@ def test_world_size_must_match_gpus():
 def test_kernel_name_follows_shape_and_mode():
     b = _bench_module()
     assert b.forward_kernel_name(2048, "p1") == "sot_area_full_kernel<256, 8, 1, false, 0>"          # p = 1, one grid: merge-free
-    assert b.forward_kernel_name(2048, "p1", same_grid=False) == "sot_forward_full_kernel<256, 8, 1, 1, false, false, 0>"
-    assert b.forward_kernel_name(1025, "cutoff") == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
-    assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<128, 9, 2, 2, true, true, 1025, false, true, 4>"
-    assert b.forward_kernel_name(2048, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 2, 2, true, true, 0, false, true, 1>"
+    assert b.forward_kernel_name(2048, "p1", same_grid=False) == "sot_forward_full_kernel<256, 8, 1, 1, false, false, 0, false>"
+    assert b.forward_kernel_name(1025, "cutoff") == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025, false>"
+    assert b.forward_kernel_name(1025, "cutoff", backward=True) == "sot_backward_full_kernel<128, 9, 2, 2, true, true, 1025, false, true, 4, false>"
+    assert b.forward_kernel_name(2048, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 2, 2, true, true, 0, false, true, 1, false>"
     assert b.forward_kernel_name(3000, "p1") == "sot_area_full_kernel<384, 8, 1, false, -1>"            # run-time length on the 3072-point geometry
     assert b.forward_kernel_name(4000, "p1") == "sot_area_full_kernel<512, 8, 1, false, -1>"
-    assert b.forward_kernel_name(1200, "cutoff") == "sot_forward_full_kernel<192, 8, 1, 2, true, true, -1>"
-    assert b.forward_kernel_name(2000, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 1, 2, true, true, -1, false, false, 1>"
-    assert b.forward_kernel_name(1000, "cutoff", backward=True) == "sot_backward_full_kernel<128, 8, 2, 2, true, true, -1, false, true, 4>"
-    assert b.forward_kernel_name(1025, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 17, 4, 2, true, true, 1025>"     # large batches: one wave per row
-    assert b.forward_kernel_name(1025, "cutoff", batch=4096) == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025>"
+    assert b.forward_kernel_name(1200, "cutoff") == "sot_forward_full_kernel<192, 8, 1, 2, true, true, -1, false>"
+    assert b.forward_kernel_name(2000, "cutoff", backward=True) == "sot_backward_full_kernel<256, 8, 1, 2, true, true, -1, false, false, 1, false>"
+    assert b.forward_kernel_name(1000, "cutoff", backward=True) == "sot_backward_full_kernel<128, 8, 2, 2, true, true, -1, false, true, 4, false>"
+    assert b.forward_kernel_name(1025, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 17, 4, 2, true, true, 1025, false>"     # large batches: one wave per row
+    assert b.forward_kernel_name(1025, "cutoff", batch=4096) == "sot_forward_full_kernel<128, 9, 2, 2, true, true, 1025, false>"
     assert b.forward_kernel_name(1025, "p1") == "sot_area_full_kernel<64, 17, 4, false, 1025>"
     assert b.forward_kernel_name(129, "p1") == "sot_area_half_kernel<5, 8, false, 129>"
     assert b.forward_kernel_name(257, "cutoff", batch=65536) == "sot_forward_half_kernel<9, 8, 2, true, true, 257>"      # two rows per wave
-    assert b.forward_kernel_name(257, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 5, 4, 2, true, true, 257>"
+    assert b.forward_kernel_name(257, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 5, 4, 2, true, true, 257, false>"
     assert b.forward_kernel_name(1000, "p1") == "sot_area_full_kernel<64, 16, 4, false, -1>"
-    assert b.forward_kernel_name(1000, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 16, 4, 2, true, true, -1>"
+    assert b.forward_kernel_name(1000, "cutoff", batch=16384) == "sot_forward_full_kernel<64, 16, 4, 2, true, true, -1, false>"
     assert "generic" in b.forward_kernel_name(100, "p1") and "generic" in b.forward_kernel_name(9000, "p1")
 
 
