@@ -446,8 +446,8 @@ at::Tensor mss_loss(const at::Tensor& target, const at::Tensor& estimate, const 
 // two are independent until the accumulation -- measured no gain: 96.0 against 97.1 us replayed at 64 clips, and 50 us more host time eager.)
 class MixLossStep : public torch::autograd::Function<MixLossStep> {
 public:
-    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window,
-                              const at::Tensor& xpos, const at::Tensor& ypos, int64_t n_fft, int64_t hop, double p, int64_t flags,
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate,
+                              const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos, int64_t n_fft, int64_t hop, double p, int64_t flags,
                               const std::vector<at::Tensor>& mss_windows, const std::vector<int64_t>& mss_sizes, double mag_weight,
                               double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions, bool grad)
     {
@@ -514,7 +514,10 @@ public:
                                              gy.data_ptr<float>(), nullptr, grad_audio.data_ptr<float>(), 1, ws.data_ptr(), ws_bytes, st), 1.0);
             ctx->saved_data["grad_audio"] = grad_audio;
         }
-        return w_sot == 1.0 ? at::add(mss_loss, sot_mean) : at::add(mss_loss, sot_mean, w_sot);
+        // (total, w_mss * MSSLoss, SOT mean): the two terms are what the reference's trainer logs per loss (trainer.py:231-236); values only
+        at::Tensor total = w_sot == 1.0 ? at::add(mss_loss, sot_mean) : at::add(mss_loss, sot_mean, w_sot);
+        ctx->mark_non_differentiable({mss_loss, sot_mean});
+        return {total, mss_loss, sot_mean};
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs)
@@ -529,7 +532,7 @@ public:
     }
 };
 
-at::Tensor mix_loss_step(const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos,
+std::vector<at::Tensor> mix_loss_step(const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos,
                          int64_t n_fft, int64_t hop, double p, int64_t flags, const std::vector<at::Tensor>& mss_windows,
                          const std::vector<int64_t>& mss_sizes, double mag_weight, double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions)
 {
@@ -553,6 +556,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("xpos"), pybind11::arg("ypos"), pybind11::arg("unit") = false);
     m.def("audio_to_loss", &audio_to_loss, "STFT magnitudes of target and estimate -> mean SOT loss; differentiable w.r.t. the estimate's audio");
     m.def("stft_magnitude", &stft_magnitude, "[clips, samples] -> [clips, frames, n_fft / 2 + 1] magnitudes (features.TorchSTFT); differentiable w.r.t. the audio");
-    m.def("mix_loss_step", &mix_loss_step, "MixOfLosses([MSSLoss, Wasserstein1D]) of the paper's training step on an audio pair: one call, one node; differentiable w.r.t. the estimate's audio");
+    m.def("mix_loss_step", &mix_loss_step, "MixOfLosses([MSSLoss, Wasserstein1D]) of the paper's training step on an audio pair: one call, one node -> (total, w_mss * MSSLoss, SOT mean); the total is differentiable w.r.t. the estimate's audio");
     m.def("mss_loss", &mss_loss, "MSSLoss in two launches (sot_mss_loss_and_grad); differentiable w.r.t. the estimate's audio");
 }

@@ -451,7 +451,7 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
 FUSED_TRAINER_STEP = True    # module switch: trainer_loss_step may take the one-node form below (tests and the bench compare both)
 
 
-def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_positions=False):
+def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_positions=False, terms=None):
     """`MixOfLosses([MSSLoss, Wasserstein1D], weights)` of the paper's step (train_config.yaml:73-102) on a float32 GPU audio pair as ONE
     C++ call and ONE autograd node (csrc/sot_torch_glue.cpp: MixLossStep) -> the 0-d total, or None when the configuration is not that
     node's case (any other mix, a target that asks for a gradient, `hinge`, per-row positions, transform sizes outside the fused MSS
@@ -489,13 +489,17 @@ def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_po
     flags = L._flags(sot.square_dist, sot.dont_normalize, sot.limit_quantile_range, sot.require_sort)
     if getattr(sot, "tie_free_gradient", False):
         flags |= nat.FLAG_TIE_FREE_GRADIENT
-    return glue.mix_loss_step(x, x_hat, _cached_window(window, n_fft, x.device), x_pos, y_pos, int(n_fft), int(hop), float(sot.p), int(flags),
-                              _cached_windows(None, sizes, x.device), list(sizes), float(mss.mag_weight), float(mss.logmag_weight), kind == "L2",
-                              w_mss, w_sot, bool(unit_positions))
+    total, mss_term, sot_mean = glue.mix_loss_step(x, x_hat, _cached_window(window, n_fft, x.device), x_pos, y_pos, int(n_fft), int(hop), float(sot.p),
+                                                   int(flags), _cached_windows(None, sizes, x.device), list(sizes), float(mss.mag_weight),
+                                                   float(mss.logmag_weight), kind == "L2", w_mss, w_sot, bool(unit_positions))
+    if terms is not None:   # what the trainer logs per loss (trainer.py:231-236): `(loss_fn(...) * weight).mean()`, values only
+        for fn in fns:      # in the order of the mix, like the reference's dict
+            terms[fn.__class__.__name__] = mss_term if fn is mss else (sot_mean if w_sot == 1.0 else sot_mean * w_sot)
+    return total
 
 
 def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop",
-                      sample_rate: float = 16000.0, positions=None, fused=None) -> torch.Tensor:
+                      sample_rate: float = 16000.0, positions=None, fused=None, terms=None) -> torch.Tensor:
     """The loss block of the reference's `trainer.shared_step` (trainer.py:183-245) for a `MixOfLosses` (or a single loss module):
     unit-scaled bin frequencies built AFRESH (`x_pos = torch.tensor(transform.get_frequencies()).to(device); x_pos = x_pos / x_pos.max();
     y_pos = x_pos.clone()`, :192-197), both signals through the transform (`TorchSTFT`, :199-200), `MSSLoss` fed the audio and every
@@ -504,12 +508,14 @@ def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int 
     host memory); the division and the clone still run per step (in the one-node form: inside the plan's launch).  The caller backpropagates into `x_hat`.
     `fused` (None = the module switch FUSED_TRAINER_STEP): the paper's own mix -- `MixOfLosses([MSSLoss, Wasserstein1D])` on float32 GPU
     audio -- runs as one host call and one autograd node (_fused_mix_step: the same kernels, none of the per-module arithmetic between
-    them); every other configuration, and `fused=False`, composes the modules one by one exactly as the reference's trainer does."""
+    them); every other configuration, and `fused=False`, composes the modules one by one exactly as the reference's trainer does.
+    `terms`: a dict that receives the value of every loss of a mix by class name -- what the trainer logs as `loss/<step>/<name>`
+    (trainer.py:231-236) -- detached; costs nothing in the one-node form (the node has both scalars anyway)."""
     if positions is None:
         positions = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device)   # torch.tensor(get_frequencies()).to(device)
     if (FUSED_TRAINER_STEP if fused is None else fused) and hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):
         # the frequencies go in as they are: the division by the maximum and the second grid are part of the node's plan launch
-        total = _fused_mix_step(loss_fn, x, x_hat, positions, positions, n_fft, hop, window, unit_positions=True)
+        total = _fused_mix_step(loss_fn, x, x_hat, positions, positions, n_fft, hop, window, unit_positions=True, terms=terms)
         if total is not None:
             return total
     x_pos = positions / positions.max()
@@ -523,8 +529,11 @@ def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int 
             a, b = (x, x_hat) if name == "MSSLoss" else (spec_x, spec_x_hat)
             distance[name] = fn(a, b, x_pos=x_pos, y_pos=y_pos) * weight
         loss = 0
-        for value in distance.values():
-            loss = loss + value.mean()
+        for key, value in distance.items():
+            term = value.mean()
+            if terms is not None:
+                terms[key] = term.detach()
+            loss = loss + term
         return loss
     a, b = (x, x_hat) if loss_fn.__class__.__name__ == "MSSLoss" else (spec_x, spec_x_hat)
     return loss_fn(a, b, x_pos=x_pos, y_pos=y_pos).mean()

@@ -273,9 +273,14 @@ def test_paper_loss_block_on_cpu_matches_reference():
     ax = torch.as_tensor(fx["step_audio_x"])
     ay = torch.as_tensor(fx["step_audio_y"]).requires_grad_(True)
     mix = _paper_mix()
-    loss = spectra.trainer_loss_step(mix, ax, ay)
+    logged = {}
+    loss = spectra.trainer_loss_step(mix, ax, ay, terms=logged)
     loss.backward()
     assert abs(float(loss) - float(fx["step_loss"])) <= 1e-6 * abs(float(fx["step_loss"]))
+    # the per-loss values the trainer logs (trainer.py:231-236)
+    assert list(logged) == ["MSSLoss", "Wasserstein1D"] and not any(v.requires_grad for v in logged.values())
+    assert abs(float(logged["MSSLoss"]) - float(fx["step_mss_term"])) <= 1e-6 * float(fx["step_mss_term"])
+    assert abs(float(logged["Wasserstein1D"]) - float(fx["step_sot_term"])) <= 1e-6 * float(fx["step_sot_term"])
     g, gw = ay.grad.numpy(), fx["step_grad_y"]
     assert np.abs(g - gw).max() <= 1e-4 * np.abs(gw).max()
 
@@ -811,7 +816,7 @@ def test_one_node_loss_step_equals_the_module_by_module_step(kind, weights, mss_
     autograd node (csrc/sot_torch_glue.cpp: MixLossStep; same kernels, none of the trainer's arithmetic between them).  Against the
     module-by-module composition (fused=False, what the fixture tests above pin to the reference): the total to 2e-7 relative (the mix
     weight rides on the MSS kernel's distance weights instead of multiplying its result: one rounding), the audio gradient to 1e-6 of its
-    peak; in either order of the two losses; with an upstream factor; without a gradient; and the configurations the node does not take
+    peak; in either order of the two losses; with an upstream factor; without a gradient; the per-loss values the trainer logs (`terms=`); and the configurations the node does not take
     (a third loss, a target that asks for a gradient) fall back to the composition."""
     from gpu_util import device, native
     from sot_amd import spectra
@@ -825,10 +830,11 @@ def test_one_node_loss_step_equals_the_module_by_module_step(kind, weights, mss_
     sot = Wasserstein1D(require_sort=True, **sot_kw)
     for fns, ws in (([mss, sot], weights), ([sot, mss], weights[::-1])):
         mix = MixOfLosses(fns, ws).to(dev)
-        results = {}
+        results, logged = {}, {}
         for fused in (False, True):
             est = e.clone().requires_grad_(True)
-            loss = spectra.trainer_loss_step(mix, x, est, fused=fused)
+            logged[fused] = {}
+            loss = spectra.trainer_loss_step(mix, x, est, fused=fused, terms=logged[fused])
             (loss * 3.0).backward()
             results[fused] = (loss.detach(), est.grad)
             if fused:
@@ -836,6 +842,12 @@ def test_one_node_loss_step_equals_the_module_by_module_step(kind, weights, mss_
         (l0, g0), (l1, g1) = results[False], results[True]
         assert abs(float(l1) - float(l0)) <= 2e-7 * abs(float(l0)), (float(l0), float(l1))
         assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
+        # the per-loss values the trainer logs (trainer.py:231-236): same keys in the mix's order, same values, no graph attached; they add up to the total
+        assert list(logged[True]) == list(logged[False]) == [f.__class__.__name__ for f in fns]
+        for key in logged[True]:
+            a, b = logged[True][key], logged[False][key]
+            assert not a.requires_grad and not b.requires_grad and abs(float(a) - float(b)) <= 2e-7 * abs(float(b)), (key, float(a), float(b))
+        assert abs(sum(float(v) for v in logged[True].values()) - float(l1)) <= 2e-7 * abs(float(l1))
         with torch.no_grad():
             assert abs(float(spectra.trainer_loss_step(mix, x, e, fused=True)) - float(l0)) <= 2e-7 * abs(float(l0))
     # not the node's case: composed module by module, same values as fused=False
