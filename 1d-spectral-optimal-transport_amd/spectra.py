@@ -448,6 +448,20 @@ def training_step_slice(loss_module, audio_target: torch.Tensor, audio_estimate:
     return loss_module(spec_x, spec_y, x_pos=pos[0], y_pos=pos[1])
 
 
+def hz_to_unit(hz, hz_min=20.0, hz_max=8000.0, clip: bool = False) -> torch.Tensor:
+    """The reference's `utils.hz_to_unit` (utils.py:85-114): frequencies -> MIDI notes (`12 (log(f) / log 2 - log(440) / log 2) + 69` in float32, 0 Hz and
+    below -> note 0) -> `(note - note(hz_min)) / (note(hz_max) - note(hz_min))`, optionally clamped to [0, 1].  The position map of the trainer for a loss
+    with `log_scaled_x` (trainer.py:187-191).  Plain torch ops: a few hundred bins once per step."""
+    def notes(f):
+        f = f.type(torch.float32) if isinstance(f, torch.Tensor) else torch.tensor(f, dtype=torch.float32)
+        two, a4 = torch.tensor(2.0, dtype=torch.float32), torch.tensor(440.0, dtype=torch.float32)
+        n = 12.0 * (torch.log(f) / torch.log(two) - torch.log(a4) / torch.log(two)) + 69.0
+        return torch.where(f <= 0.0, torch.tensor(0.0, dtype=torch.float32, device=f.device), n)
+    lo, hi = notes(hz_min), notes(hz_max)
+    unit = (notes(hz) - lo) / (hi - lo)
+    return torch.clamp(unit, 0.0, 1.0) if clip else unit
+
+
 FUSED_TRAINER_STEP = True    # module switch: trainer_loss_step may take the one-node form below (tests and the bench compare both)
 
 
@@ -499,7 +513,7 @@ def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_po
 
 
 def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int = 2048, hop: int = 256, window="flattop",
-                      sample_rate: float = 16000.0, positions=None, fused=None, terms=None) -> torch.Tensor:
+                      sample_rate: float = 16000.0, positions=None, fused=None, terms=None, freq_hz_min="auto", freq_hz_max="auto") -> torch.Tensor:
     """The loss block of the reference's `trainer.shared_step` (trainer.py:183-245) for a `MixOfLosses` (or a single loss module):
     unit-scaled bin frequencies built AFRESH (`x_pos = torch.tensor(transform.get_frequencies()).to(device); x_pos = x_pos / x_pos.max();
     y_pos = x_pos.clone()`, :192-197), both signals through the transform (`TorchSTFT`, :199-200), `MSSLoss` fed the audio and every
@@ -510,9 +524,19 @@ def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int 
     audio -- runs as one host call and one autograd node (_fused_mix_step: the same kernels, none of the per-module arithmetic between
     them); every other configuration, and `fused=False`, composes the modules one by one exactly as the reference's trainer does.
     `terms`: a dict that receives the value of every loss of a mix by class name -- what the trainer logs as `loss/<step>/<name>`
-    (trainer.py:231-236) -- detached; costs nothing in the one-node form (the node has both scalars anyway)."""
+    (trainer.py:231-236) -- detached; costs nothing in the one-node form (the node has both scalars anyway).
+    A single loss that carries `log_scaled_x` gets `hz_to_unit` positions between `freq_hz_min` / `freq_hz_max` (trainer.py:187-191)."""
     if positions is None:
         positions = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device)   # torch.tensor(get_frequencies()).to(device)
+    if getattr(loss_fn, "log_scaled_x", False):
+        # trainer.py:187-191 (the loss object itself carries the flag -- a MixOfLosses does not, whatever its members say): log-frequency positions
+        # between freq_hz_min / freq_hz_max ("auto": the transform's first / last bin frequency, trainer.py:65-70)
+        lo = float(positions[0]) if freq_hz_min == "auto" else freq_hz_min
+        hi = float(positions[-1]) if freq_hz_max == "auto" else freq_hz_max
+        x_pos = hz_to_unit(positions, lo, hi)
+        y_pos = x_pos.clone()
+        a, b = (x, x_hat) if loss_fn.__class__.__name__ == "MSSLoss" else (stft_magnitude(x, n_fft, hop, window), stft_magnitude(x_hat, n_fft, hop, window))
+        return loss_fn(a, b, x_pos=x_pos, y_pos=y_pos).mean()
     if (FUSED_TRAINER_STEP if fused is None else fused) and hasattr(loss_fn, "losses") and hasattr(loss_fn, "weights"):
         # the frequencies go in as they are: the division by the maximum and the second grid are part of the node's plan launch
         total = _fused_mix_step(loss_fn, x, x_hat, positions, positions, n_fft, hop, window, unit_positions=True, terms=terms)

@@ -902,3 +902,23 @@ def test_one_node_loss_step_in_a_hip_graph():
     want.backward()
     assert got_loss == float(want)
     assert torch.equal(got_grad, ref.grad)
+
+
+
+def test_hz_to_unit_matches_reference():
+    """spectra.hz_to_unit = the reference's utils.hz_to_unit (utils.py:85-114; oracle/make_golden_units.py): STFT bin frequencies (0 Hz -> note 0) and a
+    geometric grid, three (hz_min, hz_max, clip) settings each, bit for bit; and the trainer's branch that uses it (trainer.py:187-191)."""
+    from sot_amd import spectra
+    from sot_amd.losses import Wasserstein1D
+    fx = np.load(os.path.join(GOLDEN, "hz_to_unit.npz"))
+    for tag in ("stft2048", "stft512", "geometric"):
+        for k in range(3):
+            got = spectra.hz_to_unit(torch.as_tensor(fx[f"{tag}_{k}_hz"]), float(fx[f"{tag}_{k}_lo"]), float(fx[f"{tag}_{k}_hi"]), clip=bool(fx[f"{tag}_{k}_clip"]))
+            assert np.array_equal(got.numpy(), fx[f"{tag}_{k}_unit"]), (tag, k)
+    g = torch.Generator().manual_seed(3)
+    ax, ay = torch.randn(2, 2048, generator=g), torch.randn(2, 2048, generator=g)
+    mod = Wasserstein1D(p=2, log_scaled_x=True)
+    got = spectra.trainer_loss_step(mod, ax, ay, n_fft=512, hop=128, freq_hz_min=32.7, freq_hz_max=8000.0)
+    pos = spectra.hz_to_unit(torch.fft.rfftfreq(512, d=1.0 / 16000.0), 32.7, 8000.0)
+    want = mod(spectra.stft_magnitude(ax, 512, 128), spectra.stft_magnitude(ay, 512, 128), x_pos=pos, y_pos=pos.clone()).mean()
+    assert float(got) == float(want)
