@@ -518,8 +518,8 @@ def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int 
     unit-scaled bin frequencies built AFRESH (`x_pos = torch.tensor(transform.get_frequencies()).to(device); x_pos = x_pos / x_pos.max();
     y_pos = x_pos.clone()`, :192-197), both signals through the transform (`TorchSTFT`, :199-200), `MSSLoss` fed the audio and every
     other loss the spectra, each `loss_fn(a, b, x_pos=, y_pos=) * weight` (:206-221), the total = sum of `value.mean()` (:231-236).
-    `positions`: a device tensor of bin frequencies to start from instead of the host tensor (a captured step cannot copy from pageable
-    host memory); the division and the clone still run per step (in the one-node form: inside the plan's launch).  The caller backpropagates into `x_hat`.
+    `positions`: a device tensor of bin frequencies to start from; by default the transform's (`rfftfreq`), copied to the device on the first call
+    and kept (they are constants of the transform); the division and the clone still run per step (in the one-node form: inside the plan's launch).  The caller backpropagates into `x_hat`.
     `fused` (None = the module switch FUSED_TRAINER_STEP): the paper's own mix -- `MixOfLosses([MSSLoss, Wasserstein1D])` on float32 GPU
     audio -- runs as one host call and one autograd node (_fused_mix_step: the same kernels, none of the per-module arithmetic between
     them); every other configuration, and `fused=False`, composes the modules one by one exactly as the reference's trainer does.
@@ -527,7 +527,10 @@ def trainer_loss_step(loss_fn, x: torch.Tensor, x_hat: torch.Tensor, n_fft: int 
     (trainer.py:231-236) -- detached; costs nothing in the one-node form (the node has both scalars anyway).
     A single loss that carries `log_scaled_x` gets `hz_to_unit` positions between `freq_hz_min` / `freq_hz_max` (trainer.py:187-191)."""
     if positions is None:
-        positions = torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device)   # torch.tensor(get_frequencies()).to(device)
+        # torch.tensor(self.transform.get_frequencies()).to(x.device) (trainer.py:192): the values depend on the transform alone, so the copy from the
+        # host (pageable memory: a synchronising ~40 us per step, and impossible inside a stream capture) is made once per (n_fft, rate, device) and kept
+        positions = _WINDOWS.get(("bin frequencies", int(n_fft), float(sample_rate), str(x.device)), x.device,
+                                 lambda: torch.fft.rfftfreq(n_fft, d=1.0 / sample_rate).clone().to(x.device), host_side=True)
     if getattr(loss_fn, "log_scaled_x", False):
         # trainer.py:187-191 (the loss object itself carries the flag -- a MixOfLosses does not, whatever its members say): log-frequency positions
         # between freq_hz_min / freq_hz_max ("auto": the transform's first / last bin frequency, trainer.py:65-70)

@@ -696,8 +696,8 @@ def paper_loss_workloads(dev, nat, timed, n):
             return {"ms": ms, "what": what, "algorithmic_bytes": io_bytes, "frac": io_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "clips": clips, **kw}
 
         tag = f"{clips}clips"
-        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 (x_pos from the host every step) as spectra.trainer_loss_step runs it: the mix of MSSLoss and Wasserstein1D as ONE host call / autograd node (round 6), eager, launched from Python")
-        out[f"paper_loss_step_{tag}_device_positions"] = entry(timed(lambda i: full_step(i, False), n), "the same with the bin frequencies already on the device (division + clone per step)")
+        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 as spectra.trainer_loss_step runs it by default (positions=None: the transform's bin frequencies, kept on the device after the first call): the mix of MSSLoss and Wasserstein1D as ONE host call / autograd node (round 6), eager, launched from Python")
+        out[f"paper_loss_step_{tag}_device_positions"] = entry(timed(lambda i: full_step(i, False), n), "the same with the caller's own device tensor of bin frequencies (positions=...)")
         out[f"paper_loss_step_{tag}_module_by_module"] = entry(timed(lambda i: full_step(i, False, False), n), "the same step composed module by module as the reference's trainer does (fused=False: rounds 4-5's form), device positions, eager")
         out[f"mssloss_forward_backward_{tag}"] = entry(timed(mss_step, n), "MSSLoss(6 scales, L1, mag_weight 1) forward + backward into the estimate, eager")
         out[f"sot_slice_forward_backward_{tag}"] = entry(timed(sot_step, n), "STFT pair + Wasserstein1D (paper mode) forward + backward, eager (= config 5's slice)")

@@ -874,9 +874,9 @@ def test_one_node_loss_step_in_a_hip_graph():
     est = spectra.harmonic_batch(8, generator=gen, device=dev).requires_grad_(True)
     freqs = torch.fft.rfftfreq(2048, d=1.0 / 16000.0).to(dev)
 
-    def step():
+    def step():   # positions=None: the transform's bin frequencies, on the device since the warm-up steps (a capture could not copy them from the host)
         est.grad = None
-        loss = spectra.trainer_loss_step(mix, x, est, positions=freqs)
+        loss = spectra.trainer_loss_step(mix, x, est)
         loss.backward()
         return loss
 
