@@ -696,13 +696,20 @@ def paper_loss_workloads(dev, nat, timed, n):
             return {"ms": ms, "what": what, "algorithmic_bytes": io_bytes, "frac": io_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "clips": clips, **kw}
 
         tag = f"{clips}clips"
-        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 as spectra.trainer_loss_step runs it by default (positions=None: the transform's bin frequencies, kept on the device after the first call): the mix of MSSLoss and Wasserstein1D as ONE host call / autograd node (round 6), eager, launched from Python")
+        out[f"paper_loss_step_{tag}"] = entry(timed(full_step, n), "trainer.py:183-245 as spectra.trainer_loss_step runs it by default (positions=None: the transform's bin frequencies, kept on the device after the first call): the mix of MSSLoss and Wasserstein1D as ONE host call / autograd node (round 6; loss and gradient bit-identical to the module-by-module composition), eager, launched from Python")
         out[f"paper_loss_step_{tag}_device_positions"] = entry(timed(lambda i: full_step(i, False), n), "the same with the caller's own device tensor of bin frequencies (positions=...)")
         out[f"paper_loss_step_{tag}_module_by_module"] = entry(timed(lambda i: full_step(i, False, False), n), "the same step composed module by module as the reference's trainer does (fused=False: rounds 4-5's form), device positions, eager")
         out[f"mssloss_forward_backward_{tag}"] = entry(timed(mss_step, n), "MSSLoss(6 scales, L1, mag_weight 1) forward + backward into the estimate, eager")
         out[f"sot_slice_forward_backward_{tag}"] = entry(timed(sot_step, n), "STFT pair + Wasserstein1D (paper mode) forward + backward, eager (= config 5's slice)")
+        def folded_step(i):   # the one-node form with the mix weights inside the kernels (one rounding away from the composition instead of bit-identical)
+            spectra.FUSED_STEP_EXACT = False
+            try:
+                full_step(i, False)
+            finally:
+                spectra.FUSED_STEP_EXACT = True
+
         for key, fn in ((f"paper_loss_step_{tag}", lambda i: full_step(i, False)), (f"paper_loss_step_{tag}_module_by_module", lambda i: full_step(i, False, False)),
-                        (f"mssloss_forward_backward_{tag}", mss_step),
+                        (f"paper_loss_step_{tag}_folded_weights", folded_step), (f"mssloss_forward_backward_{tag}", mss_step),
                         (f"sot_slice_forward_backward_{tag}", sot_step)):
             try:
                 out[key + "_graph_replay"] = entry(replayed(fn), "the same kernels replayed from ONE HIP graph (GPU time of the block)")

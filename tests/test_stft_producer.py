@@ -814,10 +814,12 @@ def test_one_wave_per_frame_kernels_of_large_batches(hop, clips, samples):
 def test_one_node_loss_step_equals_the_module_by_module_step(kind, weights, mss_kw, sot_kw):
     """Round 6: spectra.trainer_loss_step runs the paper's mix -- MSSLoss on the audio, Wasserstein1D on the spectra -- as ONE host call and ONE
     autograd node (csrc/sot_torch_glue.cpp: MixLossStep; same kernels, none of the trainer's arithmetic between them).  Against the
-    module-by-module composition (fused=False, what the fixture tests above pin to the reference): the total to 2e-7 relative (the mix
-    weight rides on the MSS kernel's distance weights instead of multiplying its result: one rounding), the audio gradient to 1e-6 of its
-    peak; in either order of the two losses; with an upstream factor; without a gradient; the per-loss values the trainer logs (`terms=`); and the configurations the node does not take
-    (a third loss, a target that asks for a gradient) fall back to the composition."""
+    module-by-module composition (fused=False, what the fixture tests above pin to the reference): for the plain `loss.backward()` the total,
+    the per-loss values the trainer logs (`terms=`) and the audio gradient are EQUAL BIT FOR BIT (FUSED_STEP_EXACT, the default: the mix weights
+    are applied by the same float32 multiplications); with an upstream factor other than 1 the gradient agrees to 1e-6 of its peak (the node
+    multiplies its stored gradient, the composition scales before the STFT backward); with the weights inside the kernels
+    (FUSED_STEP_EXACT = False) total and gradient agree to 2e-7 / 1e-6; in either order of the two losses; without a gradient; and the
+    configurations the node does not take (a third loss, a target that asks for a gradient) fall back to the composition."""
     from gpu_util import device, native
     from sot_amd import spectra
     from sot_amd.losses import MixOfLosses, MSSLoss, Wasserstein1D
@@ -828,28 +830,40 @@ def test_one_node_loss_step_equals_the_module_by_module_step(kind, weights, mss_
     e = spectra.harmonic_batch(6, generator=gen, device=dev)
     mss = MSSLoss(fft_sizes=(2048, 1024, 512, 256, 128, 64), loss_type=kind, **mss_kw)
     sot = Wasserstein1D(require_sort=True, **sot_kw)
+
+    def run(mix, fused, upstream):
+        est = e.clone().requires_grad_(True)
+        logged = {}
+        loss = spectra.trainer_loss_step(mix, x, est, fused=fused, terms=logged)
+        if fused:
+            assert "MixLossStep" in loss.grad_fn.name(), loss.grad_fn.name()
+        (loss if upstream is None else loss * upstream).backward()
+        return loss.detach(), est.grad, logged
+
     for fns, ws in (([mss, sot], weights), ([sot, mss], weights[::-1])):
         mix = MixOfLosses(fns, ws).to(dev)
-        results, logged = {}, {}
-        for fused in (False, True):
-            est = e.clone().requires_grad_(True)
-            logged[fused] = {}
-            loss = spectra.trainer_loss_step(mix, x, est, fused=fused, terms=logged[fused])
-            (loss * 3.0).backward()
-            results[fused] = (loss.detach(), est.grad)
-            if fused:
-                assert "MixLossStep" in loss.grad_fn.name(), loss.grad_fn.name()
-        (l0, g0), (l1, g1) = results[False], results[True]
-        assert abs(float(l1) - float(l0)) <= 2e-7 * abs(float(l0)), (float(l0), float(l1))
-        assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
+        l0, g0, t0 = run(mix, False, None)
+        l1, g1, t1 = run(mix, True, None)
+        assert torch.equal(l1, l0), (float(l0), float(l1))
+        assert torch.equal(g1, g0), float((g1 - g0).abs().max())
         # the per-loss values the trainer logs (trainer.py:231-236): same keys in the mix's order, same values, no graph attached; they add up to the total
-        assert list(logged[True]) == list(logged[False]) == [f.__class__.__name__ for f in fns]
-        for key in logged[True]:
-            a, b = logged[True][key], logged[False][key]
-            assert not a.requires_grad and not b.requires_grad and abs(float(a) - float(b)) <= 2e-7 * abs(float(b)), (key, float(a), float(b))
-        assert abs(sum(float(v) for v in logged[True].values()) - float(l1)) <= 2e-7 * abs(float(l1))
+        assert list(t1) == list(t0) == [f.__class__.__name__ for f in fns]
+        for key in t1:
+            assert not t1[key].requires_grad and not t0[key].requires_grad and torch.equal(t1[key], t0[key]), (key, float(t1[key]), float(t0[key]))
+        assert abs(sum(float(v) for v in t1.values()) - float(l1)) <= 2e-7 * abs(float(l1))
+        _, g0u, _ = run(mix, False, 3.0)
+        _, g1u, _ = run(mix, True, 3.0)
+        assert float((g1u - g0u).abs().max()) <= 1e-6 * float(g0u.abs().max())
         with torch.no_grad():
-            assert abs(float(spectra.trainer_loss_step(mix, x, e, fused=True)) - float(l0)) <= 2e-7 * abs(float(l0))
+            assert torch.equal(spectra.trainer_loss_step(mix, x, e, fused=True), l0)
+        spectra.FUSED_STEP_EXACT = False      # the weights inside the kernels: one rounding away
+        try:
+            l2, g2, t2 = run(mix, True, None)
+        finally:
+            spectra.FUSED_STEP_EXACT = True
+        assert abs(float(l2) - float(l0)) <= 2e-7 * abs(float(l0)), (float(l0), float(l2))
+        assert float((g2 - g0).abs().max()) <= 1e-6 * float(g0.abs().max())
+        assert all(abs(float(t2[k]) - float(t0[k])) <= 2e-7 * abs(float(t0[k])) for k in t0)
     # not the node's case: composed module by module, same values as fused=False
     est = e.clone().requires_grad_(True)
     assert "MixLossStep" not in spectra.trainer_loss_step(MixOfLosses([mss, sot, sot], [0.05, 1, 1]).to(dev), x, est).grad_fn.name()
