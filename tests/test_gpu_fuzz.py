@@ -69,3 +69,19 @@ def test_random_mss_cases_against_float64(seed):
     cases, bad, failures = fuzz_mss.run(budget=170.0, seed0=seed, verbose=False, max_cases=150)
     assert cases == 150
     assert bad == 0, failures[:3]
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_random_per_row_position_cases_on_every_route(seed):
+    """tools/r6/fuzz_rowpos.py (round 6): per-row positions -- 2048-point rows (the compile-time RP kernels) most of the time, every other length on the
+    generic gathering kernels -- with random, sorted, descending, clustered, tied, one-interval and duplicated positions mixed row by row, random weights,
+    modes, p, strides: the default route (pre-sort kernel), SOT_FLAG_NO_SPECIALIZE (the row kernel's own merge sort) and the hand-over of stored
+    permutations agree BIT FOR BIT on forward rows, both weight gradients and the position gradients; the stored permutations are the stable argsort;
+    forward rows within 2e-5 of the C oracle, weight gradients within 2e-4 (p = 1, 2; 1e-3 general p) of the row's gradient scale."""
+    native()
+    sys.path.insert(0, os.path.join(ROOT, "tools", "r6"))
+    import fuzz_rowpos
+    cases, failures, worst_forward, worst_grad = fuzz_rowpos.run(budget=150.0, seed0=seed, max_cases=250, verbose=False)
+    assert cases == 250
+    assert failures == [], failures[:3]
+    assert worst_forward <= 2e-5
