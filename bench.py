@@ -840,11 +840,13 @@ def flatten_for_scalar_readers(rec, B, N):
         "paper_step_64clips_eager_ms": ms_of("paper_loss_step_64clips"),
         "paper_step_256clips_graph_ms": ms_of("paper_loss_step_256clips_graph_replay"),
         "paper_step_64clips_module_by_module_graph_ms": ms_of("paper_loss_step_64clips_module_by_module_graph_replay"),
+        "paper_step_64clips_folded_weights_graph_ms": ms_of("paper_loss_step_64clips_folded_weights_graph_replay"),
         "mss_64clips_graph_ms": ms_of("mssloss_forward_backward_64clips_graph_replay"),
         "mss_256clips_graph_ms": ms_of("mssloss_forward_backward_256clips_graph_replay"),
         "sot_slice_64clips_graph_ms": ms_of("sot_slice_forward_backward_64clips_graph_replay"),
         "per_row_forward_ms": ms_of(f"b{rows_pr}n{N}_per_row_positions_forward"),
         "per_row_backward_ms": ms_of(f"b{rows_pr}n{N}_per_row_backward"),
+        "per_row_sorted_rows_forward_ms": ms_of(f"b{rows_pr}n{N}_per_row_sorted_positions_forward"),
         "per_row_position_grad_ms": ms_of(f"b{rows_pr}n{N}_per_row_position_gradients"),
         "segmented_sort_ms": ms_of(f"b{rows_pr}n{N}_segmented_sort"),
         "module_step_1024x1025_user_graph_ms": ms_of("b1024n1025_cutoff_step_user_graph"),

@@ -281,6 +281,11 @@ def test_paper_loss_block_on_cpu_matches_reference():
     assert list(logged) == ["MSSLoss", "Wasserstein1D"] and not any(v.requires_grad for v in logged.values())
     assert abs(float(logged["MSSLoss"]) - float(fx["step_mss_term"])) <= 1e-6 * float(fx["step_mss_term"])
     assert abs(float(logged["Wasserstein1D"]) - float(fx["step_sot_term"])) <= 1e-6 * float(fx["step_sot_term"])
+    # CPU tensors are not the one-node form's case: asking for it composes the modules all the same
+    ay2 = torch.as_tensor(fx["step_audio_y"]).requires_grad_(True)
+    again = spectra.trainer_loss_step(mix, ax, ay2, fused=True)
+    again.backward()
+    assert torch.equal(again.detach(), loss.detach()) and torch.equal(ay2.grad, ay.grad)
     g, gw = ay.grad.numpy(), fx["step_grad_y"]
     assert np.abs(g - gw).max() <= 1e-4 * np.abs(gw).max()
 
