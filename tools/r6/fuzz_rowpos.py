@@ -79,8 +79,15 @@ def run(budget=120.0, seed0=0, max_cases=None, grad_tol=2e-4, verbose=True):
             xd, yd = bx.to(dev)[:, 1:n + 1], by.to(dev)[:, 2:m + 2]
         else:
             xd, yd = x.to(dev), y.to(dev)
-        xpd, ypd = xpos.to(dev), ypos.to(dev)
-        desc = dict(seed=seed, B=B, n=n, m=m, kind=kind if not mix else "mixed", w=wk, p=p, flags=flags)
+        pos_strided = rng.random() < 0.25
+        if pos_strided:    # position rows that are views into wider buffers (odd offsets: the pre-sort's scalar-load variant, unaligned staging in the row kernels)
+            ox, oy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            px, py = torch.zeros(B, n + 7), torch.zeros(B, m + 9)
+            px[:, ox:ox + n], py[:, oy:oy + m] = xpos, ypos
+            xpd, ypd = px.to(dev)[:, ox:ox + n], py.to(dev)[:, oy:oy + m]
+        else:
+            xpd, ypd = xpos.to(dev), ypos.to(dev)
+        desc = dict(seed=seed, B=B, n=n, m=m, kind=kind if not mix else "mixed", w=wk, p=p, flags=flags, pos_strided=bool(pos_strided))
         cases += 1
 
         def fail(what, **kw):
