@@ -31,7 +31,7 @@ SOT_ERR_UNSUPPORTED_SIZE = -3
 SOT_ERR_NULL_POINTER = -4
 SOT_ERR_WORKSPACE = -5
 SOT_ERR_LAUNCH = -6
-ABI_VERSION = 12                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
+ABI_VERSION = 13                  # include/sot_hip.h: SOT_ABI_VERSION (bumped with every signature change)
 COMPLETION_COUNTER_WORDS = 16    # include/sot_hip.h: SOT_COMPLETION_COUNTER_WORDS
 
 _vp = ctypes.c_void_p
@@ -94,7 +94,7 @@ EXPORTS = {
     "sot_synth_tap_tables": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, _vp]),
     "sot_mss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int]),
     "sot_mss_loss_and_grad": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, _vp, ctypes.c_int,
-                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp,
                                              ctypes.c_size_t, _vp]),
     "sot_spec_distance_workspace_bytes": (ctypes.c_size_t, []),
     "sot_spec_distance_forward": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
@@ -784,9 +784,10 @@ MSS_FUSED_SIZES = (64, 128, 256, 512, 1024, 2048)   # n_fft the two-launch form 
 
 
 def mss_loss_and_grad(target: torch.Tensor, value: torch.Tensor, fft_sizes, windows, mag_weight: float, logmag_weight: float, eps: float = 1e-5,
-                      l2: bool = False, per_clip: bool = False, want_grad: bool = True):
+                      l2: bool = False, per_clip: bool = False, want_grad: bool = True, post_scale: float = 1.0):
     """MSSLoss (losses.py:365-425) of [batch, samples] float32 audio and d loss / d value in two launches (sot_mss_loss_and_grad):
-    -> (loss: 0-d, or [batch] with per_clip; grad: [batch, samples] or None).  windows: one n_fft-tap device tensor per scale."""
+    -> (loss: 0-d, or [batch] with per_clip; grad: [batch, samples] or None).  windows: one n_fft-tap device tensor per scale.
+    post_scale: one more float32 product on the finished loss and gradient (a mix weight, losses.py:360)."""
     require_hip(target, value)
     lib = load()
     if target.ndim != 2 or target.shape != value.shape:
@@ -812,7 +813,7 @@ def mss_loss_and_grad(target: torch.Tensor, value: torch.Tensor, fft_sizes, wind
     with _on_device(value.device):
         check(lib.sot_mss_loss_and_grad(target.data_ptr(), t_stride, value.data_ptr(), v_stride, batch, samples,
                                         ctypes.cast(sizes, ctypes.c_void_p), ctypes.cast(wptr, ctypes.c_void_p), n, float(mag_weight), float(logmag_weight),
-                                        float(eps), int(bool(l2)), int(bool(per_clip)), loss.data_ptr(), _ptr(grad), ws.data_ptr(), ws.numel(),
+                                        float(eps), int(bool(l2)), int(bool(per_clip)), float(post_scale), loss.data_ptr(), _ptr(grad), ws.data_ptr(), ws.numel(),
                                         stream_ptr(value.device)))
     return loss, grad
 

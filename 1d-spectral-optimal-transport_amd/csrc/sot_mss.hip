@@ -63,6 +63,7 @@ struct MssArgs {
     int ranges;                                       // 256-point ranges per clip: ceil(ceil(samples / 2) / 256)
     int slot_info[32];                                // scale | piece << 8: which scale and which 256-point piece of its waves' spans a slot holds (dwords: scalar loads)
     float mag_weight, logmag_weight, eps; int l2, per_clip, want_grad;
+    float post_scale;                                 // multiplies the finished float32 loss value(s) and gradient entries (a caller's `* weight`, losses.py:360): one more float32 product
     double* partial_loss;                             // [task]
     float* partial_grad;                              // [clip][range r][slot][256 points]: the wave w of a scale writes piece j of its span (256 + 3 m / 4
                                                       // packed points) into slot slot_base[s] + j of range r = w + j: all a range needs is contiguous
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
                 for (int c = 0; c < a.waves[s]; ++c) acc += a.partial_loss[a.task_base[s] + o * a.waves[s] + c];
                 total += (float)(acc * a.inv_count[s]);
             }
-            a.loss[o] = total;
+            a.loss[o] = total * a.post_scale;
         }
     } else if (blockIdx.x == 0 && !MSS_DIAG_NO_LOSS) {      // (the FIRST workgroup: it is resident from the start, so the reduction runs beside the other workgroups' gathers, not behind them)
         // all clips: per scale a fixed-order sum of the task partials -- thread t adds partials t, t + 256, ... of every scale, the waves reduce by
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
                 const float ms = __shfl(mean_s, sc);
                 if (sc < a.n_scales) total += ms;                // losses.py:411-424
             }
-            if (sl == 0) a.loss[0] = total;
+            if (sl == 0) a.loss[0] = total * a.post_scale;
         }
     }
     if (!a.want_grad) return;
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(kFinishThreads) void mss_finish_kernel(const MssArg
             }
         }
         MSS_STAMP(12);
+        g0x *= a.post_scale; g0y *= a.post_scale; g1x *= a.post_scale; g1y *= a.post_scale;
         float* const dst = a.grad + (int64_t)b * a.samples + 2 * (int64_t)p;
         const int64_t left = a.samples - 2 * (int64_t)p;        // samples of the clip from 2 p on
         if (left >= 4 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) *reinterpret_cast<float4*>(dst) = make_float4(g0x, g0y, g1x, g1y);
@@ -563,7 +565,7 @@ size_t sot_mss_workspace_bytes(int64_t batch, int64_t samples, const int* fft_si
 
 int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const float* value, int64_t value_row_stride, int64_t batch,
                           int64_t samples, const int* fft_sizes, const float* const* windows, int n_scales, float mag_weight,
-                          float logmag_weight, float eps, int l2, int per_clip, float* loss, float* grad_value, void* workspace,
+                          float logmag_weight, float eps, int l2, int per_clip, float post_scale, float* loss, float* grad_value, void* workspace,
                           size_t workspace_bytes, void* stream)
 {
     using namespace sot_mss;
@@ -580,7 +582,7 @@ int sot_mss_loss_and_grad(const float* target, int64_t target_row_stride, const 
     if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return SOT_ERR_BAD_SHAPE;   // 16-byte loads of the span pieces
     a.partial_loss = reinterpret_cast<double*>(workspace);
     a.partial_grad = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + grad_off);
-    a.loss = loss; a.grad = grad_value; a.want_grad = grad_value != nullptr;
+    a.loss = loss; a.grad = grad_value; a.want_grad = grad_value != nullptr; a.post_scale = post_scale;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     (void)hipGetLastError();
     int dev = 0;

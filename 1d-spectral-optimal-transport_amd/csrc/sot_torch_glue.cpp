@@ -409,7 +409,7 @@ public:
         at::Tensor gv = grad ? at::empty({clips, samples}, target.options()) : at::Tensor();
         check_status(g_api.mss(target.data_ptr<float>(), clips > 1 ? target.stride(0) : samples, estimate.data_ptr<float>(),
                                clips > 1 ? estimate.stride(0) : samples, clips, samples, sizes, wins, n, (float)mag_weight, (float)logmag_weight, 1e-5f,
-                               l2 ? 1 : 0, per_clip ? 1 : 0, loss.data_ptr<float>(), grad ? gv.data_ptr<float>() : nullptr, ws.data_ptr(), ws_bytes,
+                               l2 ? 1 : 0, per_clip ? 1 : 0, 1.0f, loss.data_ptr<float>(), grad ? gv.data_ptr<float>() : nullptr, ws.data_ptr(), ws_bytes,
                                current_stream(target)), 1.0);
         if (grad) ctx->saved_data["gv"] = gv;
         ctx->saved_data["per_clip"] = per_clip;
@@ -449,7 +449,7 @@ public:
     static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& target, const at::Tensor& estimate,
                               const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos, int64_t n_fft, int64_t hop, double p, int64_t flags,
                               const std::vector<at::Tensor>& mss_windows, const std::vector<int64_t>& mss_sizes, double mag_weight,
-                              double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions, bool exact, bool grad)
+                              double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions, bool grad)
     {
         TORCH_CHECK(target.is_cuda() && target.scalar_type() == at::kFloat && target.dim() == 2 && target.is_contiguous() &&
                     estimate.is_cuda() && estimate.scalar_type() == at::kFloat && estimate.is_contiguous() && estimate.sizes() == target.sizes() &&
@@ -498,22 +498,19 @@ public:
         if (grad) {
             gy = at::empty({clips, frames, bins}, target.options());
             check_status(g_api.loss_and_grad(&pr, rows.data_ptr<float>(), (double)pr.B, sot_mean.data_ptr<float>(), nullptr,
-                                             (float)((exact ? 1.0 : w_sot) / (double)pr.B), gy.data_ptr<float>(), nullptr, nullptr, 0, st), p);
-            if (exact && w_sot != 1.0) gy.mul_(w_sot);   // the composition's sot_scale_inplace by fl(g * w_sot), g = 1
+                                             (float)(1.0 / (double)pr.B), gy.data_ptr<float>(), nullptr, nullptr, 0, st), p);
+            if (w_sot != 1.0) gy.mul_(w_sot);   // the composition's sot_scale_inplace by fl(g * w_sot), g = 1 (the paper's mix: w_sot = 1, nothing to do)
         } else {
             check_status(g_api.loss(&pr, rows.data_ptr<float>(), (double)pr.B, 0, 0.0f, sot_mean.data_ptr<float>(), nullptr, nullptr, nullptr, 0, st), p);
         }
 
-        // MSSLoss and its gradient.  exact: the mix weight is applied as the composition applies it -- `loss_fn(a, b) * weight` is ONE float32
-        // multiplication of the scalar, its backward ONE float32 multiplication of the stored gradient by fl(g * weight) -- so that for the plain
-        // `loss.backward()` (g = 1) loss and gradient equal the module-by-module step's bit for bit.  Otherwise the weight rides on the kernel's two
-        // distance weights: one rounding away (2e-7 of the loss, 3e-8 of the gradient's peak), two small kernels (~5 us at 64 clips) fewer.
-        const double kw = exact ? 1.0 : w_mss;
+        // MSSLoss * w_mss and its gradient.  The mix weight is applied as the composition applies it -- `loss_fn(a, b) * weight` is ONE float32
+        // multiplication of the finished scalar, its backward ONE float32 multiplication of the finished gradient by fl(g * weight) -- inside the
+        // finish kernel (post_scale, ABI 13): for the plain `loss.backward()` (g = 1) loss and gradient equal the module-by-module step's bit for bit.
         check_status(g_api.mss(target.data_ptr<float>(), samples, estimate.data_ptr<float>(), samples, clips, samples, sizes, wins, n,
-                               (float)(mag_weight * kw), (float)(logmag_weight * kw), 1e-5f, l2 ? 1 : 0, 0, mss_loss.data_ptr<float>(),
+                               (float)mag_weight, (float)logmag_weight, 1e-5f, l2 ? 1 : 0, 0, (float)w_mss, mss_loss.data_ptr<float>(),
                                grad ? grad_audio.data_ptr<float>() : nullptr, mss_ws.data_ptr(), mss_bytes, st), 1.0);
-        at::Tensor mss_term = (exact && w_mss != 1.0) ? at::mul(mss_loss, w_mss) : mss_loss;
-        if (grad && exact && w_mss != 1.0) grad_audio.mul_(w_mss);
+        const at::Tensor& mss_term = mss_loss;
         if (grad) {   // d (w_sot * SOT mean) / d estimate, added to the MSS gradient inside the kernel
             const size_t ws_bytes = g_api.stft_backward_ws(clips, samples, (int)n_fft, (int)hop);
             at::Tensor ws = at::empty({(int64_t)(ws_bytes > 0 ? ws_bytes : 1)}, target.options().dtype(at::kByte));
@@ -536,20 +533,20 @@ public:
         const c10::hip::HIPGuardMasqueradingAsCUDA guard(grad_audio.device());
         at::Tensor out = grad_audio * g;   // the stored gradient is never modified: a retained graph can be walked again
         return {at::Tensor(), out, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
 };
 
 std::vector<at::Tensor> mix_loss_step(const at::Tensor& target, const at::Tensor& estimate, const at::Tensor& window, const at::Tensor& xpos, const at::Tensor& ypos,
                          int64_t n_fft, int64_t hop, double p, int64_t flags, const std::vector<at::Tensor>& mss_windows,
-                         const std::vector<int64_t>& mss_sizes, double mag_weight, double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions, bool exact)
+                         const std::vector<int64_t>& mss_sizes, double mag_weight, double logmag_weight, bool l2, double w_mss, double w_sot, bool unit_positions)
 {
     TORCH_CHECK(g_api.mss != nullptr && g_api.stft_pair != nullptr, "sot glue: bind() has not been called");
     TORCH_CHECK(!(at::GradMode::is_enabled() && (target.requires_grad() || xpos.requires_grad() || ypos.requires_grad())),
                 "sot glue: gradients w.r.t. the target or the positions are not this path's case");
     const bool grad = at::GradMode::is_enabled() && estimate.requires_grad();
     return MixLossStep::apply(target, estimate, window, xpos, ypos, n_fft, hop, p, flags, mss_windows, mss_sizes, mag_weight, logmag_weight, l2, w_mss,
-                              w_sot, unit_positions, exact, grad);
+                              w_sot, unit_positions, grad);
 }
 
 }  // namespace

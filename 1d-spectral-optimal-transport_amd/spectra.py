@@ -463,9 +463,6 @@ def hz_to_unit(hz, hz_min=20.0, hz_max=8000.0, clip: bool = False) -> torch.Tens
 
 
 FUSED_TRAINER_STEP = True    # module switch: trainer_loss_step may take the one-node form below (tests and the bench compare both)
-FUSED_STEP_EXACT = True      # the one-node form applies the mix weights as the composition does (two small kernels): loss and gradient of a plain
-                             # `loss.backward()` equal the module-by-module step's BIT FOR BIT; False: the weights ride on the MSS kernel's distance
-                             # weights and the SOT's gradient scale -- one rounding away (2e-7 / 3e-8 of the peak), ~5 us less at the paper's 64 clips
 
 
 def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_positions=False, terms=None):
@@ -508,7 +505,7 @@ def _fused_mix_step(loss_fn, x, x_hat, x_pos, y_pos, n_fft, hop, window, unit_po
         flags |= nat.FLAG_TIE_FREE_GRADIENT
     total, mss_term, sot_term = glue.mix_loss_step(x, x_hat, _cached_window(window, n_fft, x.device), x_pos, y_pos, int(n_fft), int(hop), float(sot.p),
                                                    int(flags), _cached_windows(None, sizes, x.device), list(sizes), float(mss.mag_weight),
-                                                   float(mss.logmag_weight), kind == "L2", w_mss, w_sot, bool(unit_positions), bool(FUSED_STEP_EXACT))
+                                                   float(mss.logmag_weight), kind == "L2", w_mss, w_sot, bool(unit_positions))
     if terms is not None:   # what the trainer logs per loss (trainer.py:231-236): `(loss_fn(...) * weight).mean()`, values only
         for fn in fns:      # in the order of the mix, like the reference's dict
             terms[fn.__class__.__name__] = mss_term if fn is mss else sot_term

@@ -701,15 +701,8 @@ def paper_loss_workloads(dev, nat, timed, n):
         out[f"paper_loss_step_{tag}_module_by_module"] = entry(timed(lambda i: full_step(i, False, False), n), "the same step composed module by module as the reference's trainer does (fused=False: rounds 4-5's form), device positions, eager")
         out[f"mssloss_forward_backward_{tag}"] = entry(timed(mss_step, n), "MSSLoss(6 scales, L1, mag_weight 1) forward + backward into the estimate, eager")
         out[f"sot_slice_forward_backward_{tag}"] = entry(timed(sot_step, n), "STFT pair + Wasserstein1D (paper mode) forward + backward, eager (= config 5's slice)")
-        def folded_step(i):   # the one-node form with the mix weights inside the kernels (one rounding away from the composition instead of bit-identical)
-            spectra.FUSED_STEP_EXACT = False
-            try:
-                full_step(i, False)
-            finally:
-                spectra.FUSED_STEP_EXACT = True
-
         for key, fn in ((f"paper_loss_step_{tag}", lambda i: full_step(i, False)), (f"paper_loss_step_{tag}_module_by_module", lambda i: full_step(i, False, False)),
-                        (f"paper_loss_step_{tag}_folded_weights", folded_step), (f"mssloss_forward_backward_{tag}", mss_step),
+                        (f"mssloss_forward_backward_{tag}", mss_step),
                         (f"sot_slice_forward_backward_{tag}", sot_step)):
             try:
                 out[key + "_graph_replay"] = entry(replayed(fn), "the same kernels replayed from ONE HIP graph (GPU time of the block)")
@@ -840,7 +833,6 @@ def flatten_for_scalar_readers(rec, B, N):
         "paper_step_64clips_eager_ms": ms_of("paper_loss_step_64clips"),
         "paper_step_256clips_graph_ms": ms_of("paper_loss_step_256clips_graph_replay"),
         "paper_step_64clips_module_by_module_graph_ms": ms_of("paper_loss_step_64clips_module_by_module_graph_replay"),
-        "paper_step_64clips_folded_weights_graph_ms": ms_of("paper_loss_step_64clips_folded_weights_graph_replay"),
         "mss_64clips_graph_ms": ms_of("mssloss_forward_backward_64clips_graph_replay"),
         "mss_256clips_graph_ms": ms_of("mssloss_forward_backward_256clips_graph_replay"),
         "sot_slice_64clips_graph_ms": ms_of("sot_slice_forward_backward_64clips_graph_replay"),

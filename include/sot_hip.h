@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SOT_ABI_VERSION 12   /* bumped on every change of a signature or of a buffer contract below; the binding checks it
+#define SOT_ABI_VERSION 13   /* bumped on every change of a signature or of a buffer contract below; the binding checks it
                               * (11, round 6: sot_workspace_bytes covers the per-row pre-sort; the MSS workspace is 16-byte aligned) */
 
 typedef enum sot_status {
@@ -387,6 +387,8 @@ int sot_spec_distance_rows_backward(const float *target, const float *value, int
  *   loss = sum_s [mag_weight * mean D(T_s - V_s) + logmag_weight * mean D(slog T_s - slog V_s)]      (per_clip == 0: one float;
  *   per_clip != 0: the means run over each clip's own spectrogram, `dims` = its two axes: loss[batch]),
  *   grad_value[b, t] = d loss (or d loss[b]) / d value[b, t]   (NULL: forward only; the caller applies its upstream gradient).
+ * post_scale (ABI 13): the finished float32 loss value(s) and gradient entries are multiplied by it -- the `loss_fn(x, y) * weight` of
+ *   MixOfLosses (losses.py:360) and its backward as ONE more float32 product each, i.e. the same floats as the two torch kernels; 1 = off.
  * target / value: [batch, samples] float32 with the given row strides (in floats); fft_sizes[n_scales]: powers of two in [64, 2048],
  * n_scales <= 8; windows[s]: n_fft taps of scale s, device pointers on 8-byte boundaries (host array of device pointers).
  * One workgroup per (scale, clip, 4096-sample chunk): 2048 / n_fft frames per wavefront through a register-resident FFT, magnitudes,
@@ -396,7 +398,7 @@ int sot_spec_distance_rows_backward(const float *target, const float *value, int
 size_t sot_mss_workspace_bytes(int64_t batch, int64_t samples, const int *fft_sizes, int n_scales);
 int sot_mss_loss_and_grad(const float *target, int64_t target_row_stride, const float *value, int64_t value_row_stride,
                           int64_t batch, int64_t samples, const int *fft_sizes, const float *const *windows, int n_scales,
-                          float mag_weight, float logmag_weight, float eps, int l2, int per_clip,
+                          float mag_weight, float logmag_weight, float eps, int l2, int per_clip, float post_scale,
                           float *loss /* [1] or [batch] */, float *grad_value /* [batch, samples] contiguous, or NULL */,
                           void *workspace, size_t workspace_bytes, void *stream);
 

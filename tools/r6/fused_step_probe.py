@@ -1,6 +1,6 @@
 """The paper's loss step as ONE autograd node (spectra._fused_mix_step / csrc/sot_torch_glue.cpp: MixLossStep) against the module-by-module
 composition: loss and gradient differences, then GPU time replayed from a HIP graph and host-launched time, at 64 and 256 clips.
-python3 tools/r6/fused_step_probe.py [modes: m (module by module), n (one node, the default exact form), f (one node with the mix weights inside the kernels: spectra.FUSED_STEP_EXACT = False); default mnf] [compare=1]"""
+python3 tools/r6/fused_step_probe.py [modes: m (module by module), n (one node); default mn] [compare=1]"""
 import faulthandler
 import functools
 import os
@@ -48,8 +48,8 @@ def replayed(step_fn):
     return timed(lambda i: graph.replay())
 
 
-MODES = {"m": ("module by module", False), "n": ("one node", True), "f": ("one node, folded weights", "folded")}
-modes = [MODES[c] for c in (sys.argv[1] if len(sys.argv) > 1 else "mnf")]
+MODES = {"m": ("module by module", False), "n": ("one node", True)}
+modes = [MODES[c] for c in (sys.argv[1] if len(sys.argv) > 1 else "mn")]
 compare = (sys.argv[2] if len(sys.argv) > 2 else "1") == "1"
 for clips in (64, 256):
     gen = torch.Generator(device=dev).manual_seed(1000 + clips)
@@ -57,8 +57,6 @@ for clips in (64, 256):
     hats = [spectra.harmonic_batch(clips, generator=gen, device=dev).requires_grad_(True) for _ in range(2)]
 
     def step(i, fused):
-        spectra.FUSED_STEP_EXACT = fused != "folded"
-        fused = bool(fused)
         e = hats[i % 2]
         e.grad = None
         loss = spectra.trainer_loss_step(mix, x, e, positions=freqs, fused=fused)
@@ -72,9 +70,9 @@ for clips in (64, 256):
         del loss   # (a loss kept alive keeps the estimate's AccumulateGrad node of the DEFAULT stream alive: a capture on another stream then dies in capture_end)
     base_l, base_g = res.get("module by module", (0, 0))
     for name, (l, g) in res.items():
-        print(f"{clips} clips, {name:25s}: loss {l:.9g} (rel diff {abs(l - base_l) / abs(base_l):.2e}), gradient max diff / peak "
+        print(f"{clips} clips, {name:16s}: loss {l:.9g} (rel diff {abs(l - base_l) / abs(base_l):.2e}), gradient max diff / peak "
               f"{float((g - base_g).abs().max() / base_g.abs().max()):.2e}")
     for name, fused in modes:
         eager = timed(lambda i: step(i, fused))
         graph = replayed(lambda i: step(i, fused))
-        print(f"{clips} clips, {name:25s}: eager {eager:7.1f} us, graph replay {graph:7.1f} us")
+        print(f"{clips} clips, {name:16s}: eager {eager:7.1f} us, graph replay {graph:7.1f} us")
