@@ -2235,9 +2235,9 @@ int run_forward(const sot_problem* pr, float* row_loss, float* uq, float* vq, fl
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 512)
     full_rt = false;
 #endif
-    // per-row positions with their permutations at hand (handed in, or just written by the pre-sort kernel), 2048-point rows: the compile-time-length
-    // kernel with a position copy of its own per row (sot_forward_full.inc: RP)
-    bool full_rp = l.rowpos && l.a.perm_in != nullptr && !quant && pr->n == 2048 && pr->m == 2048 && l.vec && (pr->flags & SOT_FLAG_REQUIRE_SORT) &&
+    // per-row positions with their permutations at hand (handed in, or just written by the pre-sort kernel), 2048- / 1024- / 512-point rows: the
+    // compile-time-length kernel with a position copy of its own per row (sot_forward_full.inc: RP)
+    bool full_rp = l.rowpos && l.a.perm_in != nullptr && !quant && (pr->n == 2048 || pr->n == 1024 || pr->n == 512) && pr->m == pr->n && l.vec && (pr->flags & SOT_FLAG_REQUIRE_SORT) &&
                    (reinterpret_cast<uintptr_t>(l.a.perm_in) & 15) == 0 && !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full_rp = false;
@@ -2279,8 +2279,8 @@ int run_backward(const sot_problem* pr, const float* grad_row, int64_t grad_row_
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 1024)
     full_rt = false;
 #endif
-    // per-row positions with their permutations at hand, 2048-point rows: the compile-time-length kernel with a position copy of its own per row
-    bool full_rp = l.rowpos && b.f.perm_in != nullptr && pr->n == 2048 && pr->m == 2048 && l.vec && (pr->flags & SOT_FLAG_REQUIRE_SORT) &&
+    // per-row positions with their permutations at hand, 2048- / 512-point rows: the compile-time-length kernel with a position copy of its own per row
+    bool full_rp = l.rowpos && b.f.perm_in != nullptr && (pr->n == 2048 || pr->n == 512) && pr->m == pr->n && l.vec && (pr->flags & SOT_FLAG_REQUIRE_SORT) &&
                    (reinterpret_cast<uintptr_t>(b.f.perm_in) & 15) == 0 && !(pr->flags & (SOT_FLAG_PRENORMALIZED | SOT_FLAG_NO_SPECIALIZE));
 #if defined(SOT_STUB_MISSING_PARTS) && !(SOT_PART & 128)
     full_rp = false;

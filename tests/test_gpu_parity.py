@@ -556,8 +556,9 @@ def test_segmented_sort_adversarial_keys(n):
     assert torch.equal(got_v.cpu(), want_v) and torch.equal(got_i.cpu(), want_i)
 
 
-@pytest.mark.parametrize("shape", [(9, 2, 2), (5, 50, 70), (7, 300, 411), (6, 512, 512), (5, 1000, 1024), (4, 1025, 1025), (4, 1536, 1400), (6, 2048, 2048), (5, 2048, 2000)])
-@pytest.mark.parametrize("mode", ["p1", "cutoff"])
+@pytest.mark.parametrize("shape", [(9, 2, 2), (5, 50, 70), (7, 300, 411), (6, 512, 512), (5, 1000, 1024), (7, 1024, 1024), (4, 1025, 1025), (4, 1536, 1400), (6, 2048, 2048),
+                                   (5, 2048, 2000)])
+@pytest.mark.parametrize("mode", ["p1", "cutoff", "nocut", "p3"])
 def test_rowpos_presort_kernel_on_every_route(shape, mode):
     """Round 6: per-row positions that nobody has sorted are sorted AHEAD of the row kernel by sot_rowpos_sort_kernel (one wavefront per row,
     permutations into the caller's row_perm_out or the workspace); the row kernels gather through them.  Arrays that arrive sorted get the

@@ -56,7 +56,8 @@ def run(budget=120.0, seed0=0, max_cases=None, grad_tol=2e-4, verbose=True):
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         seed = int(rng.integers(0, 2 ** 31 - 1))
         g = torch.Generator().manual_seed(seed)
-        n = 2048 if rng.random() < 0.6 else int(rng.choice(LENGTHS))
+        r = rng.random()
+        n = 2048 if r < 0.4 else 1024 if r < 0.55 else 512 if r < 0.7 else int(rng.choice(LENGTHS))    # the three RP geometries most of the time
         m = n if rng.random() < 0.8 else (2048 if rng.random() < 0.3 else int(rng.choice(LENGTHS)))
         B = int(rng.integers(1, 40)) if rng.random() < 0.9 else int(rng.integers(200, 700))
         mix = rng.random() < 0.6          # a different kind on every row, or one kind for the batch
@@ -128,7 +129,13 @@ def run(budget=120.0, seed0=0, max_cases=None, grad_tol=2e-4, verbose=True):
             fail("ERROR backward", error=str(e))
             continue
         if not (torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1]) and torch.equal(g0[0], g2[0]) and torch.equal(g0[1], g2[1]) and torch.equal(g0[1], gy_only)):
-            fail("BACKWARD routes differ")
+            worst = {}
+            for nm, a_, b_ in (("gx default", g0[0], g1[0]), ("gy default", g0[1], g1[1]), ("gx stored", g0[0], g2[0]), ("gy stored", g0[1], g2[1]), ("gy alone", g0[1], gy_only)):
+                d = (a_ - b_).abs()
+                if float(d.max()) > 0:
+                    r = int(d.max(dim=1).values.argmax())
+                    worst[nm] = (f"{float(d.max() / a_.abs().max(dim=1).values[r].clamp_min(1e-30)):.2e}", f"row {r} ({rows_kind[r]})", f"{int((d[r] > 0).sum())} entries")
+            fail("BACKWARD routes differ", **worst)
         if not (torch.equal(q0[0], q1[0]) and torch.equal(q0[1], q1[1])):
             fail("POSITION GRADIENT routes differ")
         wx, wy = so.backward(x.numpy(), y.numpy(), xpos.numpy(), ypos.numpy(), (0.5 * grow).numpy(), p=p, flags=flags & 15)
